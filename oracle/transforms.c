@@ -1,0 +1,281 @@
+/*
+ * transforms.c -- ORACLE (test infrastructure, see vko.h): seed -> 32-byte private key.
+ *
+ * Each function names the reference lines it restates.  MT19937 / MT19937-64 live in the
+ * un-vendored crate rand_mt 4.2.2 (call sites src/transform/milksad.rs:22-24,
+ * src/mt64.rs:16-18); they are restated from Matsumoto & Nishimura's init_genrand /
+ * init_genrand64 + genrand, with the crate's fill_bytes byte order (little-endian words,
+ * confirmed by the reference's own GPU host code src/gpu/mt19937.rs:216-226).
+ */
+#include "vko.h"
+#include <stdio.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- MT19937 */
+/* src/transform/milksad.rs:17-29: only inputs <= u32::MAX; key = first 32 bytes of
+ * Mt::new(seed).fill_bytes = 8 tempered outputs, each little-endian.  Full 624-word
+ * state on purpose (the device uses a rolling window; this is the independent form). */
+int vko_milksad_key(uint64_t seed, uint8_t key[32])
+{
+    if (seed > 0xFFFFFFFFull) return 0;
+    static const int N = 624, M = 397;
+    uint32_t mt[624];
+    mt[0] = (uint32_t)seed;
+    for (int i = 1; i < N; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    /* one full twist */
+    for (int k = 0; k < N; k++) {
+        uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % N] & 0x7fffffffu);
+        mt[k] = mt[(k + M) % N] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (int i = 0; i < 8; i++) {
+        uint32_t y = mt[i];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        key[4 * i] = (uint8_t)y; key[4 * i + 1] = (uint8_t)(y >> 8);
+        key[4 * i + 2] = (uint8_t)(y >> 16); key[4 * i + 3] = (uint8_t)(y >> 24);
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------- MT19937-64 */
+/* src/mt64.rs:15-20: Mt64::new(seed).fill_bytes(32) = 4 outputs, each little-endian. */
+int vko_mt64_key(uint64_t seed, uint8_t key[32])
+{
+    static const int NN = 312, MM = 156;
+    uint64_t mt[312];
+    mt[0] = seed;
+    for (int i = 1; i < NN; i++) mt[i] = 6364136223846793005ULL * (mt[i - 1] ^ (mt[i - 1] >> 62)) + (uint64_t)i;
+    for (int k = 0; k < NN; k++) {
+        uint64_t x = (mt[k] & 0xFFFFFFFF80000000ULL) | (mt[(k + 1) % NN] & 0x7FFFFFFFULL);
+        mt[k] = mt[(k + MM) % NN] ^ (x >> 1) ^ ((x & 1ULL) ? 0xB5026F5AA96619E9ULL : 0ULL);
+    }
+    for (int i = 0; i < 4; i++) {
+        uint64_t x = mt[i];
+        x ^= (x >> 29) & 0x5555555555555555ULL;
+        x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+        x ^= (x << 37) & 0xFFF7EEE000000000ULL;
+        x ^= x >> 43;
+        for (int j = 0; j < 8; j++) key[8 * i + j] = (uint8_t)(x >> (8 * j));
+    }
+    return 1;
+}
+
+/* -------------------------------------------------------------------- LCG */
+/* src/lcg.rs:68-103 constants, :107-109 lcg_next, :114-128 generate_key;
+ * seed filter `val <= variant.max_seed()` src/transform/lcg.rs:52. */
+static const struct { const char *name; uint64_t a, c, m; } LCG[4] = {
+    {"glibc", 1103515245ull, 12345ull, 1ull << 31},
+    {"minstd", 16807ull, 0ull, (1ull << 31) - 1},
+    {"msvc", 214013ull, 2531011ull, 1ull << 32},
+    {"borland", 22695477ull, 1ull, 1ull << 32},
+};
+
+int vko_lcg_key(uint64_t seed, uint32_t variant, uint32_t little_endian, uint8_t key[32])
+{
+    if (variant >= 4) return 0;
+    if (seed > LCG[variant].m - 1) return 0;
+    uint64_t state = (uint32_t)seed;
+    for (int i = 0; i < 8; i++) {
+        state = (LCG[variant].a * state + LCG[variant].c) % LCG[variant].m; /* wrapping u64, then mod */
+        uint32_t w = (uint32_t)state;
+        if (little_endian) {
+            key[4 * i] = (uint8_t)w; key[4 * i + 1] = (uint8_t)(w >> 8);
+            key[4 * i + 2] = (uint8_t)(w >> 16); key[4 * i + 3] = (uint8_t)(w >> 24);
+        } else {
+            key[4 * i] = (uint8_t)(w >> 24); key[4 * i + 1] = (uint8_t)(w >> 16);
+            key[4 * i + 2] = (uint8_t)(w >> 8); key[4 * i + 3] = (uint8_t)w;
+        }
+    }
+    return 1;
+}
+
+/* --------------------------------------------------------------- xorshift */
+static inline uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+/* src/xorshift.rs:286-291 */
+static uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9e3779b97f4a7c15ULL;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+    return x ^ (x >> 31);
+}
+
+static void put_be64(uint8_t *p, uint64_t v) { for (int j = 0; j < 8; j++) p[j] = (uint8_t)(v >> (56 - 8 * j)); }
+static void put_be32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; }
+
+/* variants in ALL_VARIANTS order (src/xorshift.rs:69-74):
+ * 0 xorshift64 (:83-119), 1 xorshift128 (:134-172), 2 xorshift128+ (:186-224),
+ * 3 xoroshiro128** (:238-276).  Every variant maps seed 0 -> 1 and fills big-endian. */
+int vko_xorshift_key(uint64_t seed, uint32_t variant, uint8_t key[32])
+{
+    if (seed == 0) seed = 1;
+    switch (variant) {
+    case 0: {
+        uint64_t x = seed;
+        for (int i = 0; i < 4; i++) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            put_be64(key + 8 * i, x);
+        }
+        return 1;
+    }
+    case 1: {
+        uint32_t x = (uint32_t)seed, y = (uint32_t)(seed >> 32);
+        uint32_t z = (uint32_t)seed ^ 0x12345678u, w = (uint32_t)((seed >> 32) ^ 0x87654321ull);
+        for (int i = 0; i < 8; i++) {
+            uint32_t t = x ^ (x << 11);
+            x = y; y = z; z = w;
+            w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+            put_be32(key + 4 * i, w);
+        }
+        return 1;
+    }
+    case 2:
+    case 3: {
+        uint64_t s0 = splitmix64(seed), s1 = splitmix64(s0);
+        for (int i = 0; i < 4; i++) {
+            uint64_t r = (variant == 2) ? s0 + s1 : rotl64(s0 * 5, 7) * 9;
+            uint64_t t = s1 ^ s0;
+            s0 = rotl64(s0, 24) ^ t ^ (t << 16);
+            s1 = rotl64(t, 37);
+            put_be64(key + 8 * i, r);
+        }
+        return 1;
+    }
+    default: return 0;
+    }
+}
+
+/* ----------------------------------------------------------- sha256_chain */
+/* variants in ALL_VARIANTS order (src/sha256_chain.rs:74-79): 0 iterated, 1 indexed:be,
+ * 2 indexed:le, 3 counter.  generate_key_at_index: src/sha256_chain.rs:88-118. */
+int vko_sha256_chain_key(const uint8_t *seed, size_t seedlen, uint32_t variant, uint32_t index, uint8_t key[32])
+{
+    uint8_t buf[96];
+    if (seedlen > 64) return 0;
+    switch (variant) {
+    case 0:
+        vko_sha256(seed, seedlen, key);
+        for (uint32_t i = 0; i < index; i++) { uint8_t t[32]; vko_sha256(key, 32, t); memcpy(key, t, 32); }
+        return 1;
+    case 1:
+    case 2:
+        memcpy(buf, seed, seedlen);
+        if (variant == 1) put_be32(buf + seedlen, index);
+        else { buf[seedlen] = (uint8_t)index; buf[seedlen + 1] = (uint8_t)(index >> 8); buf[seedlen + 2] = (uint8_t)(index >> 16); buf[seedlen + 3] = (uint8_t)(index >> 24); }
+        vko_sha256(buf, seedlen + 4, key);
+        return 1;
+    case 3: {
+        memcpy(buf, seed, seedlen);
+        int n = snprintf((char *)buf + seedlen, sizeof buf - seedlen, "%u", index);
+        vko_sha256(buf, seedlen + (size_t)n, key);
+        return 1;
+    }
+    default: return 0;
+    }
+}
+
+/* --------------------------------------------------- generic (spec, seed, slot) */
+static const char *XS_NAME[4] = {"xorshift64", "xorshift128", "xorshift128+", "xoroshiro128**"};
+static const char *CH_NAME[4] = {"iterated", "indexed:be", "indexed:le", "counter"};
+
+uint32_t vko_slots_per_input(const vko_spec *s)
+{
+    switch (s->kind) {
+    case VKO_T_SHA256: return 3;
+    case VKO_T_MILKSAD:
+    case VKO_T_MT64: return 1;
+    case VKO_T_LCG:
+    case VKO_T_XORSHIFT: return s->variant == VKO_VARIANT_ALL ? 4 : 1;
+    case VKO_T_SHA256_CHAIN: return 2u * (s->variant == VKO_VARIANT_ALL ? 4u : 1u) * s->chain_depth;
+    default: return 0;
+    }
+}
+
+/* Emit order inside one input == ascending sub_index (the order apply_batch pushes). */
+int vko_transform_key(const vko_spec *s, uint64_t seed, uint32_t sub, uint8_t key[32])
+{
+    char dec[24];
+    int dl = snprintf(dec, sizeof dec, "%llu", (unsigned long long)seed); /* Input::from_u64, src/transform/input.rs:22-30 */
+    switch (s->kind) {
+    case VKO_T_SHA256: { /* src/transform/sha256.rs:14-28: string, BE8, LE8 */
+        uint8_t b[8];
+        if (sub == 0) { vko_sha256((const uint8_t *)dec, (size_t)dl, key); return 1; }
+        if (sub == 1) { for (int j = 0; j < 8; j++) b[j] = (uint8_t)(seed >> (56 - 8 * j)); vko_sha256(b, 8, key); return 1; }
+        if (sub == 2) { for (int j = 0; j < 8; j++) b[j] = (uint8_t)(seed >> (8 * j)); vko_sha256(b, 8, key); return 1; }
+        return 0;
+    }
+    case VKO_T_MILKSAD: return sub == 0 ? vko_milksad_key(seed, key) : 0;
+    case VKO_T_MT64: return sub == 0 ? vko_mt64_key(seed, key) : 0;
+    case VKO_T_LCG: {
+        uint32_t v = s->variant == VKO_VARIANT_ALL ? sub : s->variant;
+        if (s->variant != VKO_VARIANT_ALL && sub != 0) return 0;
+        return vko_lcg_key(seed, v, s->endian, key);
+    }
+    case VKO_T_XORSHIFT: {
+        uint32_t v = s->variant == VKO_VARIANT_ALL ? sub : s->variant;
+        if (s->variant != VKO_VARIANT_ALL && sub != 0) return 0;
+        return vko_xorshift_key(seed, v, key);
+    }
+    case VKO_T_SHA256_CHAIN: { /* src/transform/sha256_chain.rs:60-94 */
+        uint32_t nv = s->variant == VKO_VARIANT_ALL ? 4u : 1u, d = s->chain_depth;
+        if (d == 0 || sub >= 2 * nv * d) return 0;
+        uint32_t form = sub / (nv * d), r = sub % (nv * d);
+        uint32_t v = s->variant == VKO_VARIANT_ALL ? r / d : s->variant, idx = r % d;
+        if (form == 0) return vko_sha256_chain_key((const uint8_t *)dec, (size_t)dl, v, idx, key);
+        if (seed > 0xFFFFFFFFull) return 0;
+        uint8_t be[4];
+        put_be32(be, (uint32_t)seed);
+        return vko_sha256_chain_key(be, 4, v, idx, key);
+    }
+    default: return 0;
+    }
+}
+
+int vko_transform_label(const vko_spec *s, uint64_t seed, uint32_t sub, char *out, size_t cap)
+{
+    unsigned long long sd = seed;
+    switch (s->kind) {
+    case VKO_T_SHA256:
+    case VKO_T_MILKSAD:
+    case VKO_T_MT64: return snprintf(out, cap, "%llu", sd);
+    case VKO_T_LCG: /* src/transform/lcg.rs:54-66 */
+        if (s->variant != VKO_VARIANT_ALL) return snprintf(out, cap, "%llu", sd);
+        if (sub >= 4) return -1;
+        return s->endian ? snprintf(out, cap, "%llu:%s:le", sd, LCG[sub].name) : snprintf(out, cap, "%llu:%s", sd, LCG[sub].name);
+    case VKO_T_XORSHIFT: /* src/transform/xorshift.rs:43-47 */
+        if (s->variant != VKO_VARIANT_ALL) return snprintf(out, cap, "%llu", sd);
+        if (sub >= 4) return -1;
+        return snprintf(out, cap, "%llu:%s", sd, XS_NAME[sub]);
+    case VKO_T_SHA256_CHAIN: { /* src/transform/sha256_chain.rs:67,88 */
+        uint32_t nv = s->variant == VKO_VARIANT_ALL ? 4u : 1u, d = s->chain_depth;
+        if (d == 0 || sub >= 2 * nv * d) return -1;
+        uint32_t r = sub % (nv * d);
+        uint32_t v = s->variant == VKO_VARIANT_ALL ? r / d : s->variant, idx = r % d;
+        return snprintf(out, cap, "%llu[%s:%u]", sd, CH_NAME[v & 3], idx);
+    }
+    default: return -1;
+    }
+}
+
+const char *vko_transform_name(const vko_spec *s)
+{
+    switch (s->kind) {
+    case VKO_T_SHA256: return "sha256";
+    case VKO_T_MILKSAD: return "milksad";
+    case VKO_T_MT64: return "mt64";
+    case VKO_T_LCG: return "lcg";
+    case VKO_T_XORSHIFT: return "xorshift";
+    case VKO_T_SHA256_CHAIN: /* src/transform/sha256_chain.rs:46-58 */
+        switch (s->variant) {
+        case 0: return "sha256_chain:iterated";
+        case 1: return "sha256_chain:indexed:be";
+        case 2: return "sha256_chain:indexed:le";
+        case 3: return "sha256_chain:counter";
+        default: return "sha256_chain";
+        }
+    default: return "?";
+    }
+}

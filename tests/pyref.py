@@ -1,0 +1,64 @@
+"""Independent pure-Python references used to pin the C oracle (tests only).
+
+Nothing here is derived from the reference tree: python ints for secp256k1, hashlib for
+SHA-2, numpy's RandomState for MT19937.
+"""
+import hashlib
+
+P = 2**256 - 2**32 - 977
+N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+GX = 0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798
+GY = 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8
+
+
+def ec_add(a, b):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    if a[0] == b[0]:
+        if (a[1] + b[1]) % P == 0:
+            return None
+        lam = 3 * a[0] * a[0] * pow(2 * a[1], -1, P) % P
+    else:
+        lam = (b[1] - a[1]) * pow(b[0] - a[0], -1, P) % P
+    x = (lam * lam - a[0] - b[0]) % P
+    return x, (lam * (a[0] - x) - a[1]) % P
+
+
+def ec_mul(k):
+    r, q = None, (GX, GY)
+    while k:
+        if k & 1:
+            r = ec_add(r, q)
+        q = ec_add(q, q)
+        k >>= 1
+    return r
+
+
+def normalize(key: bytes) -> int:
+    k = int.from_bytes(key, "big")
+    if k == 0 or k >= N:
+        k %= N
+        if k == 0:
+            k = 1
+    return k
+
+
+def pubkeys(k: int):
+    x, y = ec_mul(k)
+    xb, yb = x.to_bytes(32, "big"), y.to_bytes(32, "big")
+    return bytes([2 | (y & 1)]) + xb, b"\x04" + xb + yb
+
+
+B58 = "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz"
+
+
+def b58check(payload: bytes) -> str:
+    full = payload + hashlib.sha256(hashlib.sha256(payload).digest()).digest()[:4]
+    n = int.from_bytes(full, "big")
+    s = ""
+    while n:
+        n, r = divmod(n, 58)
+        s = B58[r] + s
+    return "1" * (len(full) - len(full.lstrip(b"\0"))) + s

@@ -1,0 +1,234 @@
+"""Pin the oracle's seed->key transforms (oracle/transforms.c).
+
+Reference KATs used: src/lcg.rs:135-174,224-229; README.md:413,438-441 (MT19937).  Where the
+reference has no fixed vectors (mt64, xorshift, sha256 transforms -- SURVEY.md section 8c)
+the pins are independent implementations: numpy RandomState, a python MT19937-64, hashlib,
+and for xorshift a literal python transcription of the published generators.
+"""
+import hashlib
+import random
+import struct
+
+import numpy as np
+import pytest
+
+M32, M64 = 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF
+SEEDS32 = [0, 1, 2, 42, 100, 12345, 2**31 - 2, 2**31 - 1, 2**31, 2**32 - 1, 1610000002]
+SEEDS64 = SEEDS32 + [2**32, 2**63, 2**64 - 1, 0x0123456789ABCDEF]
+
+
+def np_mt_bytes(seed, n):
+    return np.random.RandomState(seed).bytes(n)
+
+
+def test_numpy_mt_matches_reference_readme_vectors():
+    # README.md:438-441 (cascade on seed 100 shows three successive 32-byte draws), README.md:413
+    b = np_mt_bytes(100, 96)
+    assert b[:32].hex() == "08961c8b18dbd0ab4337434767df7b69572fad6c4f00c186b03f43d88af70a26"
+    assert b[32:64].hex() == "5e413501b4371e2862271f1f3550bc2f4236b6abe29ec9350e166bd322c3e673"
+    assert b[64:96].hex() == "f133ff22f0aac1de185139938f664d10e4ac2de46be7d29f3c458e353a1efa85"
+    k = np_mt_bytes(1610000002, 32).hex()
+    assert k.startswith("7ed2") and k.endswith("5055")
+
+
+def test_milksad_vs_numpy(vko):
+    rnd = random.Random(3)
+    for s in SEEDS32 + [rnd.getrandbits(32) for _ in range(300)]:
+        assert vko.milksad_key(s) == np_mt_bytes(s, 32), s
+    assert vko.milksad_key(2**32) is None  # src/transform/milksad.rs:21
+    assert vko.milksad_key(100).hex() == "08961c8b18dbd0ab4337434767df7b69572fad6c4f00c186b03f43d88af70a26"
+
+
+def py_mt64_first(seed, n):
+    NN, MM = 312, 156
+    mt = [seed & M64]
+    for i in range(1, NN):
+        mt.append((6364136223846793005 * (mt[-1] ^ (mt[-1] >> 62)) + i) & M64)
+    for k in range(NN):
+        x = (mt[k] & 0xFFFFFFFF80000000) | (mt[(k + 1) % NN] & 0x7FFFFFFF)
+        mt[k] = mt[(k + MM) % NN] ^ (x >> 1) ^ (0xB5026F5AA96619E9 if x & 1 else 0)
+    out = []
+    for x in mt[:n]:
+        x ^= (x >> 29) & 0x5555555555555555
+        x ^= (x << 17) & 0x71D67FFFEDA60000
+        x ^= (x << 37) & 0xFFF7EEE000000000
+        x ^= x >> 43
+        out.append(x & M64)
+    return out
+
+
+def test_py_mt64_standard_check_value():
+    # ISO C++ [rand.predef]: the 10000th invocation of default mt19937_64 (seed 5489) is 9981545732273789042.
+    NN, MM = 312, 156
+    mt = [5489]
+    for i in range(1, NN):
+        mt.append((6364136223846793005 * (mt[-1] ^ (mt[-1] >> 62)) + i) & M64)
+    idx, val = NN, None
+    for _ in range(10000):
+        if idx >= NN:
+            for k in range(NN):
+                x = (mt[k] & 0xFFFFFFFF80000000) | (mt[(k + 1) % NN] & 0x7FFFFFFF)
+                mt[k] = mt[(k + MM) % NN] ^ (x >> 1) ^ (0xB5026F5AA96619E9 if x & 1 else 0)
+            idx = 0
+        x = mt[idx]; idx += 1
+        x ^= (x >> 29) & 0x5555555555555555
+        x ^= (x << 17) & 0x71D67FFFEDA60000
+        x ^= (x << 37) & 0xFFF7EEE000000000
+        x ^= x >> 43
+        val = x & M64
+    assert val == 9981545732273789042
+    # and the first outputs from the same code path agree with py_mt64_first
+    assert py_mt64_first(5489, 4)[0] == 14514284786278117030  # well-known first output of mt19937_64()
+
+
+def test_mt64_vs_python(vko):
+    rnd = random.Random(4)
+    for s in SEEDS64 + [rnd.getrandbits(64) for _ in range(40)]:
+        exp = b"".join(struct.pack("<Q", v) for v in py_mt64_first(s, 4))
+        assert vko.mt64_key(s) == exp, s
+
+
+def test_lcg_reference_kats(vko):
+    # src/lcg.rs:135-174
+    k = vko.lcg_key(1, 0)
+    assert struct.unpack(">8I", k)[:3] == (1103527590, 377401575, 662824084)
+    assert struct.unpack(">8I", vko.lcg_key(1, 1))[:2] == (16807, 282475249)
+    assert struct.unpack(">8I", vko.lcg_key(1, 2))[0] == 2745024
+    assert struct.unpack(">8I", vko.lcg_key(1, 3))[0] == 22695478
+    assert struct.unpack("<8I", vko.lcg_key(1, 2, le=True))[0] == 2745024
+    # src/lcg.rs:224-229 max_seed + src/transform/lcg.rs:52 filter
+    assert vko.lcg_key(2**31 - 1, 0) is not None and vko.lcg_key(2**31, 0) is None
+    assert vko.lcg_key(2**31 - 2, 1) is not None and vko.lcg_key(2**31 - 1, 1) is None
+    assert vko.lcg_key(2**32 - 1, 2) is not None and vko.lcg_key(2**32, 2) is None
+    assert vko.lcg_key(2**32 - 1, 3) is not None and vko.lcg_key(2**32, 3) is None
+
+
+def test_lcg_vs_python(vko):
+    par = [(1103515245, 12345, 2**31), (16807, 0, 2**31 - 1), (214013, 2531011, 2**32), (22695477, 1, 2**32)]
+    rnd = random.Random(5)
+    for v, (a, c, m) in enumerate(par):
+        for s in [0, 1, m - 1] + [rnd.randrange(m) for _ in range(50)]:
+            st, words = s, []
+            for _ in range(8):
+                st = (a * st + c) % m
+                words.append(st & M32)
+            assert vko.lcg_key(s, v) == struct.pack(">8I", *words)
+            assert vko.lcg_key(s, v, le=True) == struct.pack("<8I", *words)
+
+
+def rotl(x, n):
+    return ((x << n) | (x >> (64 - n))) & M64
+
+
+def splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M64
+    return x ^ (x >> 31)
+
+
+def py_xorshift(seed, variant):
+    # The reference source is the only spec here: src/xorshift.rs:83-291.
+    seed = seed or 1
+    if variant == 0:
+        x, out = seed, []
+        for _ in range(4):
+            x ^= (x << 13) & M64; x ^= x >> 7; x ^= (x << 17) & M64
+            out.append(x)
+        return struct.pack(">4Q", *out)
+    if variant == 1:
+        x, y = seed & M32, seed >> 32
+        z, w = (seed & M32) ^ 0x12345678, ((seed >> 32) ^ 0x87654321) & M32
+        out = []
+        for _ in range(8):
+            t = x ^ ((x << 11) & M32)
+            x, y, z = y, z, w
+            w = (w ^ (w >> 19)) ^ (t ^ (t >> 8))
+            out.append(w)
+        return struct.pack(">8I", *out)
+    s0 = splitmix64(seed); s1 = splitmix64(s0)
+    out = []
+    for _ in range(4):
+        out.append((s0 + s1) & M64 if variant == 2 else (rotl((s0 * 5) & M64, 7) * 9) & M64)
+        s1 ^= s0
+        s0 = rotl(s0, 24) ^ s1 ^ ((s1 << 16) & M64)
+        s1 = rotl(s1, 37)
+    return struct.pack(">4Q", *out)
+
+
+def test_xorshift_vs_python(vko):
+    rnd = random.Random(6)
+    for v in range(4):
+        for s in SEEDS64 + [rnd.getrandbits(64) for _ in range(40)]:
+            assert vko.xorshift_key(s, v) == py_xorshift(s, v), (v, s)
+        assert vko.xorshift_key(0, v) == vko.xorshift_key(1, v)  # seed 0 -> 1
+
+
+def test_xorshift_survey_anchor_vectors(vko):
+    # SURVEY.md appendix B (recomputed independently in the survey session)
+    assert vko.xorshift_key(1, 0).hex() == "0000000040822041100041060c0114419b1e842f6e862629f554f503555d8025"
+    assert vko.xorshift_key(1, 1).hex() == "87655bc487654b28375242239a8373a33795a04c9a04919d3fe29ba4be7de990"
+    assert vko.xorshift_key(1, 2).hex() == "ef4bd8f4fd3bbddf4c8e357ceae6149143f7cce93a061c71784e8ff8a0e6152d"
+    assert vko.xorshift_key(1, 3).hex() == "65094a0ab526fa3ae1ae03a0cd6ac5fca15fe9409686436869394c37f9adef90"
+
+
+def test_sha256_transform_vs_hashlib(vko):
+    sp = vko.spec(vko.T_SHA256)
+    assert vko.slots_per_input(sp) == 3 and vko.transform_name(sp) == "sha256"
+    for s in SEEDS64 + [1000000]:
+        got = vko.transform_apply(sp, s)
+        exp = [hashlib.sha256(str(s).encode()).digest(), hashlib.sha256(struct.pack(">Q", s)).digest(),
+               hashlib.sha256(struct.pack("<Q", s)).digest()]
+        assert [k for _, k in got] == exp
+        assert [l for l, _ in got] == [str(s)] * 3
+    got = vko.transform_apply(sp, 1000000)
+    assert got[0][1].hex() == "6cce36d9f8a9e151b100234af75cca89d55bcb94c153f51847debdf1f39cae45"
+
+
+def test_sha256_chain_vs_hashlib(vko):
+    names = ["iterated", "indexed:be", "indexed:le", "counter"]
+
+    def chain(seed, v, depth):
+        out = []
+        if v == 0:
+            k = hashlib.sha256(seed).digest()
+            for _ in range(depth):
+                out.append(k); k = hashlib.sha256(k).digest()
+        elif v == 1:
+            out = [hashlib.sha256(seed + struct.pack(">I", i)).digest() for i in range(depth)]
+        elif v == 2:
+            out = [hashlib.sha256(seed + struct.pack("<I", i)).digest() for i in range(depth)]
+        else:
+            out = [hashlib.sha256(seed + str(i).encode()).digest() for i in range(depth)]
+        return out
+
+    for depth in (1, 10, 12):
+        sp = vko.spec(vko.T_SHA256_CHAIN, chain_depth=depth)
+        for s in [0, 7, 2**32 - 1, 2**32, 2**64 - 1]:
+            exp = []
+            for form in ([str(s).encode()] + ([struct.pack(">I", s)] if s <= M32 else [])):
+                for v in range(4):
+                    exp += [(f"{s}[{names[v]}:{i}]", k) for i, k in enumerate(chain(form, v, depth))]
+            assert vko.transform_apply(sp, s) == exp, (depth, s)
+        for v in range(4):
+            sp1 = vko.spec(vko.T_SHA256_CHAIN, variant=v, chain_depth=depth)
+            exp = [(f"5[{names[v]}:{i}]", k) for i, k in enumerate(chain(b"5", v, depth))]
+            exp += [(f"5[{names[v]}:{i}]", k) for i, k in enumerate(chain(struct.pack(">I", 5), v, depth))]
+            assert vko.transform_apply(sp1, 5) == exp
+            assert vko.transform_name(sp1) == "sha256_chain:" + names[v]
+
+
+def test_labels_lcg_xorshift(vko):
+    # src/transform/lcg.rs:54-66, src/transform/xorshift.rs:43-47
+    sp = vko.spec(vko.T_LCG)
+    assert [l for l, _ in vko.transform_apply(sp, 5)] == ["5:glibc", "5:minstd", "5:msvc", "5:borland"]
+    assert [l for l, _ in vko.transform_apply(sp, 2**31 - 1)] == ["2147483647:glibc", "2147483647:msvc", "2147483647:borland"]
+    assert [l for l, _ in vko.transform_apply(sp, 2**31)] == ["2147483648:msvc", "2147483648:borland"]
+    assert vko.transform_apply(sp, 2**32) == []
+    sp = vko.spec(vko.T_LCG, endian=1)
+    assert [l for l, _ in vko.transform_apply(sp, 5)][:2] == ["5:glibc:le", "5:minstd:le"]
+    sp = vko.spec(vko.T_LCG, variant=1)
+    assert [l for l, _ in vko.transform_apply(sp, 5)] == ["5"]
+    sp = vko.spec(vko.T_XORSHIFT)
+    assert [l for l, _ in vko.transform_apply(sp, 5)] == ["5:xorshift64", "5:xorshift128", "5:xorshift128+", "5:xoroshiro128**"]
+    assert [l for l, _ in vko.transform_apply(vko.spec(vko.T_XORSHIFT, variant=2), 5)] == ["5"]
