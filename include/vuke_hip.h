@@ -1,0 +1,159 @@
+/*
+ * vuke_hip.h -- C ABI of the MI355X (gfx950) batch key-derivation engine.
+ *
+ * This is the drop-in boundary for vuke's hot path.  The reference (oritwoen/vuke v0.9.0)
+ * has no FFI of its own (pure-Rust trait objects); each entry point below names the
+ * reference interface it stands in for, and INTEGRATION.md shows the Rust `extern "C"`
+ * block + `impl Source for HipRangeSource` a maintainer would add.
+ *
+ *   reference interface (file:line)                         replaced by
+ *   ------------------------------------------------------  ---------------------------
+ *   Source::process / RangeSource::process                  vk_sweep, vk_generate
+ *     src/source/mod.rs:23-31, src/source/range.rs:26-79
+ *   ProcessStats  src/source/mod.rs:35-39                   vk_sweep_stats
+ *   Transform::apply_batch (numeric inputs)                 vk_transform_batch
+ *     src/transform/mod.rs:39-65
+ *   TransformType  src/transform/mod.rs:68-98               vk_transform_spec
+ *   KeyDeriver::derive  src/derive.rs:78-165                vk_derive_batch (hash160s; text
+ *                                                           encodings stay on the host)
+ *   Matcher::{from_addresses,check}  src/matcher.rs:62-98   vk_targets_set + on-device probe
+ *   MatchInfo/AddressType  src/matcher.rs:13-36             vk_hit.addr_kind
+ *   GpuError  src/gpu/error.rs:7-20                         VK_E_* + vk_last_error
+ *
+ * Conventions: plain pointers and sizes, caller owns every host buffer, the engine owns all
+ * device memory.  Return 0 on success, negative VK_E_* on failure; nothing throws or aborts
+ * across this boundary.  One engine drives one GPU and is internally serialised (safe to
+ * share between threads, like the reference's Send + Sync traits); use one engine per GPU.
+ * There is NO CPU fallback in this library: without a usable gfx950 device every call fails
+ * with VK_E_NO_DEVICE.
+ */
+#ifndef VUKE_HIP_H
+#define VUKE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VK_ABI_VERSION 1
+
+/* error codes */
+#define VK_OK 0
+#define VK_E_NO_DEVICE (-1)
+#define VK_E_HIP (-2)
+#define VK_E_INVALID_ARG (-3)
+#define VK_E_UNSUPPORTED (-4)
+#define VK_E_NOMEM (-5)
+
+/* transform kinds (TransformType, src/transform/mod.rs:68-98) */
+#define VK_T_SHA256 0u       /* src/transform/sha256.rs:13-29: 3 keys per numeric input */
+#define VK_T_MILKSAD 1u      /* src/transform/milksad.rs:17-29: MT19937, u32 seeds only */
+#define VK_T_MT64 2u         /* src/mt64.rs:15-20 */
+#define VK_T_LCG 3u          /* src/lcg.rs:68-128; variants 0 glibc, 1 minstd, 2 msvc, 3 borland */
+#define VK_T_XORSHIFT 4u     /* src/xorshift.rs:69-74; 0 xorshift64, 1 xorshift128, 2 128+, 3 xoroshiro128** */
+#define VK_T_SHA256_CHAIN 5u /* src/sha256_chain.rs:74-79; 0 iterated, 1 indexed:be, 2 indexed:le, 3 counter */
+#define VK_VARIANT_ALL 0xFFFFFFFFu
+
+typedef struct vk_transform_spec {
+    uint32_t kind;        /* VK_T_* */
+    uint32_t variant;     /* variant index, or VK_VARIANT_ALL (the reference's `None`) */
+    uint32_t endian;      /* lcg: 0 big (default), 1 little  (LcgEndian, src/lcg.rs:9-14) */
+    uint32_t chain_depth; /* sha256_chain: keys per variant (DEFAULT_CHAIN_DEPTH = 10) */
+} vk_transform_spec;
+
+/* sweep flags */
+#define VK_F_COMPRESSED 1u   /* hash160 of the 33-byte SEC1 key: P2PKH(c) and P2WPKH probes */
+#define VK_F_UNCOMPRESSED 2u /* hash160 of the 65-byte SEC1 key: P2PKH(u) probe */
+
+/* address kinds */
+#define VK_ADDR_P2PKH_C 0u
+#define VK_ADDR_P2PKH_U 1u
+#define VK_ADDR_P2WPKH 2u
+/* target kinds for vk_targets_set */
+#define VK_TARGET_P2PKH 0u
+#define VK_TARGET_P2WPKH 1u
+
+/* One match = one (input, slot) whose derived key hit the target set.  `sub_index` is the
+ * position of the key among the keys the transform emits for that input (emit order of
+ * apply_batch): sha256 0 string / 1 BE8 / 2 LE8; lcg, xorshift with VK_VARIANT_ALL: the
+ * variant; sha256_chain: form*(V*depth) + v*depth + idx (form 0 decimal string, 1 BE32). */
+typedef struct vk_hit {
+    uint64_t seed;
+    uint32_t sub_index;
+    uint32_t addr_kind;  /* VK_ADDR_*; first match in the reference's order (src/matcher.rs:72-98) */
+    uint8_t privkey[32]; /* normalised key bytes (DerivedKey.raw, src/derive.rs:94) */
+    uint8_t h160[20];    /* the hash160 that matched */
+    uint32_t _pad;
+} vk_hit;
+
+typedef struct vk_sweep_stats {
+    uint64_t inputs;       /* ProcessStats.inputs_processed = hi - lo + 1 */
+    uint64_t keys;         /* ProcessStats.keys_generated */
+    uint64_t matches;      /* ProcessStats.matches_found (keys that matched, not addresses) */
+    uint64_t hits_dropped; /* matches that did not fit hit_cap (they are still counted) */
+    uint64_t digest[4];    /* order-independent fold of every hash160 produced */
+    double kernel_seconds; /* hipEvent time of the device work on the engine's stream */
+    uint32_t launches;     /* kernel launches this call made */
+    uint32_t _pad;
+} vk_sweep_stats;
+
+typedef struct vk_engine vk_engine;
+
+typedef struct vk_engine_opts {
+    uint32_t window_bits;  /* fixed-base window width of the k*G table: 8..20 (0 = default 16) */
+    uint32_t batch;        /* keys per lane sharing one field inversion (0 = default) */
+    uint32_t blocks_per_cu;/* resident 256-thread workgroups per CU to launch (0 = default) */
+    uint32_t _reserved;
+    void *stream;          /* hipStream_t to run on (NULL = engine creates its own) */
+} vk_engine_opts;
+
+int vk_abi_version(void);
+int vk_device_count(void);
+int vk_engine_create(int device, vk_engine **out);
+int vk_engine_create_ex(int device, const vk_engine_opts *opts, vk_engine **out);
+void vk_engine_destroy(vk_engine *e);
+/* Message for the last failing call on this engine (valid until the next call); e may be NULL
+ * to read the message of a failed vk_engine_create. */
+const char *vk_last_error(const vk_engine *e);
+
+/* Matcher::from_addresses on the device.  h160 = n x 20 bytes, kind = n bytes (VK_TARGET_*).
+ * Builds an open-address table in HBM; replaces any previous set; n = 0 clears it. */
+int vk_targets_set(vk_engine *e, const uint8_t *h160, const uint8_t *kind, size_t n);
+
+/* RangeSource::process in scan mode (matcher = Some) or counting mode (no targets set):
+ * every input in [seed_lo, seed_hi] -> transform -> normalise -> k*G -> hash160 -> probe.
+ * hits (optional, unsorted) receives up to hit_cap records. */
+int vk_sweep(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_t seed_hi_inclusive,
+             uint32_t flags, vk_hit *hits, size_t hit_cap, vk_sweep_stats *out);
+
+/* RangeSource::process in generate mode (matcher = None): one record per (input, slot), in
+ * input-major order.  slots = vk_slots_per_input(t); n = (hi-lo+1)*slots.  Any output pointer
+ * may be NULL.  valid[i] = 0 where the reference emits nothing for that slot. */
+int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_t seed_hi_inclusive,
+                uint32_t flags, uint8_t *privkeys /* n*32 */, uint8_t *h160_c /* n*20 */,
+                uint8_t *h160_u /* n*20 */, uint8_t *valid /* n */, vk_sweep_stats *out);
+
+/* KeyDeriver::derive for callers that already hold keys (wordlist / stdin sources): raw 32-byte
+ * keys in, normalised keys and hash160s out.  Any output pointer may be NULL. */
+int vk_derive_batch(vk_engine *e, const uint8_t *keys /* n*32 */, size_t n, uint8_t *normalised /* n*32 */,
+                    uint8_t *h160_c /* n*20 */, uint8_t *h160_u /* n*20 */);
+
+/* Transform::apply_batch for numeric inputs: keys_out = n*slots*32, valid = n*slots. */
+int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, const uint64_t *seeds, size_t n,
+                       uint8_t *keys_out, uint8_t *valid);
+
+/* Slots one input occupies under `t` (0 if the spec is invalid). */
+uint32_t vk_slots_per_input(const vk_transform_spec *t);
+
+/* Test hook: (d << (window_bits*w)) * G table entry as 64 bytes X||Y big-endian. */
+int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digit, uint8_t xy[64]);
+/* Test hook: field multiply / inverse on the device, big-endian 32-byte operands. */
+int vk_debug_field(vk_engine *e, int op /* 0 mul, 1 sqr, 2 inv, 3 add, 4 sub */, const uint8_t *a, const uint8_t *b,
+                   size_t n, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports exactly what
+include/vuke_hip.h declares, and refuses to run without a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+
+
+def declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "vuke_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(vk_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(built):
+    from vuke_amd import _ffi
+    L = _ffi.load()
+    names = declared_functions()
+    assert "vk_sweep" in names and "vk_engine_create" in names and len(names) >= 12
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/vuke_hip.h but not exported"
+    assert sorted(_ffi.EXPORTS) == names
+    assert L.vk_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from vuke_amd import _ffi
+    assert C.sizeof(_ffi.Hit) == 72
+    assert C.sizeof(_ffi.SweepStats) == 80
+    assert C.sizeof(_ffi.TransformSpec) == 16
+    assert C.sizeof(_ffi.EngineOpts) == 24
+
+
+def test_slots_per_input_without_gpu(built):
+    import ctypes as C
+    from vuke_amd import _ffi
+    L = _ffi.load()
+    f = lambda *a: L.vk_slots_per_input(C.byref(_ffi.spec(*a)))
+    assert f(_ffi.T_SHA256) == 3 and f(_ffi.T_MILKSAD) == 1 and f(_ffi.T_MT64) == 1
+    assert f(_ffi.T_LCG) == 4 and f(_ffi.T_LCG, 2) == 1 and f(_ffi.T_LCG, 9) == 0
+    assert f(_ffi.T_XORSHIFT) == 4 and f(_ffi.T_SHA256_CHAIN) == 80 and f(_ffi.T_SHA256_CHAIN, 1, 0, 7) == 14
+    assert f(42) == 0
+
+
+def test_no_cpu_fallback(built):
+    """Without a GPU the product path must fail loudly, never compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import vuke_amd
+    with pytest.raises(vuke_amd.VkError) as ei:
+        vuke_amd.Engine(0)
+    assert ei.value.code == vuke_amd._ffi.VK_E_NO_DEVICE
+
+
+def test_product_does_not_touch_oracle():
+    """Nothing under vuke_amd/ or include/ may reference the oracle."""
+    bad = []
+    for base in ("vuke_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".cuh", ".hip", ".cpp", ".hpp", ".sh")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"\bvko_|libvko|import oracle|from oracle|oracle/vko", txt):
+                        bad.append(os.path.join(dp, f))
+    assert bad == []

@@ -1,0 +1,239 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+
+Run on the MI355X box with `pytest -m gpu`.  Every compute call goes through
+libvuke_hip.so; the oracle is only the checker.
+"""
+import random
+import struct
+
+import pytest
+
+from tests import pyref
+
+pytestmark = pytest.mark.gpu
+
+N = pyref.N
+P = pyref.P
+CHBS = bytes.fromhex("c4bbcb1fbec99d65bf59d85c8cb62ee2db963f0fe106f483d9afa73bd4e39a8a")
+EDGE_SEEDS = [0, 1, 2, 9, 10, 42, 99, 100, 12345, 999999, 1000000, 2**31 - 2, 2**31 - 1, 2**31, 2**32 - 1,
+              2**32, 2**32 + 1, 10**19, 2**63, 2**64 - 1, 1610000002]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import vuke_amd
+    e = vuke_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def be(x):
+    return x.to_bytes(32, "big")
+
+
+def test_field_ops(eng):
+    rnd = random.Random(11)
+    vals = [0, 1, 2, P - 1, P - 2, P, P + 1, 2**256 - 1, 2**256 - 2, 2**255, 0x1000003D1, 2**256 - 0x1000003D1,
+            2**224 - 1, (2**256 - 1) ^ (2**128 - 1)]
+    vals += [rnd.getrandbits(256) for _ in range(400)]
+    a = [rnd.choice(vals) for _ in range(2000)] + vals
+    b = [rnd.choice(vals) for _ in range(2000)] + vals[::-1]
+    ab, bb = [be(x) for x in a], [be(x) for x in b]
+    for op, f in ((0, lambda x, y: x * y % P), (3, lambda x, y: (x + y) % P), (4, lambda x, y: (x - y) % P)):
+        got = eng.field_op(op, ab, bb)
+        for x, y, g in zip(a, b, got):
+            assert int.from_bytes(g, "big") == f(x, y), (op, hex(x), hex(y))
+    got = eng.field_op(1, ab)
+    for x, g in zip(a, got):
+        assert int.from_bytes(g, "big") == x * x % P
+    nz = [x for x in a if x % P][:300]
+    got = eng.field_op(2, [be(x) for x in nz])
+    for x, g in zip(nz, got):
+        assert int.from_bytes(g, "big") == pow(x, -1, P)
+
+
+def test_table_entries(eng, vko):
+    # entry (w, d) = (d << 16w) * G for the default 16-bit windows
+    rnd = random.Random(12)
+    picks = [(0, 1), (0, 2), (0, 65535), (1, 1), (15, 1), (15, 65535), (7, 0x8000)]
+    picks += [(rnd.randrange(16), rnd.randrange(1, 65536)) for _ in range(40)]
+    for w, d in picks:
+        k = d << (16 * w)
+        _, p65 = vko.pubkey(be(k))
+        x, y = eng.table_entry(w, d)
+        assert x + y == p65[1:], (w, d)
+    assert eng.table_entry(3, 0) == (bytes(32), bytes(32))
+
+
+def test_derive_batch_edges_and_random(eng, vko):
+    rnd = random.Random(13)
+    keys = [bytes(32), be(1), be(2), be(N - 1), be(N), be(N + 1), be(2**256 - 1), CHBS, b"\x01" * 32,
+            be(2**255), be(2**128), be(0xFFFF), be(0x10000), be(0xFFFF << 240), be((N - 1) ^ 0xFFFF)]
+    keys += [be(1 << i) for i in range(0, 256, 7)]
+    keys += [be(rnd.getrandbits(256)) for _ in range(1500)]
+    keys += [be(rnd.getrandbits(rnd.randrange(1, 256))) for _ in range(200)]
+    norm, hc, hu = eng.derive_batch(keys)
+    for k, n_, c, u in zip(keys, norm, hc, hu):
+        assert n_ == vko.normalize_key(k)
+        assert (c, u) == vko.derive_h160(k), k.hex()
+    # reference KAT (src/derive.rs:179-200) through the device
+    i = keys.index(CHBS)
+    assert hu[i].hex() == "c4c5d791fcb4654a1ef5e03fe0ad3d9c598f9827"
+    assert pyref.b58check(b"\0" + hu[i]) == "1JwSSubhmg6iPtRjtyqhUYYH7bZg3Lfy1T"
+    assert pyref.b58check(b"\0" + hc[i]) == "1C7zdTfnkzmr13HfA2vNm5SJYRK6nEKyq8"
+    # zero key normalises to 1 (src/derive.rs:216-224)
+    assert norm[0] == be(1) and hc[0].hex() == "751e76e8199196d454941c45d1b3a323f1433bd6"
+
+
+def _specs(vko, ffi):
+    out = [(ffi.spec(ffi.T_SHA256), vko.spec(vko.T_SHA256)),
+           (ffi.spec(ffi.T_MILKSAD), vko.spec(vko.T_MILKSAD)),
+           (ffi.spec(ffi.T_MT64), vko.spec(vko.T_MT64))]
+    for v in (ffi.VARIANT_ALL, 0, 1, 2, 3):
+        for en in (0, 1):
+            out.append((ffi.spec(ffi.T_LCG, v, en), vko.spec(vko.T_LCG, v, en)))
+        out.append((ffi.spec(ffi.T_XORSHIFT, v), vko.spec(vko.T_XORSHIFT, v)))
+        for depth in (1, 3, 10):
+            out.append((ffi.spec(ffi.T_SHA256_CHAIN, v, 0, depth), vko.spec(vko.T_SHA256_CHAIN, v, 0, depth)))
+    return out
+
+
+def test_transform_batch_all_transforms(eng, vko):
+    from vuke_amd import _ffi as ffi
+    rnd = random.Random(14)
+    seeds = EDGE_SEEDS + [rnd.getrandbits(64) for _ in range(40)] + [rnd.getrandbits(32) for _ in range(40)] \
+        + [rnd.getrandbits(rnd.randrange(1, 64)) for _ in range(40)]
+    for gs, os_ in _specs(vko, ffi):
+        got = eng.transform_batch(gs, seeds)
+        slots = vko.slots_per_input(os_)
+        for s, row in zip(seeds, got):
+            exp = [vko.transform_key(os_, s, sub) for sub in range(slots)]
+            assert row == exp, (gs.kind, gs.variant, gs.endian, gs.chain_depth, s)
+
+
+def test_milksad_known_vectors(eng):
+    from vuke_amd import _ffi as ffi
+    got = eng.transform_batch(ffi.spec(ffi.T_MILKSAD), [100, 1610000002])
+    # reference README.md:439 and README.md:413
+    assert got[0][0].hex() == "08961c8b18dbd0ab4337434767df7b69572fad6c4f00c186b03f43d88af70a26"
+    assert got[1][0].hex().startswith("7ed2") and got[1][0].hex().endswith("5055")
+
+
+def test_sweep_counts_digest_all_transforms(eng, vko):
+    from vuke_amd import _ffi as ffi
+    cases = []
+    for gs, os_ in _specs(vko, ffi):
+        if gs.kind == ffi.T_SHA256_CHAIN and gs.chain_depth != 3:
+            continue
+        cases.append((gs, os_, 0, 300))
+    cases += [(ffi.spec(ffi.T_MILKSAD), vko.spec(vko.T_MILKSAD), 2**32 - 200, 2**32 + 100),   # skips > u32
+              (ffi.spec(ffi.T_LCG), vko.spec(vko.T_LCG), 2**31 - 300, 2**31 + 300),            # per-variant ceilings
+              (ffi.spec(ffi.T_LCG), vko.spec(vko.T_LCG), 2**32 - 100, 2**32 + 50),
+              (ffi.spec(ffi.T_SHA256_CHAIN), vko.spec(vko.T_SHA256_CHAIN), 2**32 - 20, 2**32 + 20),
+              (ffi.spec(ffi.T_MT64), vko.spec(vko.T_MT64), 2**64 - 500, 2**64 - 1),
+              (ffi.spec(ffi.T_SHA256), vko.spec(vko.T_SHA256), 7, 7),
+              (ffi.spec(ffi.T_MILKSAD), vko.spec(vko.T_MILKSAD), 5000, 5000 + 8191),
+              (ffi.spec(ffi.T_MILKSAD), vko.spec(vko.T_MILKSAD), 123, 123 + 8192),
+              (ffi.spec(ffi.T_XORSHIFT), vko.spec(vko.T_XORSHIFT), 0, 3000)]
+    for gs, os_, lo, hi in cases:
+        for flags in (1, 3):
+            st, hits = eng.sweep(gs, lo, hi, flags=flags)
+            ost, _ = vko.sweep(os_, lo, hi, flags=flags, nthreads=8)
+            key = (gs.kind, gs.variant, gs.endian, gs.chain_depth, lo, hi, flags)
+            assert (st["inputs"], st["keys"], st["matches"]) == (ost["inputs"], ost["keys"], 0), key
+            assert st["digest"] == ost["digest"], key
+            assert hits == []
+
+
+def test_scan_planted_targets_priority(eng, vko):
+    from vuke_amd import _ffi as ffi
+    gs, os_ = ffi.spec(ffi.T_SHA256), vko.spec(vko.T_SHA256)
+    lo, hi = 5000, 9999
+    rnd = random.Random(15)
+    lines, h160s, kinds = [], [], []
+    planted = []
+    for j in range(60):
+        seed, sub, kind = rnd.randrange(lo, hi + 1), rnd.randrange(3), j % 3
+        d = vko.derive(vko.transform_key(os_, seed, sub))
+        if kind == 0:
+            lines.append(d.p2pkh_compressed.decode()); h160s.append(bytes(d.h160_c)); kinds.append(0)
+        elif kind == 1:
+            lines.append(d.p2pkh_uncompressed.decode()); h160s.append(bytes(d.h160_u)); kinds.append(0)
+        else:
+            lines.append(d.p2wpkh.decode()); h160s.append(bytes(d.h160_c)); kinds.append(1)
+        planted.append((seed, sub))
+    # one key listed under all three kinds -> priority p2pkh_c wins; another under u + wpkh -> u wins
+    d = vko.derive(vko.transform_key(os_, 7777, 1))
+    lines += [d.p2wpkh.decode(), d.p2pkh_uncompressed.decode(), d.p2pkh_compressed.decode()]
+    h160s += [bytes(d.h160_c), bytes(d.h160_u), bytes(d.h160_c)]; kinds += [1, 0, 0]
+    d = vko.derive(vko.transform_key(os_, 7778, 0))
+    lines += [d.p2wpkh.decode(), d.p2pkh_uncompressed.decode()]
+    h160s += [bytes(d.h160_c), bytes(d.h160_u)]; kinds += [1, 0]
+    # decoys
+    for j in range(3000):
+        h = vko.sha256(b"decoy" + struct.pack("<Q", j))[:20]
+        h160s.append(h); kinds.append(j & 1)
+        lines.append(pyref.b58check(b"\0" + h) if not (j & 1) else vko.segwit_encode("bc", 0, h))
+    eng.targets_set(h160s, kinds)
+    m = vko.Matcher(lines)
+    for flags in (3, 1, 2):
+        st, hits = eng.sweep(gs, lo, hi, flags=flags)
+        ost, ohits = vko.sweep(os_, lo, hi, flags=flags, matcher=m, nthreads=8)
+        assert (st["inputs"], st["keys"], st["matches"]) == (ost["inputs"], ost["keys"], ost["matches"])
+        assert st["digest"] == ost["digest"]
+        assert hits == ohits
+        if flags == 3:
+            got = {(h["seed"], h["sub_index"]): h["addr_kind"] for h in hits}
+            assert got[(7777, 1)] == 0 and got[(7778, 0)] == 1 and st["matches"] >= 50
+    # hit_cap smaller than matches: counted, dropped
+    st, hits = eng.sweep(gs, lo, hi, flags=3, hit_cap=5)
+    assert len(hits) == 5 and st["hits_dropped"] == st["matches"] - 5
+    eng.targets_set([], [])
+    st, hits = eng.sweep(gs, lo, hi, flags=3)
+    assert st["matches"] == 0 and hits == []
+
+
+def test_generate_sha256_matches_oracle_records(eng, vko):
+    from vuke_amd import _ffi as ffi
+    gs, os_ = ffi.spec(ffi.T_SHA256), vko.spec(vko.T_SHA256)
+    lo, hi = 0, 1500
+    g = eng.generate(gs, lo, hi)
+    assert g["slots"] == 3 and g["keys"] == 3 * 1501
+    for seed in list(range(0, 40)) + [999, 1000, 1500]:
+        for sub in range(3):
+            i = (seed - lo) * 3 + sub
+            key = vko.transform_key(os_, seed, sub)
+            d = vko.derive(key)
+            assert g["valid"][i] == 1
+            assert g["privkeys"][32 * i:32 * i + 32] == bytes(d.raw)
+            assert g["h160_c"][20 * i:20 * i + 20] == bytes(d.h160_c)
+            assert g["h160_u"][20 * i:20 * i + 20] == bytes(d.h160_u)
+    # invalid slots stay zero/invalid: lcg all-variants above the minstd ceiling
+    g = eng.generate(ffi.spec(ffi.T_LCG), 2**31 - 2, 2**31 + 1)
+    assert list(g["valid"]) == [1, 1, 1, 1, 1, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1]
+
+
+def test_invalid_arguments(eng):
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+    with pytest.raises(vuke_amd.VkError):
+        eng.sweep(ffi.spec(99), 0, 10)
+    with pytest.raises(vuke_amd.VkError):
+        eng.sweep(ffi.spec(ffi.T_MILKSAD), 10, 0)
+    with pytest.raises(vuke_amd.VkError):
+        eng.sweep(ffi.spec(ffi.T_MILKSAD), 0, 10, flags=0)
+    with pytest.raises(vuke_amd.VkError):
+        eng.sweep(ffi.spec(ffi.T_LCG, 7), 0, 10)
+    with pytest.raises(vuke_amd.VkError):
+        vuke_amd.Engine(99)
+
+
+def test_other_window_widths(vko):
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+    for W, batch in ((8, 4), (12, 16), (13, 1), (20, 64)):
+        e = vuke_amd.Engine(0, window_bits=W, batch=batch)
+        st, _ = e.sweep(ffi.spec(ffi.T_MILKSAD), 1000, 1999, flags=3)
+        ost, _ = vko.sweep(vko.spec(vko.T_MILKSAD), 1000, 1999, flags=3, nthreads=8)
+        assert st["digest"] == ost["digest"] and st["keys"] == 1000, W
+        e.close()

@@ -1,0 +1,169 @@
+"""ctypes binding of libvuke_hip.so (the C ABI declared in include/vuke_hip.h).
+
+There is no fallback of any kind here: if the shared library is missing or no gfx950
+device is usable, loading / engine creation raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvuke_hip.so")
+
+VK_OK = 0
+VK_E_NO_DEVICE, VK_E_HIP, VK_E_INVALID_ARG, VK_E_UNSUPPORTED, VK_E_NOMEM = -1, -2, -3, -4, -5
+T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN = range(6)
+VARIANT_ALL = 0xFFFFFFFF
+F_COMPRESSED, F_UNCOMPRESSED = 1, 2
+ADDR_P2PKH_C, ADDR_P2PKH_U, ADDR_P2WPKH = 0, 1, 2
+TARGET_P2PKH, TARGET_P2WPKH = 0, 1
+
+
+class TransformSpec(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("variant", C.c_uint32), ("endian", C.c_uint32), ("chain_depth", C.c_uint32)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("sub_index", C.c_uint32), ("addr_kind", C.c_uint32),
+                ("privkey", C.c_uint8 * 32), ("h160", C.c_uint8 * 20), ("_pad", C.c_uint32)]
+
+
+class SweepStats(C.Structure):
+    _fields_ = [("inputs", C.c_uint64), ("keys", C.c_uint64), ("matches", C.c_uint64), ("hits_dropped", C.c_uint64),
+                ("digest", C.c_uint64 * 4), ("kernel_seconds", C.c_double), ("launches", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class EngineOpts(C.Structure):
+    _fields_ = [("window_bits", C.c_uint32), ("batch", C.c_uint32), ("blocks_per_cu", C.c_uint32),
+                ("_reserved", C.c_uint32), ("stream", C.c_void_p)]
+
+
+EXPORTS = [
+    "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy",
+    "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_transform_batch",
+    "vk_slots_per_input", "vk_debug_table_entry", "vk_debug_field",
+]
+
+_lib = None
+
+
+def load():
+    """Load libvuke_hip.so; raises OSError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} is missing: build it with vuke_amd/csrc/build.sh (or __graft_entry__.build())")
+    L = C.CDLL(LIB_PATH)
+    vp, cp, sz, u32, u64 = C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint64
+    L.vk_abi_version.restype = C.c_int
+    L.vk_device_count.restype = C.c_int
+    L.vk_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.vk_engine_create_ex.argtypes = [C.c_int, C.POINTER(EngineOpts), C.POINTER(vp)]
+    L.vk_engine_destroy.argtypes = [vp]
+    L.vk_engine_destroy.restype = None
+    L.vk_last_error.argtypes = [vp]
+    L.vk_last_error.restype = cp
+    L.vk_targets_set.argtypes = [vp, cp, cp, sz]
+    L.vk_sweep.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
+    L.vk_generate.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, vp, vp, vp, vp, C.POINTER(SweepStats)]
+    L.vk_derive_batch.argtypes = [vp, cp, sz, vp, vp, vp]
+    L.vk_transform_batch.argtypes = [vp, C.POINTER(TransformSpec), C.POINTER(u64), sz, vp, vp]
+    L.vk_slots_per_input.argtypes = [C.POINTER(TransformSpec)]
+    L.vk_slots_per_input.restype = u32
+    L.vk_debug_table_entry.argtypes = [vp, u32, u32, vp]
+    L.vk_debug_field.argtypes = [vp, C.c_int, cp, cp, sz, vp]
+    _lib = L
+    return L
+
+
+class VkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"vuke_hip error {code}: {msg}")
+        self.code = code
+
+
+class Engine:
+    """One engine per GPU (vk_engine).  Raises VkError when no gfx950 device is usable."""
+
+    def __init__(self, device=0, window_bits=0, batch=0, blocks_per_cu=0, stream=None):
+        L = load()
+        self._L = L
+        self._e = C.c_void_p()
+        opts = EngineOpts(window_bits, batch, blocks_per_cu, 0, stream)
+        rc = L.vk_engine_create_ex(device, C.byref(opts), C.byref(self._e))
+        if rc != VK_OK:
+            raise VkError(rc, (L.vk_last_error(None) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_e", None) and self._e.value:
+            self._L.vk_engine_destroy(self._e)
+            self._e = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != VK_OK:
+            raise VkError(rc, (self._L.vk_last_error(self._e) or b"").decode())
+
+    def targets_set(self, h160s, kinds):
+        n = len(h160s)
+        self._chk(self._L.vk_targets_set(self._e, b"".join(h160s), bytes(kinds), n))
+
+    def sweep(self, spec, lo, hi, flags=F_COMPRESSED, hit_cap=4096):
+        hits = (Hit * max(hit_cap, 1))()
+        st = SweepStats()
+        self._chk(self._L.vk_sweep(self._e, C.byref(spec), lo, hi, flags, hits, hit_cap, C.byref(st)))
+        n = min(st.matches, hit_cap)
+        hl = [dict(seed=h.seed, sub_index=h.sub_index, addr_kind=h.addr_kind, privkey=bytes(h.privkey), h160=bytes(h.h160))
+              for h in hits[:n]]
+        hl.sort(key=lambda h: (h["seed"], h["sub_index"]))
+        return dict(inputs=st.inputs, keys=st.keys, matches=st.matches, hits_dropped=st.hits_dropped,
+                    digest=tuple(st.digest), kernel_seconds=st.kernel_seconds, launches=st.launches), hl
+
+    def generate(self, spec, lo, hi, flags=F_COMPRESSED | F_UNCOMPRESSED):
+        slots = self._L.vk_slots_per_input(C.byref(spec))
+        n = (hi - lo + 1) * slots
+        priv, hc, hu, valid = (C.create_string_buffer(n * 32), C.create_string_buffer(n * 20),
+                               C.create_string_buffer(n * 20), C.create_string_buffer(n))
+        st = SweepStats()
+        self._chk(self._L.vk_generate(self._e, C.byref(spec), lo, hi, flags, priv, hc, hu, valid, C.byref(st)))
+        return dict(slots=slots, n=n, privkeys=priv.raw, h160_c=hc.raw, h160_u=hu.raw, valid=valid.raw,
+                    keys=st.keys, inputs=st.inputs, digest=tuple(st.digest), kernel_seconds=st.kernel_seconds)
+
+    def derive_batch(self, keys):
+        n = len(keys)
+        norm, hc, hu = C.create_string_buffer(n * 32), C.create_string_buffer(n * 20), C.create_string_buffer(n * 20)
+        self._chk(self._L.vk_derive_batch(self._e, b"".join(keys), n, norm, hc, hu))
+        return ([norm.raw[32 * i:32 * i + 32] for i in range(n)], [hc.raw[20 * i:20 * i + 20] for i in range(n)],
+                [hu.raw[20 * i:20 * i + 20] for i in range(n)])
+
+    def transform_batch(self, spec, seeds):
+        n = len(seeds)
+        slots = self._L.vk_slots_per_input(C.byref(spec))
+        arr = (C.c_uint64 * n)(*seeds)
+        keys, valid = C.create_string_buffer(n * slots * 32), C.create_string_buffer(n * slots)
+        self._chk(self._L.vk_transform_batch(self._e, C.byref(spec), arr, n, keys, valid))
+        out = []
+        for i in range(n):
+            out.append([(keys.raw[32 * (i * slots + s):32 * (i * slots + s) + 32] if valid.raw[i * slots + s] else None)
+                        for s in range(slots)])
+        return out
+
+    def table_entry(self, window, digit):
+        xy = C.create_string_buffer(64)
+        self._chk(self._L.vk_debug_table_entry(self._e, window, digit, xy))
+        return xy.raw[:32], xy.raw[32:]
+
+    def field_op(self, op, a_list, b_list=None):
+        n = len(a_list)
+        out = C.create_string_buffer(n * 32)
+        self._chk(self._L.vk_debug_field(self._e, op, b"".join(a_list), b"".join(b_list) if b_list else None, n, out))
+        return [out.raw[32 * i:32 * i + 32] for i in range(n)]
+
+
+def spec(kind, variant=VARIANT_ALL, endian=0, chain_depth=10):
+    return TransformSpec(kind, variant, endian, chain_depth)

@@ -1,0 +1,161 @@
+// vk_ec.cuh -- secp256k1 group operations for gfx950 lanes.
+//
+// Fixed-base k*G with a precomputed table of (d * 2^(W*w)) * G affine points that lives in
+// HBM and is served from L2 / Infinity Cache (W=16: 16 windows x 65536 entries x 64 B =
+// 64 MiB).  One lane owns one key: ceil(256/W) table gathers and mixed Jacobian+affine
+// additions, no doublings.  Why no special cases are needed in ecmult_table(): with k
+// normalised to [1, n) the accumulator after windows 0..w-1 is s*G with s < 2^(W*w), and the
+// addend is t*G with 2^(W*w) <= t <= k < n, so s != t and s + t = k' <= k < n (s != -t).
+//
+// Stands in for libsecp256k1's ecmult_gen reached from src/derive.rs:97 (reference).
+#pragma once
+#include "vk_field.cuh"
+
+struct jac {
+    fe x, y, z;
+};
+
+// r = p + (qx, qy), p Jacobian (not infinity), q affine, p != +-q.   8M + 3S
+VK_DEV void jac_madd(jac &r, const jac &p, const fe &qx, const fe &qy)
+{
+    fe z2, u2, s2, h, rr, h2, h3, v, t;
+    fe_sqr(z2, p.z);
+    fe_mul(u2, qx, z2);
+    fe_mul(s2, qy, z2);
+    fe_mul(s2, s2, p.z);
+    fe_sub(h, u2, p.x);
+    fe_sub(rr, s2, p.y);
+    fe_sqr(h2, h);
+    fe_mul(h3, h2, h);
+    fe_mul(v, p.x, h2);
+    fe_mul(r.z, p.z, h); // last use of p.z
+    fe_sqr(t, rr);
+    fe_sub(t, t, h3);
+    fe_sub(t, t, v);
+    fe_sub(t, t, v);     // x3
+    fe_mul(h3, h3, p.y); // y1 * h^3 (last use of p.y)
+    fe_sub(v, v, t);
+    fe_mul(v, v, rr);
+    fe_sub(r.y, v, h3);
+    r.x = t;
+}
+
+// r = 2p (a = 0), p.y != 0.   2M + 5S  (used only by the table builder)
+VK_DEV void jac_double(jac &r, const jac &p)
+{
+    fe a, b, c, d, e, f, t;
+    fe_sqr(a, p.x);
+    fe_sqr(b, p.y);
+    fe_sqr(c, b);
+    fe_add(t, p.x, b);
+    fe_sqr(t, t);
+    fe_sub(t, t, a);
+    fe_sub(t, t, c);
+    fe_add(d, t, t);
+    fe_add(e, a, a);
+    fe_add(e, e, a);
+    fe_sqr(f, e);
+    fe_mul(r.z, p.y, p.z);
+    fe_add(r.z, r.z, r.z);
+    fe_sub(f, f, d);
+    fe_sub(f, f, d); // x3
+    fe_sub(t, d, f);
+    fe_mul(t, e, t);
+    fe_add(c, c, c);
+    fe_add(c, c, c);
+    fe_add(c, c, c);
+    fe_sub(r.y, t, c);
+    r.x = f;
+}
+
+// table entry = 16 u32: x[8] then y[8], canonical little-endian limbs
+VK_DEV void table_load(fe &x, fe &y, const uint4 *__restrict__ p)
+{
+    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
+    x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+    y.v[0] = c.x; y.v[1] = c.y; y.v[2] = c.z; y.v[3] = c.w;
+    y.v[4] = d.x; y.v[5] = d.y; y.v[6] = d.z; y.v[7] = d.w;
+}
+
+VK_DEV u32 scalar_digit(const u32 k[8], u32 bitpos, u32 W)
+{
+    // W <= 20 bits starting at bitpos (may straddle two limbs)
+    u32 limb = bitpos >> 5, sh = bitpos & 31;
+    u32 lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        lo = (limb == (u32)i) ? k[i] : lo;
+        hi = (limb + 1 == (u32)i) ? k[i] : hi;
+    }
+    u64 both = ((u64)hi << 32) | lo;
+    return (u32)(both >> sh) & ((1u << W) - 1u);
+}
+
+// acc = k*G, k in [1, n).  Returns Jacobian (z = 1 possible).  table: [nwin][2^W] entries.
+VK_DEV void ecmult_table(jac &acc, const u32 k[8], const uint4 *__restrict__ table, u32 W, u32 nwin)
+{
+    bool inf = true;
+    fe_set_zero(acc.x);
+    fe_set_zero(acc.y);
+    fe_set_one(acc.z);
+    // software prefetch of the next window's entry
+    u32 d = scalar_digit(k, 0, W);
+    fe qx, qy;
+    table_load(qx, qy, table + ((size_t)d << 2));
+#pragma unroll 1
+    for (u32 w = 0; w < nwin; w++) {
+        fe cx = qx, cy = qy;
+        u32 cd = d;
+        if (w + 1 < nwin) {
+            d = scalar_digit(k, (w + 1) * W, W);
+            table_load(qx, qy, table + ((((size_t)(w + 1) << W) + d) << 2));
+        }
+        if (cd != 0) {
+            if (inf) {
+                acc.x = cx;
+                acc.y = cy;
+                inf = false;
+            } else {
+                jac_madd(acc, acc, cx, cy);
+            }
+        }
+    }
+}
+
+// generic double-and-add over all 256 bits of s (MSB first), s in [1, n).  Table builder only.
+VK_DEV void ecmult_generic(jac &acc, const u32 s[8])
+{
+    const fe gx = {{0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu, 0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu}};
+    const fe gy = {{0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u, 0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u}};
+    bool inf = true;
+#pragma unroll 1
+    for (int i = 255; i >= 0; i--) {
+        if (!inf) jac_double(acc, acc);
+        u32 limb = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) limb = ((i >> 5) == j) ? s[j] : limb;
+        if ((limb >> (i & 31)) & 1u) {
+            if (inf) {
+                acc.x = gx;
+                acc.y = gy;
+                fe_set_one(acc.z);
+                inf = false;
+            } else {
+                jac_madd(acc, acc, gx, gy);
+            }
+        }
+    }
+}
+
+// (x, y) = affine(p) given zinv = 1/p.z; canonical limbs
+VK_DEV void jac_to_affine(fe &x, fe &y, const jac &p, const fe &zinv)
+{
+    fe zi2, zi3;
+    fe_sqr(zi2, zinv);
+    fe_mul(zi3, zi2, zinv);
+    fe_mul(x, p.x, zi2);
+    fe_mul(y, p.y, zi3);
+    fe_canon(x);
+    fe_canon(y);
+}

@@ -1,0 +1,610 @@
+// vk_engine.hip -- host side of the C ABI in include/vuke_hip.h: device memory, launches,
+// error reporting.  No CPU compute path exists here: without a gfx950 device every entry
+// point returns VK_E_NO_DEVICE (the oracle under oracle/ is test infrastructure and is never
+// linked into this library).
+#include "../../include/vuke_hip.h"
+#include "vk_kernels.cuh"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+static_assert(sizeof(vk_hit) == sizeof(vk_hit_dev), "vk_hit layout");
+static_assert(sizeof(vk_hit) == 72, "vk_hit is 72 bytes");
+
+static thread_local std::string g_create_error;
+
+struct vk_engine {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cu_count = 0;
+    u32 W = 16, nwin = 16;
+    u32 batch = 32;
+    u32 blocks_per_cu = 0;
+    uint4 *table = nullptr;
+    uint4 *tgt = nullptr;
+    u32 tgt_cap = 0;
+    size_t tgt_count = 0;
+    vk_hit_dev *d_hits = nullptr;
+    size_t d_hits_cap = 0;
+    u64 *d_stats = nullptr;
+    uint4 *work = nullptr;
+    size_t work_bytes = 0;
+    std::mutex mu;
+    std::string err;
+};
+
+#define HIPCHK(e, call)                                                                             \
+    do {                                                                                            \
+        hipError_t _r = (call);                                                                     \
+        if (_r != hipSuccess) {                                                                     \
+            char _b[512];                                                                           \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
+            (e)->err = _b;                                                                          \
+            return VK_E_HIP;                                                                        \
+        }                                                                                           \
+    } while (0)
+
+static int fail(vk_engine *e, int code, const char *msg)
+{
+    if (e) e->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+extern "C" int vk_abi_version(void) { return VK_ABI_VERSION; }
+
+extern "C" int vk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" uint32_t vk_slots_per_input(const vk_transform_spec *t)
+{
+    if (!t) return 0;
+    switch (t->kind) {
+    case VK_T_SHA256: return 3;
+    case VK_T_MILKSAD:
+    case VK_T_MT64: return 1;
+    case VK_T_LCG:
+    case VK_T_XORSHIFT:
+        if (t->variant != VK_VARIANT_ALL && t->variant > 3) return 0;
+        return t->variant == VK_VARIANT_ALL ? 4u : 1u;
+    case VK_T_SHA256_CHAIN:
+        if (t->variant != VK_VARIANT_ALL && t->variant > 3) return 0;
+        if (t->chain_depth == 0 || t->chain_depth > 4096) return 0;
+        return 2u * (t->variant == VK_VARIANT_ALL ? 4u : 1u) * t->chain_depth;
+    default: return 0;
+    }
+}
+
+static int validate_spec(vk_engine *e, const vk_transform_spec *t)
+{
+    if (!t) return fail(e, VK_E_INVALID_ARG, "transform spec is NULL");
+    if (vk_slots_per_input(t) == 0) return fail(e, VK_E_INVALID_ARG, "invalid transform spec (kind / variant / chain_depth)");
+    if (t->kind == VK_T_LCG && t->endian > 1) return fail(e, VK_E_INVALID_ARG, "lcg endian must be 0 (big) or 1 (little)");
+    return VK_OK;
+}
+
+extern "C" const char *vk_last_error(const vk_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+extern "C" void vk_engine_destroy(vk_engine *e)
+{
+    if (!e) return;
+    if (e->device >= 0) (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->table) (void)hipFree(e->table);
+    if (e->tgt) (void)hipFree(e->tgt);
+    if (e->d_hits) (void)hipFree(e->d_hits);
+    if (e->d_stats) (void)hipFree(e->d_stats);
+    if (e->work) (void)hipFree(e->work);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(e, VK_E_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(e, VK_E_INVALID_ARG, "device index out of range");
+    HIPCHK(e, hipSetDevice(device));
+    e->device = device;
+    hipDeviceProp_t prop;
+    HIPCHK(e, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        e->err = std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only";
+        return VK_E_NO_DEVICE;
+    }
+    e->cu_count = prop.multiProcessorCount;
+    if (opts && opts->window_bits) {
+        if (opts->window_bits < 4 || opts->window_bits > 22) return fail(e, VK_E_INVALID_ARG, "window_bits must be in 4..22");
+        e->W = opts->window_bits;
+    }
+    e->nwin = (256 + e->W - 1) / e->W;
+    if (opts && opts->batch) {
+        if (opts->batch > 1024) return fail(e, VK_E_INVALID_ARG, "batch must be <= 1024");
+        e->batch = opts->batch;
+    }
+    if (opts && opts->blocks_per_cu) {
+        if (opts->blocks_per_cu > 8) return fail(e, VK_E_INVALID_ARG, "blocks_per_cu must be <= 8");
+        e->blocks_per_cu = opts->blocks_per_cu;
+    }
+    if (opts && opts->stream) {
+        e->stream = (hipStream_t)opts->stream;
+    } else {
+        HIPCHK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    HIPCHK(e, hipEventCreate(&e->ev0));
+    HIPCHK(e, hipEventCreate(&e->ev1));
+    HIPCHK(e, hipMalloc(&e->d_stats, 8 * sizeof(u64)));
+    if (e->blocks_per_cu == 0) {
+        int occ = 0;
+        HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vk_sweep_kernel<VK_T_MILKSAD>, VK_BLOCK, 0));
+        e->blocks_per_cu = (u32)std::max(1, std::min(occ, 4));
+    }
+    // the k*G table: nwin x 2^W affine points, built on the device
+    const size_t entries = (size_t)e->nwin << e->W;
+    HIPCHK(e, hipMalloc(&e->table, entries * 64));
+    const u32 blocks = (u32)((entries + VK_BLOCK - 1) / VK_BLOCK);
+    hipLaunchKernelGGL(vk_table_kernel, dim3(blocks), dim3(VK_BLOCK), 0, e->stream, e->table, e->W, e->nwin);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return VK_OK;
+}
+
+extern "C" int vk_engine_create_ex(int device, const vk_engine_opts *opts, vk_engine **out)
+{
+    if (!out) return fail(nullptr, VK_E_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    vk_engine *e = new (std::nothrow) vk_engine();
+    if (!e) return fail(nullptr, VK_E_NOMEM, "out of host memory");
+    int rc = engine_init(e, device, opts);
+    if (rc != VK_OK) {
+        g_create_error = e->err;
+        vk_engine_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return VK_OK;
+}
+
+extern "C" int vk_engine_create(int device, vk_engine **out) { return vk_engine_create_ex(device, nullptr, out); }
+
+// ------------------------------------------------------------------------- targets
+extern "C" int vk_targets_set(vk_engine *e, const uint8_t *h160, const uint8_t *kind, size_t n)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHK(e, hipSetDevice(e->device));
+    if (e->tgt) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        HIPCHK(e, hipFree(e->tgt));
+        e->tgt = nullptr;
+        e->tgt_cap = 0;
+        e->tgt_count = 0;
+    }
+    if (n == 0) return VK_OK;
+    if (!h160 || !kind) return fail(e, VK_E_INVALID_ARG, "h160 / kind is NULL");
+    if (n > (1ull << 30)) return fail(e, VK_E_INVALID_ARG, "too many targets (max 2^30)");
+    size_t cap = 1024;
+    while (cap < 2 * n) cap <<= 1; // load factor <= 1/2
+    std::vector<u32> tab(cap * 8, 0u);
+    const u32 mask = (u32)(cap - 1);
+    for (size_t i = 0; i < n; i++) {
+        if (kind[i] > 1) return fail(e, VK_E_INVALID_ARG, "target kind must be 0 (p2pkh) or 1 (p2wpkh)");
+        u32 h[5];
+        memcpy(h, h160 + 20 * i, 20); // little-endian host == RIPEMD-160 state words
+        u32 bit = 1u << kind[i];
+        u32 s = h[0] & mask;
+        for (;;) {
+            u32 *slot = &tab[(size_t)s * 8];
+            if (slot[5] == 0) {
+                memcpy(slot, h, 20);
+                slot[5] = bit;
+                break;
+            }
+            if (memcmp(slot, h, 20) == 0) { // same hash160 listed under both kinds
+                slot[5] |= bit;
+                break;
+            }
+            s = (s + 1) & mask;
+        }
+    }
+    HIPCHK(e, hipMalloc(&e->tgt, cap * 32));
+    HIPCHK(e, hipMemcpy(e->tgt, tab.data(), cap * 32, hipMemcpyHostToDevice));
+    e->tgt_cap = (u32)cap;
+    e->tgt_count = n;
+    return VK_OK;
+}
+
+// ------------------------------------------------------------------------- launch helper
+struct launch_io {
+    vk_hit *hits = nullptr;
+    size_t hit_cap = 0;
+    const u32 *in_keys = nullptr; // device
+    u32 *out_priv = nullptr;      // device
+    u32 *out_h160c = nullptr;
+    u32 *out_h160u = nullptr;
+    unsigned char *out_valid = nullptr;
+};
+
+template <u32 KIND>
+static void launch_sweep(const vk_sweep_params &p, u32 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(vk_sweep_kernel<KIND>, dim3(grid), dim3(VK_BLOCK), 0, s, p);
+}
+
+// run [lo, lo+span] (span+1 inputs) under `spec`; accumulates into *st
+static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots, u64 lo, u64 span, u32 flags,
+                     const launch_io &io, vk_sweep_stats *st)
+{
+    HIPCHK(e, hipSetDevice(e->device));
+    u32 R = std::max(1u, e->batch / slots);
+    const u32 B = R * slots;
+    const u64 tile_inputs = (u64)VK_BLOCK * R;
+    const u64 ntiles = span / tile_inputs + 1;
+    const u64 max_grid = (u64)e->cu_count * e->blocks_per_cu;
+    const u32 grid = (u32)std::min<u64>(ntiles, max_grid);
+    const size_t need = (size_t)grid * VK_BLOCK * B * 8 * sizeof(uint4);
+    if (need > e->work_bytes) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (e->work) HIPCHK(e, hipFree(e->work));
+        e->work = nullptr;
+        e->work_bytes = 0;
+        HIPCHK(e, hipMalloc(&e->work, need));
+        e->work_bytes = need;
+    }
+    if (io.hit_cap > e->d_hits_cap) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (e->d_hits) HIPCHK(e, hipFree(e->d_hits));
+        e->d_hits = nullptr;
+        e->d_hits_cap = 0;
+        HIPCHK(e, hipMalloc(&e->d_hits, io.hit_cap * sizeof(vk_hit_dev)));
+        e->d_hits_cap = io.hit_cap;
+    }
+    HIPCHK(e, hipMemsetAsync(e->d_stats, 0, 8 * sizeof(u64), e->stream));
+
+    vk_sweep_params p;
+    memset(&p, 0, sizeof p);
+    p.spec = spec;
+    p.lo = lo;
+    p.span = span;
+    p.ntiles = ntiles;
+    p.slots = slots;
+    p.R = R;
+    p.flags = flags;
+    p.W = e->W;
+    p.nwin = e->nwin;
+    p.table = e->table;
+    p.tgt = e->tgt;
+    p.tgt_mask = e->tgt_cap ? e->tgt_cap - 1 : 0;
+    p.hits = e->d_hits;
+    p.hit_cap = (u32)std::min<size_t>(io.hit_cap, 0xFFFFFFFFu);
+    p.stats = e->d_stats;
+    p.work = e->work;
+    p.in_keys = io.in_keys;
+    p.out_priv = io.out_priv;
+    p.out_h160c = io.out_h160c;
+    p.out_h160u = io.out_h160u;
+    p.out_valid = io.out_valid;
+
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    switch (kind) {
+    case VK_T_SHA256: launch_sweep<VK_T_SHA256>(p, grid, e->stream); break;
+    case VK_T_MILKSAD: launch_sweep<VK_T_MILKSAD>(p, grid, e->stream); break;
+    case VK_T_MT64: launch_sweep<VK_T_MT64>(p, grid, e->stream); break;
+    case VK_T_LCG: launch_sweep<VK_T_LCG>(p, grid, e->stream); break;
+    case VK_T_XORSHIFT: launch_sweep<VK_T_XORSHIFT>(p, grid, e->stream); break;
+    case VK_T_SHA256_CHAIN: launch_sweep<VK_T_SHA256_CHAIN>(p, grid, e->stream); break;
+    case VK_T_RAWKEYS: launch_sweep<VK_T_RAWKEYS>(p, grid, e->stream); break;
+    default: return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
+    }
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    u64 hs[8];
+    HIPCHK(e, hipMemcpyAsync(hs, e->d_stats, sizeof hs, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    const u64 found = hs[2];
+    const u64 had = st->matches;
+    if (io.hits && found) {
+        // append after hits already delivered by earlier launches of this call
+        const u64 room = had < io.hit_cap ? io.hit_cap - had : 0;
+        const u64 take = std::min<u64>(std::min<u64>(found, p.hit_cap), room);
+        if (take) HIPCHK(e, hipMemcpy(io.hits + had, e->d_hits, take * sizeof(vk_hit), hipMemcpyDeviceToHost));
+    }
+    st->keys += hs[0];
+    st->matches += hs[1];
+    st->digest[0] ^= hs[3];
+    st->digest[1] ^= hs[4];
+    st->digest[2] ^= hs[5];
+    st->digest[3] += hs[6];
+    st->kernel_seconds += (double)ms * 1e-3;
+    st->launches += 1;
+    return VK_OK;
+}
+
+static vk_spec_dev to_dev(const vk_transform_spec *t)
+{
+    vk_spec_dev s;
+    s.kind = t->kind;
+    s.variant = t->variant;
+    s.endian = t->endian;
+    s.chain_depth = t->chain_depth;
+    return s;
+}
+
+// inputs per launch: keeps one launch in the 0.1 - 1 s range and the counters well inside u64
+static const u64 VK_LAUNCH_INPUTS = 1ull << 30;
+
+extern "C" int vk_sweep(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, uint32_t flags, vk_hit *hits,
+                        size_t hit_cap, vk_sweep_stats *out)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int rc = validate_spec(e, t);
+    if (rc) return rc;
+    if (!out) return fail(e, VK_E_INVALID_ARG, "stats out pointer is NULL");
+    if (hi < lo) return fail(e, VK_E_INVALID_ARG, "seed_hi < seed_lo");
+    if (!(flags & (VK_F_COMPRESSED | VK_F_UNCOMPRESSED)) || (flags & ~(VK_F_COMPRESSED | VK_F_UNCOMPRESSED)))
+        return fail(e, VK_E_INVALID_ARG, "flags must be a non-empty subset of VK_F_COMPRESSED | VK_F_UNCOMPRESSED");
+    if (hi - lo == ~0ull) return fail(e, VK_E_INVALID_ARG, "range too large (max 2^64 - 1 inputs per call)");
+    memset(out, 0, sizeof *out);
+    const u32 slots = vk_slots_per_input(t);
+    const vk_spec_dev spec = to_dev(t);
+    launch_io io;
+    io.hits = hits;
+    io.hit_cap = hits ? hit_cap : 0;
+    const u64 per = std::max<u64>(1, VK_LAUNCH_INPUTS / slots);
+    u64 cur = lo;
+    for (;;) {
+        const u64 left = hi - cur; // inclusive span remaining
+        const u64 span = std::min<u64>(left, per - 1);
+        rc = run_range(e, spec, t->kind, slots, cur, span, flags, io, out);
+        if (rc) return rc;
+        if (span == left) break;
+        cur += span + 1;
+    }
+    out->inputs = hi - lo + 1;
+    out->hits_dropped = out->matches > io.hit_cap ? out->matches - io.hit_cap : 0;
+    return VK_OK;
+}
+
+extern "C" int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, uint32_t flags,
+                           uint8_t *privkeys, uint8_t *h160_c, uint8_t *h160_u, uint8_t *valid, vk_sweep_stats *out)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int rc = validate_spec(e, t);
+    if (rc) return rc;
+    if (hi < lo) return fail(e, VK_E_INVALID_ARG, "seed_hi < seed_lo");
+    if (!(flags & (VK_F_COMPRESSED | VK_F_UNCOMPRESSED)) || (flags & ~(VK_F_COMPRESSED | VK_F_UNCOMPRESSED)))
+        return fail(e, VK_E_INVALID_ARG, "flags must be a non-empty subset of VK_F_COMPRESSED | VK_F_UNCOMPRESSED");
+    const u32 slots = vk_slots_per_input(t);
+    if (hi - lo >= (1ull << 40) / slots) return fail(e, VK_E_INVALID_ARG, "generate range too large for one call");
+    vk_sweep_stats local;
+    memset(&local, 0, sizeof local);
+    HIPCHK(e, hipSetDevice(e->device));
+    const vk_spec_dev spec = to_dev(t);
+    const u64 chunk_inputs = std::max<u64>(1, (1ull << 24) / slots);
+    u32 *d_priv = nullptr, *d_hc = nullptr, *d_hu = nullptr;
+    unsigned char *d_valid = nullptr;
+    const u64 chunk_items = chunk_inputs * slots;
+    HIPCHK(e, hipMalloc(&d_priv, chunk_items * 32));
+    HIPCHK(e, hipMalloc(&d_hc, chunk_items * 20));
+    HIPCHK(e, hipMalloc(&d_hu, chunk_items * 20));
+    HIPCHK(e, hipMalloc(&d_valid, chunk_items));
+    auto cleanup = [&]() {
+        (void)hipFree(d_priv);
+        (void)hipFree(d_hc);
+        (void)hipFree(d_hu);
+        (void)hipFree(d_valid);
+    };
+    u64 cur = lo, done_items = 0;
+    for (;;) {
+        const u64 left = hi - cur;
+        const u64 span = std::min<u64>(left, chunk_inputs - 1);
+        const u64 items = (span + 1) * slots;
+        hipError_t r1 = hipMemsetAsync(d_valid, 0, items, e->stream);
+        hipError_t r2 = hipMemsetAsync(d_priv, 0, items * 32, e->stream);
+        hipError_t r3 = hipMemsetAsync(d_hc, 0, items * 20, e->stream);
+        hipError_t r4 = hipMemsetAsync(d_hu, 0, items * 20, e->stream);
+        if (r1 != hipSuccess || r2 != hipSuccess || r3 != hipSuccess || r4 != hipSuccess) {
+            cleanup();
+            return fail(e, VK_E_HIP, "hipMemsetAsync failed in vk_generate");
+        }
+        launch_io io;
+        io.out_priv = d_priv;
+        io.out_h160c = d_hc;
+        io.out_h160u = d_hu;
+        io.out_valid = d_valid;
+        rc = run_range(e, spec, t->kind, slots, cur, span, flags | VK_F_EMIT, io, &local);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+        hipError_t c = hipSuccess;
+        if (privkeys && c == hipSuccess) c = hipMemcpy(privkeys + done_items * 32, d_priv, items * 32, hipMemcpyDeviceToHost);
+        if (h160_c && c == hipSuccess) c = hipMemcpy(h160_c + done_items * 20, d_hc, items * 20, hipMemcpyDeviceToHost);
+        if (h160_u && c == hipSuccess) c = hipMemcpy(h160_u + done_items * 20, d_hu, items * 20, hipMemcpyDeviceToHost);
+        if (valid && c == hipSuccess) c = hipMemcpy(valid + done_items, d_valid, items, hipMemcpyDeviceToHost);
+        if (c != hipSuccess) {
+            cleanup();
+            return fail(e, VK_E_HIP, "hipMemcpy D2H failed in vk_generate");
+        }
+        done_items += items;
+        if (span == left) break;
+        cur += span + 1;
+    }
+    cleanup();
+    local.inputs = hi - lo + 1;
+    if (out) *out = local;
+    return VK_OK;
+}
+
+extern "C" int vk_derive_batch(vk_engine *e, const uint8_t *keys, size_t n, uint8_t *normalised, uint8_t *h160_c, uint8_t *h160_u)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (n == 0) return VK_OK;
+    if (!keys) return fail(e, VK_E_INVALID_ARG, "keys is NULL");
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t chunk = 1u << 22;
+    u32 *d_in = nullptr, *d_priv = nullptr, *d_hc = nullptr, *d_hu = nullptr;
+    const size_t cn = std::min(n, chunk);
+    HIPCHK(e, hipMalloc(&d_in, cn * 32));
+    HIPCHK(e, hipMalloc(&d_priv, cn * 32));
+    HIPCHK(e, hipMalloc(&d_hc, cn * 20));
+    HIPCHK(e, hipMalloc(&d_hu, cn * 20));
+    auto cleanup = [&]() {
+        (void)hipFree(d_in);
+        (void)hipFree(d_priv);
+        (void)hipFree(d_hc);
+        (void)hipFree(d_hu);
+    };
+    vk_spec_dev spec = {VK_T_RAWKEYS, 0, 0, 0};
+    const u32 flags = (h160_u ? VK_F_UNCOMPRESSED : 0u) | ((h160_c || !h160_u) ? VK_F_COMPRESSED : 0u) | VK_F_EMIT;
+    for (size_t done = 0; done < n; done += chunk) {
+        const size_t m = std::min(chunk, n - done);
+        hipError_t c = hipMemcpy(d_in, keys + done * 32, m * 32, hipMemcpyHostToDevice);
+        if (c != hipSuccess) {
+            cleanup();
+            return fail(e, VK_E_HIP, "hipMemcpy H2D failed in vk_derive_batch");
+        }
+        launch_io io;
+        io.in_keys = d_in;
+        io.out_priv = d_priv;
+        io.out_h160c = d_hc;
+        io.out_h160u = d_hu;
+        vk_sweep_stats st;
+        memset(&st, 0, sizeof st);
+        int rc = run_range(e, spec, VK_T_RAWKEYS, 1, 0, m - 1, flags, io, &st);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+        if (normalised && c == hipSuccess) c = hipMemcpy(normalised + done * 32, d_priv, m * 32, hipMemcpyDeviceToHost);
+        if (h160_c && c == hipSuccess) c = hipMemcpy(h160_c + done * 20, d_hc, m * 20, hipMemcpyDeviceToHost);
+        if (h160_u && c == hipSuccess) c = hipMemcpy(h160_u + done * 20, d_hu, m * 20, hipMemcpyDeviceToHost);
+        if (c != hipSuccess) {
+            cleanup();
+            return fail(e, VK_E_HIP, "hipMemcpy D2H failed in vk_derive_batch");
+        }
+    }
+    cleanup();
+    return VK_OK;
+}
+
+template <u32 KIND>
+static void launch_transform(const vk_spec_dev &s, const u64 *seeds, u64 n, u32 slots, u32 *keys, unsigned char *valid, hipStream_t st)
+{
+    const u64 items = n * slots;
+    hipLaunchKernelGGL(vk_transform_kernel<KIND>, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, st, s, seeds, n,
+                       slots, keys, valid);
+}
+
+extern "C" int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, const uint64_t *seeds, size_t n, uint8_t *keys_out,
+                                  uint8_t *valid)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int rc = validate_spec(e, t);
+    if (rc) return rc;
+    if (n == 0) return VK_OK;
+    if (!seeds || !keys_out || !valid) return fail(e, VK_E_INVALID_ARG, "seeds / keys_out / valid is NULL");
+    const u32 slots = vk_slots_per_input(t);
+    if ((u64)n * slots > (1ull << 31)) return fail(e, VK_E_INVALID_ARG, "too many keys for one vk_transform_batch call (max 2^31)");
+    HIPCHK(e, hipSetDevice(e->device));
+    const vk_spec_dev spec = to_dev(t);
+    u64 *d_seeds = nullptr;
+    u32 *d_keys = nullptr;
+    unsigned char *d_valid = nullptr;
+    const u64 items = (u64)n * slots;
+    HIPCHK(e, hipMalloc(&d_seeds, n * 8));
+    HIPCHK(e, hipMalloc(&d_keys, items * 32));
+    HIPCHK(e, hipMalloc(&d_valid, items));
+    auto cleanup = [&]() {
+        (void)hipFree(d_seeds);
+        (void)hipFree(d_keys);
+        (void)hipFree(d_valid);
+    };
+    hipError_t c = hipMemcpy(d_seeds, seeds, n * 8, hipMemcpyHostToDevice);
+    if (c == hipSuccess) {
+        switch (t->kind) {
+        case VK_T_SHA256: launch_transform<VK_T_SHA256>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
+        case VK_T_MILKSAD: launch_transform<VK_T_MILKSAD>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
+        case VK_T_MT64: launch_transform<VK_T_MT64>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
+        case VK_T_LCG: launch_transform<VK_T_LCG>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
+        case VK_T_XORSHIFT: launch_transform<VK_T_XORSHIFT>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
+        case VK_T_SHA256_CHAIN: launch_transform<VK_T_SHA256_CHAIN>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
+        default: cleanup(); return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
+        }
+        c = hipGetLastError();
+    }
+    if (c == hipSuccess) c = hipStreamSynchronize(e->stream);
+    if (c == hipSuccess) c = hipMemcpy(keys_out, d_keys, items * 32, hipMemcpyDeviceToHost);
+    if (c == hipSuccess) c = hipMemcpy(valid, d_valid, items, hipMemcpyDeviceToHost);
+    cleanup();
+    if (c != hipSuccess) {
+        e->err = std::string("vk_transform_batch: ") + hipGetErrorString(c);
+        return VK_E_HIP;
+    }
+    return VK_OK;
+}
+
+// ------------------------------------------------------------------------- test hooks
+extern "C" int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digit, uint8_t xy[64])
+{
+    if (!e || !xy) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (window >= e->nwin || digit >= (1u << e->W)) return fail(e, VK_E_INVALID_ARG, "table index out of range");
+    HIPCHK(e, hipSetDevice(e->device));
+    u32 raw[16];
+    HIPCHK(e, hipMemcpy(raw, e->table + (((size_t)window << e->W) + digit) * 4, 64, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) {
+        u32 xv = raw[7 - i], yv = raw[8 + 7 - i];
+        xy[4 * i] = (uint8_t)(xv >> 24); xy[4 * i + 1] = (uint8_t)(xv >> 16); xy[4 * i + 2] = (uint8_t)(xv >> 8); xy[4 * i + 3] = (uint8_t)xv;
+        xy[32 + 4 * i] = (uint8_t)(yv >> 24); xy[32 + 4 * i + 1] = (uint8_t)(yv >> 16); xy[32 + 4 * i + 2] = (uint8_t)(yv >> 8); xy[32 + 4 * i + 3] = (uint8_t)yv;
+    }
+    return VK_OK;
+}
+
+extern "C" int vk_debug_field(vk_engine *e, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out)
+{
+    if (!e || !a || !out || n == 0) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHK(e, hipSetDevice(e->device));
+    u32 *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(e, hipMalloc(&da, n * 32));
+    HIPCHK(e, hipMalloc(&dout, n * 32));
+    hipError_t c = hipMemcpy(da, a, n * 32, hipMemcpyHostToDevice);
+    if (b && c == hipSuccess) {
+        c = hipMalloc(&db, n * 32);
+        if (c == hipSuccess) c = hipMemcpy(db, b, n * 32, hipMemcpyHostToDevice);
+    }
+    if (c == hipSuccess) {
+        hipLaunchKernelGGL(vk_field_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, e->stream, op, da, db, (u64)n, dout);
+        c = hipGetLastError();
+    }
+    if (c == hipSuccess) c = hipStreamSynchronize(e->stream);
+    if (c == hipSuccess) c = hipMemcpy(out, dout, n * 32, hipMemcpyDeviceToHost);
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dout);
+    if (c != hipSuccess) {
+        e->err = std::string("vk_debug_field: ") + hipGetErrorString(c);
+        return VK_E_HIP;
+    }
+    return VK_OK;
+}

@@ -1,0 +1,188 @@
+// vk_hash.cuh -- SHA-256 and RIPEMD-160 compression for gfx950 lanes, fully unrolled with a
+// 16-word rolling message schedule in VGPRs (no scratch), specialised for the message shapes
+// on the hot path: 33-byte and 65-byte SEC1 public keys, 32-byte digests, and <= 55-byte
+// transform inputs.  Stands in for bitcoin_hashes (hash160 inside Address::p2pkh,
+// src/derive.rs:112-118) and sha2 (src/transform/sha256.rs:16-26) of the reference.
+#pragma once
+#include "vk_field.cuh"
+
+VK_DEV u32 rotr32(u32 x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+VK_DEV u32 rotl32(u32 x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
+VK_DEV u32 bswap32(u32 x) { return __builtin_bswap32(x); }
+
+__device__ __constant__ const u32 VK_K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
+    0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+#define VK_SHA256_IV {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u}
+
+// one compression; w[16] is consumed (used as the rolling schedule)
+VK_DEV void sha256_compress(u32 st[8], u32 w[16])
+{
+    u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (i >= 16) {
+            u32 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            u32 s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+            u32 s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        }
+        u32 S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+        u32 ch = g ^ (e & (f ^ g));
+        u32 t1 = h + S1 + ch + VK_K256[i] + w[i & 15];
+        u32 S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+        u32 mj = (a & b) | (c & (a | b));
+        u32 t2 = S0 + mj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+// SHA-256 of a single pre-padded block
+VK_DEV void sha256_oneblock(u32 out[8], u32 w[16])
+{
+    u32 st[8] = VK_SHA256_IV;
+    sha256_compress(st, w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = st[i];
+}
+
+// SHA-256 of a 32-byte message given as 8 big-endian words
+VK_DEV void sha256_of_digest(u32 out[8], const u32 in[8])
+{
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = in[i];
+    w[8] = 0x80000000u;
+#pragma unroll
+    for (int i = 9; i < 15; i++) w[i] = 0;
+    w[15] = 256;
+    sha256_oneblock(out, w);
+}
+
+// big-endian word j (0 = most significant) of a canonical field element
+#define FE_BE(f, j) ((f).v[7 - (j)])
+
+// SHA-256(0x02|0x03 || X): the 33-byte compressed SEC1 key, one block
+VK_DEV void sha256_pub33(u32 out[8], const fe &x, u32 y_odd)
+{
+    u32 w[16];
+    w[0] = ((0x02u | y_odd) << 24) | (FE_BE(x, 0) >> 8);
+#pragma unroll
+    for (int i = 1; i < 8; i++) w[i] = (FE_BE(x, i - 1) << 24) | (FE_BE(x, i) >> 8);
+    w[8] = (FE_BE(x, 7) << 24) | 0x00800000u;
+#pragma unroll
+    for (int i = 9; i < 15; i++) w[i] = 0;
+    w[15] = 33 * 8;
+    sha256_oneblock(out, w);
+}
+
+// SHA-256(0x04 || X || Y): the 65-byte uncompressed SEC1 key, two blocks
+VK_DEV void sha256_pub65(u32 out[8], const fe &x, const fe &y)
+{
+    u32 w[16];
+    u32 st[8] = VK_SHA256_IV;
+    w[0] = (0x04u << 24) | (FE_BE(x, 0) >> 8);
+#pragma unroll
+    for (int i = 1; i < 8; i++) w[i] = (FE_BE(x, i - 1) << 24) | (FE_BE(x, i) >> 8);
+    w[8] = (FE_BE(x, 7) << 24) | (FE_BE(y, 0) >> 8);
+#pragma unroll
+    for (int i = 1; i < 8; i++) w[8 + i] = (FE_BE(y, i - 1) << 24) | (FE_BE(y, i) >> 8);
+    sha256_compress(st, w);
+    w[0] = (FE_BE(y, 7) << 24) | 0x00800000u;
+#pragma unroll
+    for (int i = 1; i < 15; i++) w[i] = 0;
+    w[15] = 65 * 8;
+    sha256_compress(st, w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = st[i];
+}
+
+// ------------------------------------------------------------------ RIPEMD-160
+VK_DEV u32 rmd_f1(u32 x, u32 y, u32 z) { return x ^ y ^ z; }
+VK_DEV u32 rmd_f2(u32 x, u32 y, u32 z) { return z ^ (x & (y ^ z)); }       // (x&y)|(~x&z)
+VK_DEV u32 rmd_f3(u32 x, u32 y, u32 z) { return (x | ~y) ^ z; }
+VK_DEV u32 rmd_f4(u32 x, u32 y, u32 z) { return y ^ (z & (x ^ y)); }       // (x&z)|(y&~z)
+VK_DEV u32 rmd_f5(u32 x, u32 y, u32 z) { return x ^ (y | ~z); }
+
+// Message-word order and rotate amounts of the two lines (RIPEMD-160 paper, tables r, r', s, s').
+// The loops below are fully unrolled, so every table lookup folds to an immediate.
+__device__ __constant__ const unsigned char VK_RMD_RL[80] = {
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 7, 4, 13, 1, 10, 6, 15, 3, 12, 0, 9, 5, 2, 14, 11, 8,
+    3, 10, 14, 4, 9, 15, 8, 1, 2, 7, 0, 6, 13, 11, 5, 12, 1, 9, 11, 10, 0, 8, 12, 4, 13, 3, 7, 15, 14, 5, 6, 2,
+    4, 0, 5, 9, 7, 12, 2, 10, 14, 1, 3, 8, 11, 6, 15, 13};
+__device__ __constant__ const unsigned char VK_RMD_RR[80] = {
+    5, 14, 7, 0, 9, 2, 11, 4, 13, 6, 15, 8, 1, 10, 3, 12, 6, 11, 3, 7, 0, 13, 5, 10, 14, 15, 8, 12, 4, 9, 1, 2,
+    15, 5, 1, 3, 7, 14, 6, 9, 11, 8, 12, 2, 10, 0, 4, 13, 8, 6, 4, 1, 3, 11, 15, 0, 5, 12, 2, 13, 9, 7, 10, 14,
+    12, 15, 10, 4, 1, 5, 8, 7, 6, 2, 13, 14, 0, 3, 9, 11};
+__device__ __constant__ const unsigned char VK_RMD_SL[80] = {
+    11, 14, 15, 12, 5, 8, 7, 9, 11, 13, 14, 15, 6, 7, 9, 8, 7, 6, 8, 13, 11, 9, 7, 15, 7, 12, 15, 9, 11, 7, 13, 12,
+    11, 13, 6, 7, 14, 9, 13, 15, 14, 8, 13, 6, 5, 12, 7, 5, 11, 12, 14, 15, 14, 15, 9, 8, 9, 14, 5, 6, 8, 6, 5, 12,
+    9, 15, 5, 11, 6, 8, 13, 12, 5, 12, 13, 14, 11, 8, 5, 6};
+__device__ __constant__ const unsigned char VK_RMD_SR[80] = {
+    8, 9, 9, 11, 13, 15, 15, 5, 7, 7, 8, 11, 14, 14, 12, 6, 9, 13, 15, 7, 12, 8, 9, 11, 7, 7, 12, 7, 6, 15, 13, 11,
+    9, 7, 15, 11, 8, 6, 6, 14, 12, 13, 5, 14, 13, 13, 7, 5, 15, 5, 8, 11, 14, 14, 6, 14, 6, 9, 12, 9, 12, 5, 15, 8,
+    8, 5, 12, 9, 12, 5, 14, 6, 8, 13, 6, 5, 15, 13, 11, 11};
+
+VK_DEV u32 rmd_f(int round, u32 x, u32 y, u32 z)
+{
+    switch (round) {
+    case 0: return rmd_f1(x, y, z);
+    case 1: return rmd_f2(x, y, z);
+    case 2: return rmd_f3(x, y, z);
+    case 3: return rmd_f4(x, y, z);
+    default: return rmd_f5(x, y, z);
+    }
+}
+
+// RIPEMD-160 of a 32-byte message: in[8] = SHA-256 state words (big-endian words of the digest).
+// out[5] = state words; the 20 digest bytes are their little-endian serialisation.
+VK_DEV void ripemd160_of_digest(u32 out[5], const u32 in[8])
+{
+    u32 x[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = bswap32(in[i]);
+    x[8] = 0x80u;
+#pragma unroll
+    for (int i = 9; i < 14; i++) x[i] = 0;
+    x[14] = 256;
+    x[15] = 0;
+    const u32 KL[5] = {0x00000000u, 0x5a827999u, 0x6ed9eba1u, 0x8f1bbcdcu, 0xa953fd4eu};
+    const u32 KR[5] = {0x50a28be6u, 0x5c4dd124u, 0x6d703ef3u, 0x7a6d76e9u, 0x00000000u};
+    const u32 h0 = 0x67452301u, h1 = 0xefcdab89u, h2 = 0x98badcfeu, h3 = 0x10325476u, h4 = 0xc3d2e1f0u;
+    u32 al = h0, bl = h1, cl = h2, dl = h3, el = h4;
+    u32 ar = h0, br = h1, cr = h2, dr = h3, er = h4;
+#pragma unroll
+    for (int j = 0; j < 80; j++) {
+        u32 t = rotl32(al + rmd_f(j >> 4, bl, cl, dl) + x[VK_RMD_RL[j]] + KL[j >> 4], VK_RMD_SL[j]) + el;
+        al = el; el = dl; dl = rotl32(cl, 10); cl = bl; bl = t;
+        t = rotl32(ar + rmd_f(4 - (j >> 4), br, cr, dr) + x[VK_RMD_RR[j]] + KR[j >> 4], VK_RMD_SR[j]) + er;
+        ar = er; er = dr; dr = rotl32(cr, 10); cr = br; br = t;
+    }
+    out[0] = h1 + cl + dr;
+    out[1] = h2 + dl + er;
+    out[2] = h3 + el + ar;
+    out[3] = h4 + al + br;
+    out[4] = h0 + bl + cr;
+}
+
+// hash160 words (RIPEMD-160 state) of the compressed / uncompressed SEC1 encodings
+VK_DEV void hash160_pub33(u32 out[5], const fe &x, u32 y_odd)
+{
+    u32 d[8];
+    sha256_pub33(d, x, y_odd);
+    ripemd160_of_digest(out, d);
+}
+VK_DEV void hash160_pub65(u32 out[5], const fe &x, const fe &y)
+{
+    u32 d[8];
+    sha256_pub65(d, x, y);
+    ripemd160_of_digest(out, d);
+}

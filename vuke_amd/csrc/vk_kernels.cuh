@@ -1,0 +1,352 @@
+// vk_kernels.cuh -- the fused sweep kernel: seed -> key -> k*G -> hash160 -> probe, on gfx950.
+//
+// Shape of one workgroup tile (256 lanes, B = R * slots items per lane):
+//   pass 1  for each item: transform -> normalise -> ecmult_table -> Jacobian (X, Y, Z);
+//           running product c_b = Z_0..Z_b; (X, Y, Z, c_b) parked in an HBM workspace laid out
+//           [item][quad][thread] so every access is a 16-byte-per-lane coalesced line.
+//   invert  one field inversion of c_{B-1} per lane (Montgomery's trick: 3 multiplies per key
+//           instead of a 255-squaring inversion per key).
+//   pass 2  walk the items backwards: zinv_b = inv * c_{b-1}; inv *= Z_b; affine (x, y);
+//           SHA-256 + RIPEMD-160 of the SEC1 encoding(s); digest fold; open-address probe of
+//           the target table; hit record / generate-mode record.
+// No LDS, no cross-lane traffic in the loop, no MFMA: the path is integer-VALU bound; the
+// only memory streams are the table gathers (64 B per window, L2 / Infinity-Cache resident),
+// the workspace (256 B per key) and one 32-byte probe line per hash160.
+//
+// Replaces the closure body of RangeSource::process (reference src/source/range.rs:42-70):
+// Transform::apply_batch -> KeyDeriver::derive -> Matcher::check -> counters.
+#pragma once
+#include "vk_ec.cuh"
+#include "vk_transforms.cuh"
+
+#define VK_F_COMPRESSED 1u
+#define VK_F_UNCOMPRESSED 2u
+#define VK_F_EMIT 0x10000u /* internal: generate-mode records */
+
+#define VK_BLOCK 256
+
+struct vk_hit_dev { // must match vk_hit in include/vuke_hip.h (72 bytes)
+    u64 seed;
+    u32 sub_index;
+    u32 addr_kind;
+    u32 privkey[8]; // raw bytes, i.e. big-endian words already byte-swapped for memory
+    u32 h160[5];
+    u32 pad;
+};
+
+struct vk_sweep_params {
+    vk_spec_dev spec;
+    u64 lo;         // first input
+    u64 span;       // last input - lo (inclusive range => span + 1 inputs)
+    u64 ntiles;
+    u32 slots;      // slots per input
+    u32 R;          // inputs per lane per tile
+    u32 flags;
+    u32 W, nwin;
+    u32 tgt_mask;   // capacity - 1 (power of two), valid when tgt != nullptr
+    u32 hit_cap;
+    u32 pad0;
+    const uint4 *table;
+    const uint4 *tgt;  // slots of 2 x uint4: {h0,h1,h2,h3}, {h4, kindbits, 0, 0}
+    vk_hit_dev *hits;
+    u64 *stats;        // [0] keys [1] matches [2] hit cursor [3..6] digest
+    uint4 *work;       // batch-inversion workspace
+    const u32 *in_keys;   // VK_T_RAWKEYS: n x 8 words (raw bytes)
+    u32 *out_priv;     // generate mode: n_items x 8 words (raw bytes)
+    u32 *out_h160c;    // n_items x 5 words
+    u32 *out_h160u;
+    unsigned char *out_valid;
+};
+
+VK_DEV u32 probe_targets(const uint4 *__restrict__ tgt, u32 mask, const u32 h[5])
+{
+    u32 i = h[0] & mask;
+#pragma unroll 1
+    for (u32 n = 0; n <= mask; n++) {
+        uint4 a = tgt[2 * (size_t)i], b = tgt[2 * (size_t)i + 1];
+        if (b.y == 0) return 0; // empty slot
+        if (a.x == h[0] && a.y == h[1] && a.z == h[2] && a.w == h[3] && b.x == h[4]) return b.y;
+        i = (i + 1) & mask;
+    }
+    return 0;
+}
+
+VK_DEV void digest_fold(u64 dg[4], const u32 h[5])
+{
+    u64 a = (u64)h[0] | ((u64)h[1] << 32), b = (u64)h[2] | ((u64)h[3] << 32);
+    dg[0] ^= a;
+    dg[1] ^= b;
+    dg[2] ^= (u64)h[4];
+    dg[3] += a + b + h[4];
+}
+
+VK_DEV void work_store(uint4 *base, u64 stride, const fe &f)
+{
+    base[0] = make_uint4(f.v[0], f.v[1], f.v[2], f.v[3]);
+    base[stride] = make_uint4(f.v[4], f.v[5], f.v[6], f.v[7]);
+}
+VK_DEV void work_load(fe &f, const uint4 *base, u64 stride)
+{
+    uint4 a = base[0], b = base[stride];
+    f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+    f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+
+VK_DEV u64 wave_xor(u64 v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
+    return v;
+}
+VK_DEV u64 wave_add(u64 v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// produce the key words for item (off, sub); returns false where the reference emits nothing
+template <u32 KIND>
+VK_DEV bool item_key(u32 kw[8], const vk_sweep_params &p, u64 off, u32 sub)
+{
+    if (off > p.span) return false;
+    if (KIND == VK_T_RAWKEYS) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.in_keys) + off * 2;
+        uint4 a = src[0], b = src[1];
+        kw[0] = bswap32(a.x); kw[1] = bswap32(a.y); kw[2] = bswap32(a.z); kw[3] = bswap32(a.w);
+        kw[4] = bswap32(b.x); kw[5] = bswap32(b.y); kw[6] = bswap32(b.z); kw[7] = bswap32(b.w);
+        return true;
+    }
+    return transform_key<KIND>(kw, p.spec, p.lo + off, sub);
+}
+
+template <u32 KIND>
+__global__ void __launch_bounds__(VK_BLOCK) vk_sweep_kernel(const vk_sweep_params p)
+{
+    const u32 tid = threadIdx.x;
+    const u64 gtid = (u64)blockIdx.x * VK_BLOCK + tid;
+    const u64 nth = (u64)gridDim.x * VK_BLOCK;
+    const u32 B = p.R * p.slots;
+    u64 n_keys = 0, n_match = 0;
+    u64 dg[4] = {0, 0, 0, 0};
+    uint4 *wk = p.work + gtid; // item b, quad q lives at wk[(b*8 + q) * nth]
+
+#pragma unroll 1
+    for (u64 tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const u64 tile_off = tile * ((u64)VK_BLOCK * p.R);
+        // ---------------------------------------------------------------- pass 1
+        fe c;
+        u32 r = 0, sub = 0;
+#pragma unroll 1
+        for (u32 b = 0; b < B; b++) {
+            const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
+            u32 kw[8];
+            jac P;
+            if (item_key<KIND>(kw, p, off, sub)) {
+                u32 k[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) k[i] = kw[7 - i];
+                scalar_normalize(k);
+                ecmult_table(P, k, p.table, p.W, p.nwin);
+            } else { // (0, 0, 1) marks "no key here"; (0,0) is not on the curve
+                fe_set_zero(P.x);
+                fe_set_zero(P.y);
+                fe_set_one(P.z);
+            }
+            if (b == 0) c = P.z;
+            else fe_mul(c, c, P.z);
+            uint4 *it = wk + (u64)b * 8 * nth;
+            work_store(it, nth, P.x);
+            work_store(it + 2 * nth, nth, P.y);
+            work_store(it + 4 * nth, nth, P.z);
+            work_store(it + 6 * nth, nth, c);
+            if (++sub == p.slots) {
+                sub = 0;
+                r++;
+            }
+        }
+        // ---------------------------------------------------------------- invert
+        fe inv;
+        fe_inv(inv, c);
+        // ---------------------------------------------------------------- pass 2
+#pragma unroll 1
+        for (u32 bb = B; bb > 0; bb--) {
+            const u32 b = bb - 1;
+            if (sub == 0) {
+                sub = p.slots - 1;
+                r--;
+            } else {
+                sub--;
+            }
+            const uint4 *it = wk + (u64)b * 8 * nth;
+            jac P;
+            fe zinv;
+            work_load(P.x, it, nth);
+            work_load(P.y, it + 2 * nth, nth);
+            work_load(P.z, it + 4 * nth, nth);
+            if (b > 0) {
+                fe cp;
+                work_load(cp, it - 2 * nth, nth); // c of item b-1
+                fe_mul(zinv, inv, cp);
+                fe_mul(inv, inv, P.z);
+            } else {
+                zinv = inv;
+            }
+            u32 nz = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) nz |= P.x.v[i] | P.y.v[i];
+            if (nz == 0) continue;
+            fe x, y;
+            jac_to_affine(x, y, P, zinv);
+            n_keys++;
+            const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
+            u32 hc[5], hu[5];
+            u32 bits_c = 0, bits_u = 0;
+            if (p.flags & VK_F_COMPRESSED) {
+                hash160_pub33(hc, x, y.v[0] & 1u);
+                digest_fold(dg, hc);
+                if (p.tgt) bits_c = probe_targets(p.tgt, p.tgt_mask, hc);
+            }
+            if (p.flags & VK_F_UNCOMPRESSED) {
+                hash160_pub65(hu, x, y);
+                digest_fold(dg, hu);
+                if (p.tgt) bits_u = probe_targets(p.tgt, p.tgt_mask, hu);
+            }
+            // Matcher::check order (reference src/matcher.rs:72-98): p2pkh(c), p2pkh(u), p2wpkh
+            int kind = -1;
+            if (bits_c & 1u) kind = 0;
+            else if (bits_u & 1u) kind = 1;
+            else if (bits_c & 2u) kind = 2;
+            const bool emit = (p.flags & VK_F_EMIT) != 0;
+            if (kind >= 0 || emit) {
+                // rare (or output-bound) path: regenerate the normalised key bytes
+                u32 kw[8], k[8];
+                item_key<KIND>(kw, p, off, sub);
+#pragma unroll
+                for (int i = 0; i < 8; i++) k[i] = kw[7 - i];
+                scalar_normalize(k);
+                if (kind >= 0) {
+                    n_match++;
+                    u64 slot = atomicAdd((unsigned long long *)&p.stats[2], 1ull);
+                    if (slot < p.hit_cap) {
+                        vk_hit_dev *h = p.hits + slot;
+                        h->seed = p.lo + off;
+                        h->sub_index = sub;
+                        h->addr_kind = (u32)kind;
+#pragma unroll
+                        for (int i = 0; i < 8; i++) h->privkey[i] = bswap32(k[7 - i]);
+#pragma unroll
+                        for (int i = 0; i < 5; i++) h->h160[i] = (kind == 1) ? hu[i] : hc[i];
+                        h->pad = 0;
+                    }
+                }
+                if (emit) {
+                    const u64 item = off * p.slots + sub;
+                    if (p.out_valid) p.out_valid[item] = 1;
+                    if (p.out_priv) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) p.out_priv[item * 8 + i] = bswap32(k[7 - i]);
+                    }
+                    if (p.out_h160c && (p.flags & VK_F_COMPRESSED)) {
+#pragma unroll
+                        for (int i = 0; i < 5; i++) p.out_h160c[item * 5 + i] = hc[i];
+                    }
+                    if (p.out_h160u && (p.flags & VK_F_UNCOMPRESSED)) {
+#pragma unroll
+                        for (int i = 0; i < 5; i++) p.out_h160u[item * 5 + i] = hu[i];
+                    }
+                }
+            }
+        }
+    }
+    // ------------------------------------------------------------------- counters
+    n_keys = wave_add(n_keys);
+    n_match = wave_add(n_match);
+    dg[0] = wave_xor(dg[0]);
+    dg[1] = wave_xor(dg[1]);
+    dg[2] = wave_xor(dg[2]);
+    dg[3] = wave_add(dg[3]);
+    if ((tid & 63) == 0) {
+        atomicAdd((unsigned long long *)&p.stats[0], (unsigned long long)n_keys);
+        atomicAdd((unsigned long long *)&p.stats[1], (unsigned long long)n_match);
+        atomicXor((unsigned long long *)&p.stats[3], (unsigned long long)dg[0]);
+        atomicXor((unsigned long long *)&p.stats[4], (unsigned long long)dg[1]);
+        atomicXor((unsigned long long *)&p.stats[5], (unsigned long long)dg[2]);
+        atomicAdd((unsigned long long *)&p.stats[6], (unsigned long long)dg[3]);
+    }
+}
+
+// ---------------------------------------------------------------- table builder
+// entry (w, d) = (d << (W*w)) * G, affine canonical; d = 0 and unrepresentable entries = 0.
+__global__ void __launch_bounds__(VK_BLOCK) vk_table_kernel(uint4 *table, u32 W, u32 nwin)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    const u64 total = (u64)nwin << W;
+    if (idx >= total) return;
+    const u32 d = (u32)(idx & ((1u << W) - 1u)), w = (u32)(idx >> W);
+    uint4 *dst = table + idx * 4;
+    const u32 shift = W * w;
+    const u32 dbits = 32 - __builtin_clz(d | 1u);
+    if (d == 0 || shift + dbits > 256) {
+        dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    u32 s[8];
+    const u32 limb = shift >> 5, sh = shift & 31;
+    const u64 wide = (u64)d << sh;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 v = 0;
+        v = (limb == (u32)i) ? (u32)wide : v;
+        v = (limb + 1 == (u32)i) ? (u32)(wide >> 32) : v;
+        s[i] = v;
+    }
+    jac P;
+    ecmult_generic(P, s);
+    fe zi, x, y;
+    fe_inv(zi, P.z);
+    jac_to_affine(x, y, P, zi);
+    dst[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    dst[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    dst[2] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+    dst[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+}
+
+// ---------------------------------------------------------------- Transform::apply_batch
+template <u32 KIND>
+__global__ void __launch_bounds__(VK_BLOCK) vk_transform_kernel(vk_spec_dev spec, const u64 *seeds, u64 n, u32 slots,
+                                                                u32 *keys_out, unsigned char *valid)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    if (idx >= n * slots) return;
+    const u64 i = idx / slots;
+    const u32 sub = (u32)(idx - i * slots);
+    u32 kw[8];
+    bool ok = transform_key<KIND>(kw, spec, seeds[i], sub);
+#pragma unroll
+    for (int j = 0; j < 8; j++) keys_out[idx * 8 + j] = ok ? bswap32(kw[j]) : 0u;
+    valid[idx] = ok ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- field test hook
+__global__ void vk_field_kernel(int op, const u32 *a, const u32 *b, u64 n, u32 *out)
+{
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    fe x, y, r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { // operands arrive as big-endian bytes
+        x.v[i] = bswap32(a[idx * 8 + 7 - i]);
+        y.v[i] = b ? bswap32(b[idx * 8 + 7 - i]) : 0u;
+    }
+    switch (op) {
+    case 0: fe_mul(r, x, y); break;
+    case 1: fe_sqr(r, x); break;
+    case 2: fe_inv(r, x); break;
+    case 3: fe_add(r, x, y); break;
+    default: fe_sub(r, x, y); break;
+    }
+    fe_canon(r);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[idx * 8 + 7 - i] = bswap32(r.v[i]);
+}

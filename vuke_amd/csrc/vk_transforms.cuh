@@ -1,0 +1,315 @@
+// vk_transforms.cuh -- seed -> 32-byte private key, one (seed, slot) per lane, all in VGPRs.
+//
+// Every function fills kw[8] = the key's bytes as eight big-endian words (kw[0] = bytes 0..3)
+// and returns false where the reference emits nothing for that slot.  Reference behaviour
+// restated (see also oracle/transforms.c for the CPU form the tests compare against):
+//   sha256        src/transform/sha256.rs:13-29
+//   milksad       src/transform/milksad.rs:17-29 (rand_mt Mt::new + fill_bytes, LE words)
+//   mt64          src/mt64.rs:15-20
+//   lcg           src/lcg.rs:68-128, src/transform/lcg.rs:43-72
+//   xorshift      src/xorshift.rs:83-317, src/transform/xorshift.rs:33-52
+//   sha256_chain  src/sha256_chain.rs:88-145, src/transform/sha256_chain.rs:60-94
+#pragma once
+#include "vk_hash.cuh"
+
+#define VK_T_SHA256 0u
+#define VK_T_MILKSAD 1u
+#define VK_T_MT64 2u
+#define VK_T_LCG 3u
+#define VK_T_XORSHIFT 4u
+#define VK_T_SHA256_CHAIN 5u
+#define VK_T_RAWKEYS 100u /* keys come from memory (vk_derive_batch) */
+#define VK_VARIANT_ALL 0xFFFFFFFFu
+
+struct vk_spec_dev {
+    u32 kind, variant, endian, chain_depth;
+};
+
+// ---- byte-stream builder for single-block SHA-256 messages (<= 55 bytes) -------------
+// OR byte `b` into big-endian message position `pos` of w[16] without dynamic indexing.
+VK_DEV void msg_put(u32 w[16], u32 pos, u32 b)
+{
+    u32 wi = pos >> 2, val = b << (24 - 8 * (pos & 3));
+#pragma unroll
+    for (int i = 0; i < 14; i++) w[i] |= (wi == (u32)i) ? val : 0u;
+}
+
+// append the decimal digits of v at byte position pos; returns new position
+VK_DEV u32 msg_put_decimal(u32 w[16], u32 pos, u64 v)
+{
+    // count digits
+    u32 nd = 1;
+    u64 p = 10;
+#pragma unroll 1
+    for (int i = 0; i < 19 && v >= p; i++) {
+        nd++;
+        p *= 10;
+    }
+    u32 at = pos + nd;
+#pragma unroll 1
+    for (u32 i = 0; i < nd; i++) {
+        u64 q = v / 10;
+        msg_put(w, --at, (u32)('0' + (u32)(v - q * 10)));
+        v = q;
+    }
+    return pos + nd;
+}
+
+VK_DEV void msg_finish(u32 w[16], u32 len)
+{
+    msg_put(w, len, 0x80u);
+    w[14] = 0;
+    w[15] = len * 8;
+}
+
+// ---- MT19937 (Milksad) ----------------------------------------------------------------
+VK_DEV u32 mt_init_step(u32 prev, u32 i) { return 1812433253u * (prev ^ (prev >> 30)) + i; }
+
+// Only state words 0..8 and 397..404 of init_genrand(seed) feed the first 8 outputs.
+VK_DEV bool transform_milksad(u32 kw[8], u64 seed)
+{
+    if (seed > 0xFFFFFFFFull) return false;
+    u32 lo[9], hi[8];
+    u32 m = (u32)seed;
+    lo[0] = m;
+#pragma unroll
+    for (int i = 1; i <= 8; i++) {
+        m = mt_init_step(m, (u32)i);
+        lo[i] = m;
+    }
+#pragma unroll 4
+    for (u32 i = 9; i < 397; i++) m = mt_init_step(m, i);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        m = mt_init_step(m, 397u + (u32)i);
+        hi[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 y = (lo[i] & 0x80000000u) | (lo[i + 1] & 0x7fffffffu);
+        u32 v = hi[i] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        v ^= v >> 11;
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= v >> 18;
+        kw[i] = bswap32(v); // key bytes 4i..4i+3 = LE32(v)
+    }
+    return true;
+}
+
+// ---- MT19937-64 -------------------------------------------------------------------------
+VK_DEV u64 mt64_init_step(u64 prev, u64 i) { return 6364136223846793005ull * (prev ^ (prev >> 62)) + i; }
+
+VK_DEV bool transform_mt64(u32 kw[8], u64 seed)
+{
+    u64 lo[5], hi[4];
+    u64 m = seed;
+    lo[0] = m;
+#pragma unroll
+    for (int i = 1; i <= 4; i++) {
+        m = mt64_init_step(m, (u64)i);
+        lo[i] = m;
+    }
+#pragma unroll 4
+    for (u32 i = 5; i < 156; i++) m = mt64_init_step(m, (u64)i);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        m = mt64_init_step(m, 156ull + (u64)i);
+        hi[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 x = (lo[i] & 0xFFFFFFFF80000000ull) | (lo[i + 1] & 0x7FFFFFFFull);
+        u64 v = hi[i] ^ (x >> 1) ^ ((x & 1ull) ? 0xB5026F5AA96619E9ull : 0ull);
+        v ^= (v >> 29) & 0x5555555555555555ull;
+        v ^= (v << 17) & 0x71D67FFFEDA60000ull;
+        v ^= (v << 37) & 0xFFF7EEE000000000ull;
+        v ^= v >> 43;
+        // key bytes 8i..8i+7 = LE64(v)
+        kw[2 * i] = bswap32((u32)v);
+        kw[2 * i + 1] = bswap32((u32)(v >> 32));
+    }
+    return true;
+}
+
+// ---- LCG ------------------------------------------------------------------------------------
+VK_DEV bool transform_lcg(u32 kw[8], u64 seed, u32 variant, u32 little_endian)
+{
+    u64 a, c, m;
+    switch (variant) {
+    case 0: a = 1103515245ull; c = 12345ull; m = 1ull << 31; break;
+    case 1: a = 16807ull; c = 0ull; m = (1ull << 31) - 1; break;
+    case 2: a = 214013ull; c = 2531011ull; m = 1ull << 32; break;
+    case 3: a = 22695477ull; c = 1ull; m = 1ull << 32; break;
+    default: return false;
+    }
+    if (seed > m - 1) return false;
+    u64 st = (u32)seed;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = a * st + c; // < 2^63, no wrap
+        if (variant == 1) {
+            // mod 2^31 - 1 by folding (t < 2^46)
+            t = (t & 0x7FFFFFFFull) + (t >> 31);
+            t = (t & 0x7FFFFFFFull) + (t >> 31);
+            if (t >= 0x7FFFFFFFull) t -= 0x7FFFFFFFull;
+        } else {
+            t &= (m - 1);
+        }
+        st = t;
+        u32 w = (u32)st;
+        kw[i] = little_endian ? bswap32(w) : w;
+    }
+    return true;
+}
+
+// ---- xorshift family ---------------------------------------------------------------------
+VK_DEV u64 rotl64(u64 x, int n) { return (x << n) | (x >> (64 - n)); }
+VK_DEV u64 splitmix64(u64 x)
+{
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+
+VK_DEV bool transform_xorshift(u32 kw[8], u64 seed, u32 variant)
+{
+    if (seed == 0) seed = 1;
+    if (variant == 0) {
+        u64 x = seed;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            x ^= x << 13;
+            x ^= x >> 7;
+            x ^= x << 17;
+            kw[2 * i] = (u32)(x >> 32);
+            kw[2 * i + 1] = (u32)x;
+        }
+        return true;
+    }
+    if (variant == 1) {
+        u32 x = (u32)seed, y = (u32)(seed >> 32);
+        u32 z = (u32)seed ^ 0x12345678u, w = (u32)(seed >> 32) ^ 0x87654321u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            u32 t = x ^ (x << 11);
+            x = y;
+            y = z;
+            z = w;
+            w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+            kw[i] = w;
+        }
+        return true;
+    }
+    if (variant == 2 || variant == 3) {
+        u64 s0 = splitmix64(seed), s1 = splitmix64(s0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            u64 r = (variant == 2) ? s0 + s1 : rotl64(s0 * 5, 7) * 9;
+            u64 t = s1 ^ s0;
+            s0 = rotl64(s0, 24) ^ t ^ (t << 16);
+            s1 = rotl64(t, 37);
+            kw[2 * i] = (u32)(r >> 32);
+            kw[2 * i + 1] = (u32)r;
+        }
+        return true;
+    }
+    return false;
+}
+
+// ---- sha256 ------------------------------------------------------------------------------------
+VK_DEV bool transform_sha256(u32 kw[8], u64 seed, u32 sub)
+{
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = 0;
+    if (sub == 0) {
+        u32 len = msg_put_decimal(w, 0, seed);
+        msg_finish(w, len);
+    } else if (sub == 1) {
+        w[0] = (u32)(seed >> 32);
+        w[1] = (u32)seed;
+        w[2] = 0x80000000u;
+        w[15] = 64;
+    } else if (sub == 2) {
+        w[0] = bswap32((u32)seed);
+        w[1] = bswap32((u32)(seed >> 32));
+        w[2] = 0x80000000u;
+        w[15] = 64;
+    } else {
+        return false;
+    }
+    sha256_oneblock(kw, w);
+    return true;
+}
+
+// ---- sha256_chain ---------------------------------------------------------------------------
+// slot = form*(V*D) + v*D + idx; form 0: seed bytes = decimal string, form 1: 4-byte BE (u32 only)
+VK_DEV bool transform_sha256_chain(u32 kw[8], u64 seed, u32 sub, u32 spec_variant, u32 depth)
+{
+    u32 nv = (spec_variant == VK_VARIANT_ALL) ? 4u : 1u;
+    if (depth == 0 || sub >= 2u * nv * depth) return false;
+    u32 form = sub / (nv * depth), r = sub % (nv * depth);
+    u32 v = (spec_variant == VK_VARIANT_ALL) ? r / depth : spec_variant, idx = r % depth;
+    if (form == 1 && seed > 0xFFFFFFFFull) return false;
+    if (v > 3) return false;
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = 0;
+    u32 len;
+    if (form == 0) {
+        len = msg_put_decimal(w, 0, seed);
+    } else {
+        w[0] = (u32)seed;
+        len = 4;
+    }
+    if (v == 1 || v == 2) {
+        u32 iw = (v == 1) ? idx : bswap32(idx);
+        msg_put(w, len, iw >> 24);
+        msg_put(w, len + 1, (iw >> 16) & 0xff);
+        msg_put(w, len + 2, (iw >> 8) & 0xff);
+        msg_put(w, len + 3, iw & 0xff);
+        len += 4;
+    } else if (v == 3) {
+        len = msg_put_decimal(w, len, (u64)idx);
+    }
+    msg_finish(w, len);
+    sha256_oneblock(kw, w);
+    if (v == 0) {
+#pragma unroll 1
+        for (u32 i = 0; i < idx; i++) {
+            u32 t[8];
+            sha256_of_digest(t, kw);
+#pragma unroll
+            for (int j = 0; j < 8; j++) kw[j] = t[j];
+        }
+    }
+    return true;
+}
+
+// ---- dispatch ------------------------------------------------------------------------------
+VK_DEV u32 spec_slots(const vk_spec_dev &s)
+{
+    switch (s.kind) {
+    case VK_T_SHA256: return 3;
+    case VK_T_MILKSAD:
+    case VK_T_MT64: return 1;
+    case VK_T_LCG:
+    case VK_T_XORSHIFT: return s.variant == VK_VARIANT_ALL ? 4u : 1u;
+    case VK_T_SHA256_CHAIN: return 2u * (s.variant == VK_VARIANT_ALL ? 4u : 1u) * s.chain_depth;
+    default: return 1;
+    }
+}
+
+template <u32 KIND>
+VK_DEV bool transform_key(u32 kw[8], const vk_spec_dev &s, u64 seed, u32 sub)
+{
+    if (KIND == VK_T_SHA256) return transform_sha256(kw, seed, sub);
+    if (KIND == VK_T_MILKSAD) return transform_milksad(kw, seed);
+    if (KIND == VK_T_MT64) return transform_mt64(kw, seed);
+    if (KIND == VK_T_LCG) return transform_lcg(kw, seed, s.variant == VK_VARIANT_ALL ? sub : s.variant, s.endian);
+    if (KIND == VK_T_XORSHIFT) return transform_xorshift(kw, seed, s.variant == VK_VARIANT_ALL ? sub : s.variant);
+    if (KIND == VK_T_SHA256_CHAIN) return transform_sha256_chain(kw, seed, sub, s.variant, s.chain_depth);
+    return false;
+}
