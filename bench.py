@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- keys/sec (seed -> P2PKH hash160 -> target probe) for the Milksad sweep on MI355X.
+
+Workload (BASELINE.json configs[1]): Milksad (MT19937) seeds, compressed P2PKH, 1024 planted
+targets in the on-device probe table.  One *step* = one 2^28-seed block of the 2^32 seed space
+per GPU (16 steps on one GPU = the whole sweep).  With N GPUs, rank r sweeps blocks
+(r*K + step) mod 16: the seed space is range-partitioned, no data-path collective; RCCL is used
+only to all-reduce the counters after the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see README "bench contract").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BLOCK_LOG2 = 28
+BLOCK = 1 << BLOCK_LOG2
+NBLOCKS = 1 << (32 - BLOCK_LOG2)
+# canonical algorithmic work per Milksad key (32-bit integer ops)
+OPS_PER_KEY = 1736 + 213000 + 2168 + 1455
+# Integer-VALU peak: 256 CUs x 4 SIMD-32 x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md: SIMD-32,
+# a wave64 VALU op issues in 2 cycles; 157.3 TFLOP/s fp32 = 78.6 T FMA lanes/s).  SURVEY.md 8(d)
+# quoted 64 lanes/CU/clk (39.3e12); both fractions are reported.
+PEAK_INT32 = 256 * 128 * 2.4e9
+PEAK_INT32_SURVEY = 256 * 64 * 2.4e9
+N_PLANTED = 1024
+
+
+def planted_seeds():
+    return [(0x9E3779B1 * j + 12345) & 0xFFFFFFFF for j in range(N_PLANTED)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus != 1:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+        sys.exit(2)
+    n_gpus = world
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+
+    eng = vuke_amd.Engine(local_rank, window_bits=args.window_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu)
+    spec = ffi.spec(ffi.T_MILKSAD)
+
+    # synthetic targets: compressed P2PKH hash160 of 1024 known seeds, derived on the device
+    pseeds = planted_seeds()
+    keys = [row[0] for row in eng.transform_batch(spec, pseeds)]
+    _, h160c, _ = eng.derive_batch(keys)
+    eng.targets_set(h160c, [ffi.TARGET_P2PKH] * len(h160c))
+
+    def block_of(step):
+        b = (rank * args.steps + step) % NBLOCKS
+        return b * BLOCK, b * BLOCK + BLOCK - 1
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        lo, hi = block_of(w)
+        eng.sweep(spec, lo, lo + (BLOCK >> 4) - 1, flags=ffi.F_COMPRESSED, hit_cap=N_PLANTED)
+
+    keys_done = matches = expected = 0
+    kernel_s = 0.0
+    launches = 0
+    digest = [0, 0, 0, 0]
+    sync()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        lo, hi = block_of(s)
+        st, hits = eng.sweep(spec, lo, hi, flags=ffi.F_COMPRESSED, hit_cap=N_PLANTED)
+        keys_done += st["keys"]
+        matches += st["matches"]
+        kernel_s += st["kernel_seconds"]
+        launches += st["launches"]
+        for i in range(3):
+            digest[i] ^= st["digest"][i]
+        digest[3] = (digest[3] + st["digest"][3]) & (2**64 - 1)
+        expected += sum(1 for p in pseeds if lo <= p <= hi)
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    # counters: one tiny all-reduce over RCCL (the only collective on this path)
+    tot = torch.tensor([keys_done, matches, expected], dtype=torch.int64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_keys, total_matches, total_expected = (int(x) for x in tot.tolist())
+    t = float(tmax.item())
+    if total_matches != total_expected:
+        print(f"bench.py: PARITY FAILURE: {total_matches} matches, {total_expected} planted seeds in range", file=sys.stderr)
+        sys.exit(3)
+
+    if rank == 0:
+        value = total_keys / t
+        per_launch_keys = keys_done / max(launches, 1)
+        per_launch_s = kernel_s / max(launches, 1)
+        achieved = per_launch_keys * OPS_PER_KEY / per_launch_s
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        extra = {}
+        if os.path.exists(pmc_path):
+            try:
+                pj = json.load(open(pmc_path))
+                traffic = pj.get("hbm_bytes_per_launch")
+                extra = {k: pj[k] for k in ("valu_insts_per_key", "valu_busy_frac", "source") if k in pj}
+            except Exception:
+                pass
+        out = {
+            "metric": "keys/sec (seed->P2PKH addr), Milksad sweep",
+            "value": value,
+            "unit": "keys/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * t / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "Milksad (MT19937) seed sweep, P2PKH compressed, 1024 planted targets; "
+                            f"step = one 2^{BLOCK_LOG2}-seed block per GPU (16 blocks = full 2^32 sweep)",
+                "seeds_per_step_per_gpu": BLOCK,
+                "window_bits": args.window_bits or 16,
+                "parallelism": f"range-partition x{n_gpus}",
+            },
+            "sweep_2p32_seconds_at_this_rate": (1 << 32) / value,
+            "matches": total_matches,
+            "digest": [f"{d:016x}" for d in digest],
+            "roofline": {
+                "bound": "valu-int32",
+                "achieved": achieved / 1e12,
+                "peak": PEAK_INT32 / 1e12,
+                "unit": "Tops/s (canonical 32-bit integer ops, SURVEY 8d: %d per key)" % OPS_PER_KEY,
+                "frac": achieved / PEAK_INT32,
+                "frac_vs_survey_peak_39.3T": achieved / PEAK_INT32_SURVEY,
+                "traffic": traffic,
+                "kernel": "vk_sweep_kernel<MILKSAD>",
+                "kernel_ms_per_launch": 1e3 * per_launch_s,
+                "keys_per_launch": per_launch_keys,
+                **extra,
+            },
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline():
+    """The CPU oracle ("port": our C restatement, not the Rust binary) on the host cores."""
+    from oracle import vko
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("VUKE_CPU_THREADS", "16"))))  # the 1-GPU box's CPU share is 16
+    sp = vko.spec(vko.T_MILKSAD)
+    vko.sweep(sp, 0, 4095, flags=vko.F_COMPRESSED, nthreads=cores)  # builds the table, warms up
+    n = 1 << 21
+    t = time.perf_counter()
+    st, _ = vko.sweep(sp, 0, n - 1, flags=vko.F_COMPRESSED, nthreads=cores)
+    dt = time.perf_counter() - t
+    nf = 1 << 19
+    t = time.perf_counter()
+    stf, _ = vko.sweep(sp, 0, nf - 1, flags=vko.F_COMPRESSED | vko.F_UNCOMPRESSED | vko.F_FAITHFUL, nthreads=cores)
+    dtf = time.perf_counter() - t
+    return {
+        "value": st["keys"] / dt,
+        "unit": "keys/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"Milksad seeds [0, 2^21), compressed hash160 + probe, oracle/ C restatement, {cores} threads, {dt:.1f} s",
+        "ref_faithful_value": stf["keys"] / dtf,
+        "ref_faithful_sample": f"seeds [0, 2^19), everything KeyDeriver::derive does per key (3 x k*G, both hash160, "
+                               f"base58/bech32/WIF/decimal strings), {dtf:.1f} s",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,16 +1,23 @@
-// ubench.hip -- per-instruction VALU throughput on gfx950 for the ops the key-derivation
-// path is made of.  Prints giga-lane-ops/s for the whole chip and cycles per wave-instruction
-// per SIMD.  Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench tools/ubench.hip
+// ubench.hip -- per-instruction VALU throughput on gfx950 for the instructions the
+// key-derivation path is made of (inline asm, so the compiler cannot fold the chains).
+// Reports wave-instructions issue cost in shader cycles per SIMD (clock measured in-kernel
+// with s_memtime / s_memrealtime) and chip-wide lane-ops/s.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench tools/ubench.hip
 #include <hip/hip_runtime.h>
-#include <cstdio>
 #include <cstdint>
-#include <vector>
+#include <cstdio>
 typedef uint32_t u32;
 typedef uint64_t u64;
 #define CHAINS 8
+#define UNROLL 8
+
+enum { ADD, XOR, MULLO, MULHI, MAD64, ALIGNBIT, ADD3, BFI, MAD24, MULHI24, FMA64, ADDC, LSHLADD, XAD, CNDMASK, PERM, NOPS };
+static const char *NAMES[NOPS] = {"v_add_u32", "v_xor_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_alignbit_b32",
+                                  "v_add3_u32", "v_bfi_b32", "v_mad_u32_u24", "v_mul_hi_u32_u24", "v_fma_f64", "v_addc_co_u32",
+                                  "v_lshl_add_u32", "v_xad_u32", "v_cndmask_b32", "v_perm_b32"};
 
 template <int OP>
-__global__ void __launch_bounds__(256) k(u32 *out, u32 seed, int iters)
+__global__ void __launch_bounds__(256) k(u64 *out, u32 seed, int iters)
 {
     u32 t = blockIdx.x * 256 + threadIdx.x;
     u32 a[CHAINS], b[CHAINS];
@@ -23,36 +30,48 @@ __global__ void __launch_bounds__(256) k(u32 *out, u32 seed, int iters)
         c[j] = ((u64)a[j] << 32) | b[j];
         d[j] = 1.0 + 1e-9 * (double)(a[j] & 0xffff);
     }
+    u64 c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; it++) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < UNROLL; u++) {
 #pragma unroll
             for (int j = 0; j < CHAINS; j++) {
-                if (OP == 0) a[j] = a[j] + b[j];
-                if (OP == 1) a[j] = a[j] ^ (b[j] & a[j]) ;            // v_bfi/and+xor class
-                if (OP == 2) a[j] = a[j] * b[j];                      // v_mul_lo_u32
-                if (OP == 3) a[j] = __umulhi(a[j], b[j]) + 1u;        // v_mul_hi_u32 (+add)
-                if (OP == 4) c[j] = (u64)(u32)c[j] * (u64)b[j] + c[j];// v_mad_u64_u32
-                if (OP == 5) a[j] = __builtin_amdgcn_alignbit(a[j], a[j], 7) ^ b[j];
-                if (OP == 6) a[j] = a[j] + b[j] + (u32)j;             // v_add3_u32
-                if (OP == 7) a[j] = __builtin_amdgcn_alignbit(a[j], b[j], 13);
-                if (OP == 8) a[j] = (a[j] & 0xffffffu) * (b[j] & 0xffffffu) + a[j]; // v_mad_u32_u24 class
-                if (OP == 9) d[j] = __builtin_fma(d[j], 1.0000001, 1e-12);   // v_fma_f64
-                if (OP == 10) c[j] = c[j] + (((u64)b[j] << 32) | a[j]);      // 64-bit add = add_co + addc
+                if (OP == ADD) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == XOR) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == MULLO) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == MULHI) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == MAD64) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c[j]) : "v"(a[j]), "v"(b[j]) : "vcc");
+                if (OP == ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == ADD3) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == BFI) asm volatile("v_bfi_b32 %0, %0, %1, %1" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == MAD24) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == MULHI24) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == FMA64) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d[j]) : "v"(d[(j + 1) % CHAINS]));
+                if (OP == ADDC) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[j]) : "v"(b[j]) : "vcc");
+                if (OP == LSHLADD) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == XAD) asm volatile("v_xad_u32 %0, %0, %1, %1" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[j]) : "v"(b[j]) : "vcc");
+                if (OP == PERM) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(a[j]) : "v"(b[j]));
             }
         }
     }
+    u64 c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     u32 r = 0;
 #pragma unroll
     for (int j = 0; j < CHAINS; j++) r ^= a[j] ^ (u32)c[j] ^ (u32)(c[j] >> 32) ^ (u32)d[j];
-    out[t] = r;
+    if (r == 0x12345678u) out[3] = r; // keep everything live
+    if (t == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
 }
 
 template <int OP>
-static void run(const char *name, int blocks_per_cu, int cus, u32 *out)
+static void run(int waves_per_simd, int cus, u64 *out)
 {
-    const int iters = 2000;
-    dim3 grid(cus * blocks_per_cu), block(256);
+    const int iters = 4000;
+    // waves_per_simd waves on each SIMD: blocks of 256 threads = 4 waves = 1 per SIMD
+    dim3 grid(cus * waves_per_simd), block(256);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -64,13 +83,21 @@ static void run(const char *name, int blocks_per_cu, int cus, u32 *out)
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    double ops = (double)grid.x * 256 * iters * 4.0 * CHAINS;
-    double gops = ops / (ms * 1e-3) / 1e9;
-    // cycles per wave-instruction per SIMD at 2.4 GHz nominal
-    double wave_instr = ops / 64.0;
-    double simds = cus * 4.0;
-    double cyc = (ms * 1e-3) * 2.4e9 / (wave_instr / simds);
-    printf("%-28s waves/SIMD=%d  %9.1f Glane-ops/s   %.2f cyc/wave-instr/SIMD @2.4GHz  (%.3f ms)\n", name, blocks_per_cu, gops, cyc, ms);
+    u64 h[2];
+    hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
+    double ghz = (double)h[0] / ((double)h[1] / 100e6) / 1e9; // s_memrealtime ticks at 100 MHz
+    double wave_instr_per_wave = (double)iters * UNROLL * CHAINS;
+    double cyc_per_instr_per_simd = (double)h[0] / (wave_instr_per_wave * waves_per_simd);
+    double lane_ops = (double)grid.x * 256 * wave_instr_per_wave;
+    printf("%-18s waves/SIMD=%d  %6.2f cyc/wave-instr/SIMD   %8.1f Tlane-ops/s   clk %.2f GHz  (%.2f ms)\n", NAMES[OP], waves_per_simd,
+           cyc_per_instr_per_simd, lane_ops / (ms * 1e-3) / 1e12, ghz, ms);
+}
+
+template <int OP>
+static void sweep_occ(int cus, u64 *out)
+{
+    for (int w : {1, 2, 4, 8}) run<OP>(w, cus, out);
+    printf("\n");
 }
 
 int main()
@@ -78,22 +105,24 @@ int main()
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     int cus = p.multiProcessorCount;
-    printf("device %s  CUs %d  clock %d kHz\n", p.gcnArchName, cus, p.clockRate);
-    u32 *out;
-    hipMalloc(&out, (size_t)cus * 8 * 256 * 4);
-    for (int occ : {1, 2, 4, 8}) {
-        run<0>("v_add_u32", occ, cus, out);
-        run<1>("and+xor (2 ops)", occ, cus, out);
-        run<2>("v_mul_lo_u32", occ, cus, out);
-        run<3>("v_mul_hi_u32 + add (2 ops)", occ, cus, out);
-        run<4>("v_mad_u64_u32", occ, cus, out);
-        run<5>("alignbit + xor (2 ops)", occ, cus, out);
-        run<6>("v_add3_u32", occ, cus, out);
-        run<7>("v_alignbit_b32", occ, cus, out);
-        run<8>("mad_u32_u24 class (3 ops)", occ, cus, out);
-        run<9>("v_fma_f64", occ, cus, out);
-        run<10>("64-bit add (2 ops)", occ, cus, out);
-        printf("\n");
-    }
+    printf("device %s  CUs %d  nominal clock %d kHz\n", p.gcnArchName, cus, p.clockRate);
+    u64 *out;
+    hipMalloc(&out, 64);
+    sweep_occ<ADD>(cus, out);
+    sweep_occ<XOR>(cus, out);
+    sweep_occ<ADD3>(cus, out);
+    sweep_occ<BFI>(cus, out);
+    sweep_occ<ALIGNBIT>(cus, out);
+    sweep_occ<ADDC>(cus, out);
+    sweep_occ<CNDMASK>(cus, out);
+    sweep_occ<LSHLADD>(cus, out);
+    sweep_occ<XAD>(cus, out);
+    sweep_occ<PERM>(cus, out);
+    sweep_occ<MULLO>(cus, out);
+    sweep_occ<MULHI>(cus, out);
+    sweep_occ<MAD64>(cus, out);
+    sweep_occ<MAD24>(cus, out);
+    sweep_occ<MULHI24>(cus, out);
+    sweep_occ<FMA64>(cus, out);
     return 0;
 }
