@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate vuke_amd/csrc/vk_field_gen.cuh: the v_mad_u64_u32 column kernels of the 256x256-bit
+multiply / square for gfx950, as inline-asm statements.
+
+Scheme (see vk_field.cuh): product scanning; column k = i + j accumulates into the register pair
+(limb k, limb k+1); the multiplier's carry-out is counted into cy[k] = limb k+2, which is where
+the next column of the same parity starts.  Each asm statement handles one even column and the
+following odd column, interleaved, so dependent multiplies are always 3 issue slots apart; the
+even column carries through vcc, the odd one through a scratch SGPR pair.
+"""
+import os
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vuke_amd", "csrc", "vk_field_gen.cuh")
+
+
+def col_products_mul(k):
+    return [(i, k - i) for i in range(max(0, k - 7), min(k, 7) + 1)]
+
+
+def col_products_sqr(k):
+    return [(i, k - i) for i in range(max(0, k - 7), min(k, 7) + 1) if i < k - i]
+
+
+def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same):
+    """one asm statement: even column ke and odd column ke+1."""
+    ko = ke + 1
+    # operand table
+    ops_out = []   # (constraint, expr)
+    ops_in = []
+    idx = {}
+
+    def out(c, e):
+        idx[e] = len(ops_out)
+        ops_out.append((c, e))
+
+    have_e, have_o = bool(prods_e), bool(prods_o)
+    if have_e:
+        out("+v", f"acc[{ke}]")
+        if len(prods_e) > 1:
+            out("+v", f"cy[{ke}]")
+    if have_o:
+        out("+v", f"acc[{ko}]")
+        if len(prods_o) > 1:
+            out("+v", f"cy[{ko}]")
+            out("=&s", "sc")
+    used = []
+    for (i, j) in prods_e + prods_o:
+        for nm in ((a_name, i), (a_name if same else b_name, j)):
+            if nm not in used:
+                used.append(nm)
+    base = len(ops_out)
+    for n, nm in enumerate(used):
+        idx[nm] = base + n
+        ops_in.append(("v", f"{nm[0]}.v[{nm[1]}]"))
+
+    def r(e):
+        return f"%{idx[e]}"
+
+    body = []
+    ne, no = len(prods_e), len(prods_o)
+    for step in range(max(ne, no)):
+        if step < ne:
+            i, j = prods_e[step]
+            body.append(f"v_mad_u64_u32 {r(f'acc[{ke}]')}, vcc, {r((a_name, i))}, {r((a_name if same else b_name, j))}, {r(f'acc[{ke}]')}")
+        if step < no:
+            i, j = prods_o[step]
+            sd = r("sc") if no > 1 else "vcc"
+            if no > 1 or step >= ne or True:
+                pass
+            body.append(f"v_mad_u64_u32 {r(f'acc[{ko}]')}, {sd}, {r((a_name, i))}, {r((a_name if same else b_name, j))}, {r(f'acc[{ko}]')}")
+        if step < ne and step > 0:
+            body.append(f"v_addc_co_u32 {r(f'cy[{ke}]')}, vcc, 0, {r(f'cy[{ke}]')}, vcc")
+        if step < no and step > 0:
+            body.append(f"v_addc_co_u32 {r(f'cy[{ko}]')}, {r('sc')}, 0, {r(f'cy[{ko}]')}, {r('sc')}")
+    # vcc hazard: if the odd column has a single product it would write vcc between the even
+    # column's multiply and its carry add -> route it through a dead SGPR pair instead
+    if no == 1 and ne > 1:
+        body = [b.replace(f"{r(f'acc[{ko}]')}, vcc,", f"{r(f'acc[{ko}]')}, s[100:101],") if b.startswith(f"v_mad_u64_u32 {r(f'acc[{ko}]')}") else b for b in body]
+        clob = '"vcc", "s100", "s101"'
+    else:
+        clob = '"vcc"'
+    s = '    asm("' + '\\n\\t"\n        "'.join(body) + '"\n'
+    s += "        : " + ", ".join(f'"{c}"({e})' for c, e in ops_out) + "\n"
+    s += "        : " + ", ".join(f'"{c}"({e})' for c, e in ops_in) + "\n"
+    s += f"        : {clob});\n"
+    lines.append(s)
+
+
+def gen_cols(name, prods_fn, same):
+    L = []
+    sig = "const fe &a" if same else "const fe &a, const fe &b"
+    L.append(f"// acc[k] = pair (limb k, limb k+1) of column k; returns limb 15 of the odd number\n")
+    L.append(f"VK_DEV u32 {name}(u64 acc[15], {sig})\n{{\n")
+    L.append("    u32 cy[15];\n    vk_carry sc;\n    (void)sc;\n")
+    L.append("#pragma unroll\n    for (int k = 0; k < 15; k++) cy[k] = 0;\n")
+    for ke in range(0, 15, 2):
+        pe, po = prods_fn(ke), (prods_fn(ke + 1) if ke + 1 < 15 else [])
+        for k in (ke, ke + 1):
+            if k < 15:
+                L.append(f"    acc[{k}] = {'(u64)cy[%d]' % (k - 2) if k >= 2 else '0ull'};\n")
+        if pe or po:
+            emit_pair(L, ke, pe, po, "a", "b", same)
+    L.append("    return cy[13];\n}\n\n")
+    return "".join(L)
+
+
+def gen_merge():
+    L = []
+    L.append("// t[0..15] = E + O: column k's pair acc[k] = (limb k, limb k+1); top = limb 15 of O\n")
+    L.append("VK_DEV void merge_eo(u32 t[16], const u64 acc[15], u32 top)\n{\n")
+    L.append("    u32 e[16], o[16];\n#pragma unroll\n    for (int m = 0; m < 8; m++) {\n        e[2 * m] = (u32)acc[2 * m];\n        e[2 * m + 1] = (u32)(acc[2 * m] >> 32);\n    }\n")
+    L.append("#pragma unroll\n    for (int m = 0; m < 7; m++) {\n        o[2 * m + 1] = (u32)acc[2 * m + 1];\n        o[2 * m + 2] = (u32)(acc[2 * m + 1] >> 32);\n    }\n    o[15] = top;\n    t[0] = e[0];\n    vk_carry c;\n")
+    # first half: t1..t7
+    body = ["v_add_co_u32 %0, vcc, %8, %15"]
+    for j in range(2, 8):
+        last = j == 7
+        body.append(f"v_addc_co_u32 %{j - 1}, {'%7' if last else 'vcc'}, %{7 + j}, %{14 + j}, vcc")
+    s = '    asm("' + '\\n\\t"\n        "'.join(body) + '"\n'
+    s += "        : " + ", ".join(f'"=&v"(t[{j}])' for j in range(1, 8)) + ', "=&s"(c)\n'
+    s += "        : " + ", ".join(f'"v"(e[{j}])' for j in range(1, 8)) + ", " + ", ".join(f'"v"(o[{j}])' for j in range(1, 8)) + "\n"
+    s += '        : "vcc");\n'
+    L.append(s)
+    # second half: t8..t15, carry in %24
+    body = []
+    for j in range(8, 16):
+        first = j == 8
+        body.append(f"v_addc_co_u32 %{j - 8}, vcc, %{j}, %{j + 8}, {'%24' if first else 'vcc'}")
+    s = '    asm("' + '\\n\\t"\n        "'.join(body) + '"\n'
+    s += "        : " + ", ".join(f'"=&v"(t[{j}])' for j in range(8, 16)) + "\n"
+    s += "        : " + ", ".join(f'"v"(e[{j}])' for j in range(8, 16)) + ", " + ", ".join(f'"v"(o[{j}])' for j in range(8, 16)) + ', "s"(c)\n'
+    s += '        : "vcc");\n}\n\n'
+    L.append(s)
+    return "".join(L)
+
+
+class Asm:
+    """Build one inline-asm statement from symbolic operands."""
+
+    def __init__(self):
+        self.outs, self.ins, self.body, self.clob = [], [], [], ["vcc"]
+        self.map = {}
+
+    def out(self, cons, expr):
+        if expr not in self.map:
+            self.map[expr] = ("o", len(self.outs))
+            self.outs.append((cons, expr))
+        return expr
+
+    def inp(self, cons, expr):
+        if expr not in self.map:
+            self.map[expr] = ("i", len(self.ins))
+            self.ins.append((cons, expr))
+        return expr
+
+    def ins_(self, text, *ops):
+        self.body.append((text, ops))
+
+    def render(self, indent="    "):
+        def num(e):
+            kind, n = self.map[e]
+            return n if kind == "o" else len(self.outs) + n
+        lines = []
+        for text, ops in self.body:
+            lines.append(text.format(*[f"%{num(o)}" if o in self.map else o for o in ops]))
+        assert len(self.outs) + len(self.ins) <= 30, (len(self.outs), len(self.ins))
+        s = indent + 'asm("' + ('\\n\\t"\n' + indent + '    "').join(lines) + '"\n'
+        s += indent + "    : " + ", ".join(f'"{c}"({e})' for c, e in self.outs) + "\n"
+        s += indent + "    : " + ", ".join(f'"{c}"({e})' for c, e in self.ins) + "\n"
+        s += indent + "    : " + ", ".join(f'"{c}"' for c in self.clob) + ");\n"
+        return s
+
+
+def chain(dst, xs, ys, first_carry_in=None, carry_out=None, sub=False):
+    """dst[i] = xs[i] +/- ys[i] with a vcc carry chain.  ys[i] may be the literal '0'."""
+    a = Asm()
+    n = len(dst)
+    for d in dst:
+        a.out("=&v", d)
+    if carry_out:
+        a.out("=&s", carry_out)
+    for x in xs:
+        if x != "0":
+            a.inp("v", x)
+    for y in ys:
+        if y != "0":
+            a.inp("v", y)
+    if first_carry_in:
+        a.inp("s", first_carry_in)
+    op0, opc = ("v_sub_co_u32", "v_subb_co_u32") if sub else ("v_add_co_u32", "v_addc_co_u32")
+    for i in range(n):
+        sd = carry_out if (carry_out and i == n - 1) else "vcc"
+        if i == 0 and not first_carry_in:
+            a.ins_(op0 + " {}, {}, {}, {}", dst[i], sd, xs[i], ys[i])
+        else:
+            ci = first_carry_in if i == 0 else "vcc"
+            a.ins_(opc + " {}, {}, {}, {}, {}", dst[i], sd, xs[i], ys[i], ci)
+    return a.render()
+
+
+def gen_reduce():
+    L = []
+    L.append("// r = t_lo + t_hi * (2^32 + 977) folded to 8 limbs, weakly reduced (see vk_field.cuh)\n")
+    L.append("VK_DEV void fe_reduce16(fe &r, const u32 t[16])\n{\n")
+    L.append("    u32 ql[8], qh[8];\n#pragma unroll\n    for (int i = 0; i < 8; i++) {\n        u64 q = mul_wide_s(t[8 + i], VK_PC0);\n        ql[i] = (u32)q;\n        qh[i] = (u32)(q >> 32);\n    }\n")
+    L.append("    u32 a[9], b[9], s[9];\n    vk_carry c1, c3;\n")
+    # chain 1: a_j = t_j + ql_j, a_8 = carry
+    a = Asm()
+    for j in range(9):
+        a.out("=&v", f"a[{j}]")
+    for j in range(8):
+        a.inp("v", f"t[{j}]")
+    for j in range(8):
+        a.inp("v", f"ql[{j}]")
+    a.ins_("v_add_co_u32 {}, vcc, {}, {}", "a[0]", "t[0]", "ql[0]")
+    for j in range(1, 8):
+        a.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", f"a[{j}]", f"t[{j}]", f"ql[{j}]")
+    a.ins_("v_addc_co_u32 {}, vcc, 0, 0, vcc", "a[8]")
+    L.append(a.render())
+    # chain 2: b_j = a_j + qh_{j-1}, j = 1..8 (no carry out of limb 8)
+    L.append(chain([f"b[{j}]" for j in range(1, 9)], [f"a[{j}]" for j in range(1, 9)], [f"qh[{j - 1}]" for j in range(1, 9)]))
+    # chain 3: s_j = b_j + t[8+j-1], j = 1..8, carry out c3 = bit 32 of limb 8
+    L.append(chain([f"s[{j}]" for j in range(1, 9)], [f"b[{j}]" for j in range(1, 9)], [f"t[{7 + j}]" for j in range(1, 9)], carry_out="c3"))
+    L.append("    s[0] = a[0];\n")
+    # stage 3: fold o = s[8] + 2^32*c3:  o*C = s8*977 + (s8 << 32) + c3*(977 << 32) + c3 << 64
+    L.append("    u64 m = mul_wide_s(s[8], VK_PC0);\n    u32 ml = (u32)m, mh = (u32)(m >> 32);\n")
+    L.append("    u32 w1, w2;\n    vk_carry c4;\n")
+    a = Asm()
+    for e in ("w1", "w2"):
+        a.out("=&v", e)
+    for j in range(8):
+        a.out("=&v", f"r.v[{j}]")
+    a.out("=&s", "c4")
+    for e in ("mh", "ml") + tuple(f"s[{j}]" for j in range(9)):
+        a.inp("v", e)
+    a.inp("s", "c3")
+    a.inp("v", "VK_PC0")
+    a.ins_("v_cndmask_b32 {}, 0, {}, {}", "w1", "VK_PC0", "c3")       # 977 * c3
+    a.ins_("v_add_u32 {}, {}, {}", "w1", "w1", "mh")                    # <= 1953
+    a.ins_("v_add_co_u32 {}, vcc, {}, {}", "w1", "w1", "s[8]")          # + s8, carry k in vcc
+    a.ins_("v_cndmask_b32 {}, 0, 1, {}", "w2", "c3")
+    a.ins_("v_addc_co_u32 {}, vcc, 0, {}, vcc", "w2", "w2")             # c3 + k  (limb 2 addend)
+    a.ins_("v_add_co_u32 {}, vcc, {}, {}", "r.v[0]", "s[0]", "ml")
+    a.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", "r.v[1]", "s[1]", "w1")
+    a.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", "r.v[2]", "s[2]", "w2")
+    for j in range(3, 7):
+        a.ins_("v_addc_co_u32 {}, vcc, 0, {}, vcc", f"r.v[{j}]", f"s[{j}]")
+    a.ins_("v_addc_co_u32 {}, {}, 0, {}, vcc", "r.v[7]", "c4", "s[7]")
+    L.append(a.render())
+    L.append("    if (__builtin_expect(c4 != 0, 0)) fe_wrap_add(r, c4); // value was 2^256 + small: add C (cannot carry again)\n}\n\n")
+    return "".join(L)
+
+
+def gen_addsub():
+    L = []
+    for name, sub in (("fe_add", False), ("fe_sub", True)):
+        L.append(f"// r = a {'-' if sub else '+'} b (mod p), weakly reduced; operands may alias\n")
+        L.append(f"VK_DEV void {name}(fe &r, const fe &a, const fe &b)\n{{\n    u32 d[8];\n    vk_carry c1;\n")
+        L.append(chain([f"d[{j}]" for j in range(8)], [f"a.v[{j}]" for j in range(8)], [f"b.v[{j}]" for j in range(8)], carry_out="c1", sub=sub))
+        # fix-up: +/- C under mask c1
+        L.append("    u32 k0, k1;\n    vk_carry c2;\n")
+        a = Asm()
+        for e in ("k0", "k1"):
+            a.out("=&v", e)
+        for j in range(8):
+            a.out("=&v", f"r.v[{j}]")
+        a.out("=&s", "c2")
+        for j in range(8):
+            a.inp("v", f"d[{j}]")
+        a.inp("s", "c1")
+        a.inp("v", "VK_PC0")
+        a.ins_("v_cndmask_b32 {}, 0, {}, {}", "k0", "VK_PC0", "c1")
+        a.ins_("v_cndmask_b32 {}, 0, 1, {}", "k1", "c1")
+        o0, oc = ("v_sub_co_u32", "v_subb_co_u32") if sub else ("v_add_co_u32", "v_addc_co_u32")
+        a.ins_(o0 + " {}, vcc, {}, {}", "r.v[0]", "d[0]", "k0")
+        a.ins_(oc + " {}, vcc, {}, {}, vcc", "r.v[1]", "d[1]", "k1")
+        for j in range(2, 7):
+            a.ins_(oc + " {}, vcc, {}, 0, vcc", f"r.v[{j}]", f"d[{j}]")
+        a.ins_(oc + " {}, {}, {}, 0, vcc", "r.v[7]", "c2", "d[7]")
+        L.append(a.render())
+        fn = "fe_wrap_sub" if sub else "fe_wrap_add"
+        L.append(f"    if (__builtin_expect(c2 != 0, 0)) {fn}(r, c2); // second wrap: only for operands in the 2^32-wide sliver next to 2^256\n}}\n\n")
+    return "".join(L)
+
+
+def main():
+    hdr = "// GENERATED by tools/gen_field.py -- do not edit.  Column kernels of the 256-bit multiply / square\n"
+    hdr += "// on v_mad_u64_u32 (see the scheme in vk_field.cuh).\n#pragma once\n\n"
+    txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_addsub() + gen_reduce()
+    open(OUT, "w").write(txt)
+    print("wrote", OUT, len(txt.splitlines()), "lines")
+
+
+if __name__ == "__main__":
+    main()

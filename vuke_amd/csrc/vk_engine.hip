@@ -126,7 +126,7 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     }
     e->cu_count = prop.multiProcessorCount;
     if (opts && opts->window_bits) {
-        if (opts->window_bits < 4 || opts->window_bits > 22) return fail(e, VK_E_INVALID_ARG, "window_bits must be in 4..22");
+        if (opts->window_bits < 4 || opts->window_bits > 26) return fail(e, VK_E_INVALID_ARG, "window_bits must be in 4..26");
         e->W = opts->window_bits;
     }
     e->nwin = (256 + e->W - 1) / e->W;
