@@ -157,7 +157,10 @@ def main():
                 "workload": "Milksad (MT19937) seed sweep, P2PKH compressed, 1024 planted targets; "
                             f"step = one 2^{BLOCK_LOG2}-seed block per GPU (16 blocks = full 2^32 sweep)",
                 "seeds_per_step_per_gpu": BLOCK,
-                "window_bits": args.window_bits or 16,
+                "window_bits": eng.info()["window_bits"],
+                "table_gb": eng.info()["table_bytes"] / 1e9,
+                "table_build_seconds": eng.info()["table_build_seconds"],
+                "batch": eng.info()["batch"],
                 "parallelism": f"range-partition x{n_gpus}",
             },
             "sweep_2p32_seconds_at_this_rate": (1 << 32) / value,

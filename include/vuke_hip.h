@@ -102,18 +102,30 @@ typedef struct vk_sweep_stats {
 typedef struct vk_engine vk_engine;
 
 typedef struct vk_engine_opts {
-    uint32_t window_bits;  /* fixed-base window width of the k*G table: 8..20 (0 = default 16) */
+    uint32_t window_bits;  /* fixed-base window width of the k*G table: 4..26 (0 = default 24: 11.8 GB) */
     uint32_t batch;        /* keys per lane sharing one field inversion (0 = default) */
     uint32_t blocks_per_cu;/* resident 256-thread workgroups per CU to launch (0 = default) */
     uint32_t _reserved;
     void *stream;          /* hipStream_t to run on (NULL = engine creates its own) */
 } vk_engine_opts;
 
+typedef struct vk_engine_info_t {
+    int32_t device;
+    uint32_t cu_count;
+    uint32_t window_bits;   /* W */
+    uint32_t windows;       /* ceil(256 / W) table lookups + (windows - 1) point additions per key */
+    uint32_t batch;         /* keys per lane per field inversion */
+    uint32_t blocks_per_cu;
+    uint64_t table_bytes;   /* windows * 2^W * 64 */
+    double table_build_seconds;
+} vk_engine_info_t;
+
 int vk_abi_version(void);
 int vk_device_count(void);
 int vk_engine_create(int device, vk_engine **out);
 int vk_engine_create_ex(int device, const vk_engine_opts *opts, vk_engine **out);
 void vk_engine_destroy(vk_engine *e);
+int vk_engine_info(const vk_engine *e, vk_engine_info_t *out);
 /* Message for the last failing call on this engine (valid until the next call); e may be NULL
  * to read the message of a failed vk_engine_create. */
 const char *vk_last_error(const vk_engine *e);

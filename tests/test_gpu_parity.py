@@ -52,17 +52,34 @@ def test_field_ops(eng):
         assert int.from_bytes(g, "big") == pow(x, -1, P)
 
 
-def test_table_entries(eng, vko):
-    # entry (w, d) = (d << 16w) * G for the default 16-bit windows
-    rnd = random.Random(12)
-    picks = [(0, 1), (0, 2), (0, 65535), (1, 1), (15, 1), (15, 65535), (7, 0x8000)]
-    picks += [(rnd.randrange(16), rnd.randrange(1, 65536)) for _ in range(40)]
+def _check_table(e, vko, rnd, n_random):
+    info = e.info()
+    W, nwin = info["window_bits"], info["windows"]
+    h = max(W // 2, 3)
+    top_bits = 256 - W * (nwin - 1)
+    picks = [(0, 1), (0, 2), (0, (1 << W) - 1), (1, 1), (nwin - 1, 1), (nwin - 1, (1 << min(W, top_bits)) - 1)]
+    # seeded low / high multiples and combined entries around the seams of the two-phase builder
+    picks += [(2, 1 << h), (2, (1 << h) + 1), (2, (1 << h) - 1), (3, (5 << h) | 7), (nwin - 2, ((1 << (W - h)) - 1) << h),
+              (nwin - 2, (((1 << (W - h)) - 1) << h) | ((1 << h) - 1)), (1, (3 << h) | 8), (1, (3 << h) | 15), (1, (3 << h) | 16)]
+    picks += [(rnd.randrange(nwin), rnd.randrange(1, 1 << W)) for _ in range(n_random)]
     for w, d in picks:
-        k = d << (16 * w)
+        k = d << (W * w)
+        x, y = e.table_entry(w, d)
+        if k >> 256 or d == 0:
+            assert (x, y) == (bytes(32), bytes(32)), (W, w, d)
+            continue
         _, p65 = vko.pubkey(be(k))
-        x, y = eng.table_entry(w, d)
-        assert x + y == p65[1:], (w, d)
-    assert eng.table_entry(3, 0) == (bytes(32), bytes(32))
+        assert x + y == p65[1:], (W, w, d)
+    assert e.table_entry(nwin // 2, 0) == (bytes(32), bytes(32))
+    if top_bits < W:  # digits of the top window that cannot occur in a 256-bit scalar stay zero
+        assert e.table_entry(nwin - 1, 1 << top_bits) == (bytes(32), bytes(32))
+        assert e.table_entry(nwin - 1, (1 << W) - 1) == (bytes(32), bytes(32))
+
+
+def test_table_entries(eng, vko):
+    # entry (w, d) = (d << W*w) * G; default engine = 24-bit windows
+    assert eng.info()["window_bits"] == 24 and eng.info()["windows"] == 11
+    _check_table(eng, vko, random.Random(12), 60)
 
 
 def test_derive_batch_edges_and_random(eng, vko):
@@ -231,8 +248,10 @@ def test_invalid_arguments(eng):
 def test_other_window_widths(vko):
     import vuke_amd
     from vuke_amd import _ffi as ffi
-    for W, batch in ((8, 4), (12, 16), (13, 1), (20, 64)):
+    for W, batch in ((6, 4), (12, 16), (13, 1), (16, 32), (21, 64)):
         e = vuke_amd.Engine(0, window_bits=W, batch=batch)
+        assert e.info()["window_bits"] == W and e.info()["batch"] == batch
+        _check_table(e, vko, random.Random(W), 12)
         st, _ = e.sweep(ffi.spec(ffi.T_MILKSAD), 1000, 1999, flags=3)
         ost, _ = vko.sweep(vko.spec(vko.T_MILKSAD), 1000, 1999, flags=3, nthreads=8)
         assert st["digest"] == ost["digest"] and st["keys"] == 1000, W

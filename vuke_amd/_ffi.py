@@ -37,8 +37,14 @@ class EngineOpts(C.Structure):
                 ("_reserved", C.c_uint32), ("stream", C.c_void_p)]
 
 
+class EngineInfo(C.Structure):
+    _fields_ = [("device", C.c_int32), ("cu_count", C.c_uint32), ("window_bits", C.c_uint32), ("windows", C.c_uint32),
+                ("batch", C.c_uint32), ("blocks_per_cu", C.c_uint32), ("table_bytes", C.c_uint64),
+                ("table_build_seconds", C.c_double)]
+
+
 EXPORTS = [
-    "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy",
+    "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
     "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_transform_batch",
     "vk_slots_per_input", "vk_debug_table_entry", "vk_debug_field",
 ]
@@ -61,6 +67,7 @@ def load():
     L.vk_engine_create_ex.argtypes = [C.c_int, C.POINTER(EngineOpts), C.POINTER(vp)]
     L.vk_engine_destroy.argtypes = [vp]
     L.vk_engine_destroy.restype = None
+    L.vk_engine_info.argtypes = [vp, C.POINTER(EngineInfo)]
     L.vk_last_error.argtypes = [vp]
     L.vk_last_error.restype = cp
     L.vk_targets_set.argtypes = [vp, cp, cp, sz]
@@ -104,6 +111,11 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def info(self):
+        i = EngineInfo()
+        self._chk(self._L.vk_engine_info(self._e, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in EngineInfo._fields_}
 
     def _chk(self, rc):
         if rc != VK_OK:

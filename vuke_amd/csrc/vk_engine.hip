@@ -23,7 +23,8 @@ struct vk_engine {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int cu_count = 0;
-    u32 W = 16, nwin = 16;
+    u32 W = 24, nwin = 11; // default: 11 windows x 2^24 entries x 64 B = 11.8 GB of the 288 GB HBM
+    double table_build_seconds = 0.0;
     u32 batch = 32;
     u32 blocks_per_cu = 0;
     uint4 *table = nullptr;
@@ -152,13 +153,27 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
         HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vk_sweep_kernel<VK_T_MILKSAD>, VK_BLOCK, 0));
         e->blocks_per_cu = (u32)std::max(1, std::min(occ, 4));
     }
-    // the k*G table: nwin x 2^W affine points, built on the device
+    // the k*G table: nwin x 2^W affine points (64 B each), built on the device in two phases
     const size_t entries = (size_t)e->nwin << e->W;
     HIPCHK(e, hipMalloc(&e->table, entries * 64));
-    const u32 blocks = (u32)((entries + VK_BLOCK - 1) / VK_BLOCK);
-    hipLaunchKernelGGL(vk_table_kernel, dim3(blocks), dim3(VK_BLOCK), 0, e->stream, e->table, e->W, e->nwin);
-    HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    {
+        u32 h = e->W / 2;
+        if (h < 3) h = 3; // the combine kernel walks VK_TBL_K = 8 low digits per lane
+        const u64 seeds = (u64)e->nwin * ((1ull << h) + (1ull << (e->W - h)));
+        const u64 runs = (u64)e->nwin * (1ull << (e->W - h)) * ((1ull << h) / VK_TBL_K);
+        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+        hipLaunchKernelGGL(vk_table_seed_kernel, dim3((u32)((seeds + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, e->table,
+                           e->W, e->nwin, h);
+        HIPCHK(e, hipGetLastError());
+        hipLaunchKernelGGL(vk_table_combine_kernel, dim3((u32)((runs + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, e->table,
+                           e->W, e->nwin, h);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->table_build_seconds = (double)ms * 1e-3;
+    }
     return VK_OK;
 }
 
@@ -179,6 +194,21 @@ extern "C" int vk_engine_create_ex(int device, const vk_engine_opts *opts, vk_en
 }
 
 extern "C" int vk_engine_create(int device, vk_engine **out) { return vk_engine_create_ex(device, nullptr, out); }
+
+extern "C" int vk_engine_info(const vk_engine *e, vk_engine_info_t *out)
+{
+    if (!e || !out) return VK_E_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    out->device = e->device;
+    out->cu_count = (uint32_t)e->cu_count;
+    out->window_bits = e->W;
+    out->windows = e->nwin;
+    out->batch = e->batch;
+    out->blocks_per_cu = e->blocks_per_cu;
+    out->table_bytes = ((uint64_t)e->nwin << e->W) * 64;
+    out->table_build_seconds = e->table_build_seconds;
+    return VK_OK;
+}
 
 // ------------------------------------------------------------------------- targets
 extern "C" int vk_targets_set(vk_engine *e, const uint8_t *h160, const uint8_t *kind, size_t n)

@@ -24,6 +24,9 @@
 #define VK_F_EMIT 0x10000u /* internal: generate-mode records */
 
 #define VK_BLOCK 256
+#ifndef VK_SWEEP_WAVES
+#define VK_SWEEP_WAVES 2 /* minimum waves per SIMD the sweep kernel is register-budgeted for */
+#endif
 
 struct vk_hit_dev { // must match vk_hit in include/vuke_hip.h (72 bytes)
     u64 seed;
@@ -121,7 +124,7 @@ VK_DEV bool item_key(u32 kw[8], const vk_sweep_params &p, u64 off, u32 sub)
 }
 
 template <u32 KIND>
-__global__ void __launch_bounds__(VK_BLOCK) vk_sweep_kernel(const vk_sweep_params p)
+__global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(const vk_sweep_params p)
 {
     const u32 tid = threadIdx.x;
     const u64 gtid = (u64)blockIdx.x * VK_BLOCK + tid;
@@ -278,20 +281,16 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_sweep_kernel(const vk_sweep_param
 
 // ---------------------------------------------------------------- table builder
 // entry (w, d) = (d << (W*w)) * G, affine canonical; d = 0 and unrepresentable entries = 0.
-__global__ void __launch_bounds__(VK_BLOCK) vk_table_kernel(uint4 *table, u32 W, u32 nwin)
+//
+// Two phases so that even a 2^26-entry-per-window table (43 GB) builds in a fraction of a second:
+//   seed     the 2^h "low" multiples d = j and the 2^(W-h) "high" multiples d = i << h of every
+//            window, each by a generic double-and-add (a few 10^4 scalar multiplications);
+//   combine  every other entry is T[i << h] + T[j]: one affine + affine addition, eight of them
+//            per lane sharing one field inversion (Montgomery's trick).
+VK_DEV bool table_scalar(u32 s[8], u32 d, u32 shift)
 {
-    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
-    const u64 total = (u64)nwin << W;
-    if (idx >= total) return;
-    const u32 d = (u32)(idx & ((1u << W) - 1u)), w = (u32)(idx >> W);
-    uint4 *dst = table + idx * 4;
-    const u32 shift = W * w;
     const u32 dbits = 32 - __builtin_clz(d | 1u);
-    if (d == 0 || shift + dbits > 256) {
-        dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(0, 0, 0, 0);
-        return;
-    }
-    u32 s[8];
+    if (d == 0 || shift + dbits > 256) return false;
     const u32 limb = shift >> 5, sh = shift & 31;
     const u64 wide = (u64)d << sh;
 #pragma unroll
@@ -301,15 +300,106 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_table_kernel(uint4 *table, u32 W,
         v = (limb + 1 == (u32)i) ? (u32)(wide >> 32) : v;
         s[i] = v;
     }
+    return true;
+}
+
+VK_DEV void table_store(uint4 *dst, const fe &x, const fe &y)
+{
+    dst[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    dst[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    dst[2] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+    dst[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+}
+
+// seed phase: idx enumerates, per window, the 2^h low digits then the 2^(W-h) high digits
+__global__ void __launch_bounds__(VK_BLOCK) vk_table_seed_kernel(uint4 *table, u32 W, u32 nwin, u32 h)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    const u32 nlo = 1u << h, nhi = 1u << (W - h), per = nlo + nhi;
+    if (idx >= (u64)nwin * per) return;
+    const u32 w = (u32)(idx / per), r = (u32)(idx % per);
+    if (r == nlo) return; // high digit 0 is entry 0 again
+    const u32 d = r < nlo ? r : (r - nlo) << h;
+    uint4 *dst = table + (((u64)w << W) + d) * 4;
+    u32 s[8];
+    if (!table_scalar(s, d, W * w)) {
+        dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(0, 0, 0, 0);
+        return;
+    }
     jac P;
     ecmult_generic(P, s);
     fe zi, x, y;
     fe_inv(zi, P.z);
     jac_to_affine(x, y, P, zi);
-    dst[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    dst[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
-    dst[2] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
-    dst[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+    table_store(dst, x, y);
+}
+
+#define VK_TBL_K 8
+// combine phase: one lane = one (window, high digit i >= 1) and VK_TBL_K consecutive low digits
+__global__ void __launch_bounds__(VK_BLOCK) vk_table_combine_kernel(uint4 *table, u32 W, u32 nwin, u32 h)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    const u32 nlo = 1u << h, nhi = 1u << (W - h), runs = nlo / VK_TBL_K;
+    if (idx >= (u64)nwin * nhi * runs) return;
+    const u32 run = (u32)(idx % runs);
+    const u32 i = (u32)((idx / runs) % nhi), w = (u32)(idx / ((u64)runs * nhi));
+    if (i == 0) return; // those are the seeded low multiples themselves
+    uint4 *win = table + ((u64)w << W) * 4;
+    const u32 shift = W * w;
+    const u32 hi_d = i << h;
+    // digits whose scalar does not fit 256 bits are never looked up: leave them zero
+    u32 tmp[8];
+    const bool hi_ok = table_scalar(tmp, hi_d, shift);
+    fe xi, yi;
+    table_load(xi, yi, win + (u64)hi_d * 4);
+    fe c[VK_TBL_K]; // running products of the x differences
+    fe one;
+    fe_set_one(one);
+#pragma unroll
+    for (int k = 0; k < VK_TBL_K; k++) {
+        const u32 j = run * VK_TBL_K + k;
+        fe xj, yj, dx;
+        table_load(xj, yj, win + (u64)j * 4);
+        fe_sub(dx, xj, xi);
+        if (j == 0 || !hi_ok) dx = one;
+        if (k == 0) c[0] = dx;
+        else fe_mul(c[k], c[k - 1], dx);
+    }
+    fe inv;
+    fe_inv(inv, c[VK_TBL_K - 1]);
+#pragma unroll
+    for (int k = VK_TBL_K - 1; k >= 0; k--) {
+        const u32 j = run * VK_TBL_K + k;
+        fe xj, yj, dx, dinv;
+        table_load(xj, yj, win + (u64)j * 4);
+        fe_sub(dx, xj, xi);
+        if (j == 0 || !hi_ok) dx = one;
+        if (k > 0) {
+            fe_mul(dinv, inv, c[k - 1]);
+            fe_mul(inv, inv, dx);
+        } else {
+            dinv = inv;
+        }
+        uint4 *dst = win + ((u64)hi_d + j) * 4;
+        if (j == 0) continue; // the seeded high multiple itself
+        if (!hi_ok) {
+            dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(0, 0, 0, 0);
+            continue;
+        }
+        // (xi, yi) + (xj, yj), distinct x guaranteed (distinct scalars below n, never negatives of each other)
+        fe lam, x3, y3, t;
+        fe_sub(t, yj, yi);
+        fe_mul(lam, t, dinv);
+        fe_sqr(x3, lam);
+        fe_sub(x3, x3, xi);
+        fe_sub(x3, x3, xj);
+        fe_sub(t, xi, x3);
+        fe_mul(y3, lam, t);
+        fe_sub(y3, y3, yi);
+        fe_canon(x3);
+        fe_canon(y3);
+        table_store(dst, x3, y3);
+    }
 }
 
 // ---------------------------------------------------------------- Transform::apply_batch
