@@ -34,6 +34,25 @@ PEAK_INT32_SURVEY = 256 * 64 * 2.4e9
 N_PLANTED = 1024
 
 
+def block_of(rank, step, steps, block_log2=BLOCK_LOG2):
+    """Seed block (inclusive) that `rank` sweeps at `step`: rank-major contiguous blocks, wrapping
+    inside the 2^32 Milksad seed space."""
+    nblocks = 1 << (32 - block_log2)
+    b = (rank * steps + step) % nblocks
+    return b << block_log2, ((b + 1) << block_log2) - 1
+
+
+def reduce_counters(dist, dev, counters, elapsed):
+    """Sum the integer counters and take the max elapsed time over ranks (one tiny collective each)."""
+    import torch
+    tot = torch.tensor(list(counters), dtype=torch.int64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return [int(x) for x in tot.tolist()], float(tmax.item())
+
+
 def planted_seeds():
     return [(0x9E3779B1 * j + 12345) & 0xFFFFFFFF for j in range(N_PLANTED)]
 
@@ -79,9 +98,8 @@ def main():
     _, h160c, _ = eng.derive_batch(keys)
     eng.targets_set(h160c, [ffi.TARGET_P2PKH] * len(h160c))
 
-    def block_of(step):
-        b = (rank * args.steps + step) % NBLOCKS
-        return b * BLOCK, b * BLOCK + BLOCK - 1
+    def my_block(step):
+        return block_of(rank, step, args.steps)
 
     def sync():
         torch.cuda.synchronize()
@@ -90,7 +108,7 @@ def main():
         torch.cuda.synchronize()
 
     for w in range(args.warmup):
-        lo, hi = block_of(w)
+        lo, hi = my_block(w)
         eng.sweep(spec, lo, lo + (BLOCK >> 4) - 1, flags=ffi.F_COMPRESSED, hit_cap=N_PLANTED)
 
     keys_done = matches = expected = 0
@@ -100,7 +118,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        lo, hi = block_of(s)
+        lo, hi = my_block(s)
         st, hits = eng.sweep(spec, lo, hi, flags=ffi.F_COMPRESSED, hit_cap=N_PLANTED)
         keys_done += st["keys"]
         matches += st["matches"]
@@ -114,13 +132,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # counters: one tiny all-reduce over RCCL (the only collective on this path)
-    tot = torch.tensor([keys_done, matches, expected], dtype=torch.int64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_keys, total_matches, total_expected = (int(x) for x in tot.tolist())
-    t = float(tmax.item())
+    (total_keys, total_matches, total_expected), t = reduce_counters(dist, dev, [keys_done, matches, expected], elapsed)
     if total_matches != total_expected:
         print(f"bench.py: PARITY FAILURE: {total_matches} matches, {total_expected} planted seeds in range", file=sys.stderr)
         sys.exit(3)

@@ -1,0 +1,169 @@
+"""CPU tests of the C++ host layer (vuke_amd/host): transform grammar, labels, text codecs, record
+assembly, output formats, Matcher -- checked against the oracle and the reference's own tests."""
+import ctypes as C
+import os
+import random
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host():
+    import __graft_entry__ as ge
+    ge.build()
+    L = C.CDLL(os.path.join(ROOT, "vuke_amd", "lib", "libvuke_host.so"))
+    L.vkh_matcher_load.restype = C.c_long
+    return L
+
+
+class Spec(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("variant", C.c_uint32), ("endian", C.c_uint32), ("chain_depth", C.c_uint32)]
+
+
+ALL = 0xFFFFFFFF
+
+
+def parse(host, s):
+    sp, name, err = Spec(), C.create_string_buffer(64), C.create_string_buffer(512)
+    rc = host.vkh_parse_transform(s.encode(), C.byref(sp), name, 64, err, 512)
+    if rc != 0:
+        return None, err.value.decode()
+    return (sp.kind, sp.variant, sp.endian, sp.chain_depth), name.value.decode()
+
+
+def test_transform_grammar_reference_cases(host):
+    # src/lcg.rs parse_tests, src/xorshift.rs:334-357, src/sha256_chain.rs:187-217, src/transform/mod.rs:170-215
+    assert parse(host, "sha256") == ((0, ALL, 0, 10), "sha256")
+    assert parse(host, "SHA256") == ((0, ALL, 0, 10), "sha256")
+    assert parse(host, "milksad") == ((1, ALL, 0, 10), "milksad")
+    assert parse(host, "mt64") == ((2, ALL, 0, 10), "mt64")
+    assert parse(host, "lcg") == ((3, ALL, 0, 10), "lcg")
+    assert parse(host, "lcg:le") == ((3, ALL, 1, 10), "lcg")
+    assert parse(host, "lcg:glibc") == ((3, 0, 0, 10), "lcg")
+    assert parse(host, "lcg:GLIBC:LE") == ((3, 0, 1, 10), "lcg")
+    assert parse(host, "lcg:borland:be") == ((3, 3, 0, 10), "lcg")
+    assert parse(host, "lcg:") == ((3, ALL, 0, 10), "lcg")          # trailing ':' trimmed
+    assert parse(host, "lcg:big") == ((3, ALL, 0, 10), "lcg")
+    assert parse(host, "xorshift") == ((4, ALL, 0, 10), "xorshift")
+    for alias, v in (("64", 0), ("xorshift64", 0), ("128", 1), ("128plus", 2), ("128+", 2), ("plus", 2), ("xoroshiro", 3),
+                     ("starstar", 3), ("xoroshiro128**", 3), ("xoroshiro128starstar", 3)):
+        assert parse(host, "xorshift:" + alias) == ((4, v, 0, 10), "xorshift")
+    assert parse(host, "sha256_chain") == ((5, ALL, 0, 10), "sha256_chain")
+    assert parse(host, "sha256_chain:iterated") == ((5, 0, 0, 10), "sha256_chain:iterated")
+    assert parse(host, "sha256_chain:indexed") == ((5, 1, 0, 10), "sha256_chain:indexed:be")
+    assert parse(host, "sha256_chain:indexed:be") == ((5, 1, 0, 10), "sha256_chain:indexed:be")
+    assert parse(host, "sha256_chain:indexed:le") == ((5, 2, 0, 10), "sha256_chain:indexed:le")
+    assert parse(host, "sha256_chain:counter") == ((5, 3, 0, 10), "sha256_chain:counter")
+    # errors carry the reference's wording
+    assert parse(host, "lcg:nope") == (None, "Invalid LCG variant or endian: 'nope'. Valid variants: glibc, minstd, msvc, borland. Valid endian: be, le")
+    assert parse(host, "lcg:glibc:xx") == (None, "Invalid endian: 'xx'. Valid: be, le")
+    assert parse(host, "lcg:a:b:c")[1].startswith("Invalid LCG format")
+    assert parse(host, "xorshift:7")[1].startswith("Invalid xorshift variant: '7'")
+    assert parse(host, "sha256_chain:foo")[1].startswith("Invalid SHA256 chain variant: 'foo'")
+    assert parse(host, "sha256_chain:iterated:le")[1].startswith("Invalid SHA256 chain format")
+    assert parse(host, "nothing")[1].startswith("Unknown transform: nothing. Valid: direct, sha256,")
+    assert parse(host, "md5")[0] is None and "outside the device hot path" in parse(host, "md5")[1]
+
+
+def test_labels_match_oracle(host, vko):
+    seeds = [0, 5, 2**31 - 1, 2**32, 2**64 - 1]
+    for kind, var, en, depth in [(0, ALL, 0, 10), (1, ALL, 0, 10), (2, ALL, 0, 10), (3, ALL, 0, 10), (3, ALL, 1, 10), (3, 2, 1, 10),
+                                 (4, ALL, 0, 10), (4, 3, 0, 10), (5, ALL, 0, 10), (5, ALL, 0, 3), (5, 2, 0, 10)]:
+        sp, osp = Spec(kind, var, en, depth), vko.spec(kind, var, en, depth)
+        for s in seeds:
+            for sub in range(vko.slots_per_input(osp)):
+                out = C.create_string_buffer(128)
+                host.vkh_label(C.byref(sp), C.c_uint64(s), sub, out, 128)
+                assert out.value.decode() == vko.transform_label(osp, s, sub), (kind, var, en, depth, s, sub)
+
+
+def test_codecs_match_oracle(host, vko):
+    rnd = random.Random(21)
+    for _ in range(300):
+        n = rnd.choice([1, 21, 33, 34, 21, 21])
+        p = bytes([rnd.choice([0, 0, rnd.getrandbits(8)])]) + bytes(rnd.getrandbits(8) for _ in range(n - 1))
+        out = C.create_string_buffer(128)
+        host.vkh_base58check_encode(p, len(p), out, 128)
+        assert out.value.decode() == vko.base58check_encode(p)
+        dec = C.create_string_buffer(64)
+        m = host.vkh_base58check_decode(out.value, dec, 64)
+        assert dec.raw[:m] == p
+        h = bytes(rnd.getrandbits(8) for _ in range(20))
+        host.vkh_segwit_encode(b"bc", 0, h, 20, out, 128)
+        assert out.value.decode() == vko.segwit_encode("bc", 0, h)
+        ver = C.c_int()
+        m = host.vkh_segwit_decode(b"bc", out.value, C.byref(ver), dec, 64)
+        assert (ver.value, dec.raw[:m]) == (0, h)
+        msg = bytes(rnd.getrandbits(8) for _ in range(rnd.randrange(0, 150)))
+        d = C.create_string_buffer(32)
+        host.vkh_sha256(msg, len(msg), d)
+        assert d.raw == vko.sha256(msg)
+    dec = C.create_string_buffer(64)
+    assert host.vkh_base58check_decode(b"1NonExistentAddress", dec, 64) == -1
+    assert host.vkh_base58check_decode(b"1JwSSubhmg6iPtRjtyqhUYYH7bZg3Lfy1U", dec, 64) == -1
+    ver = C.c_int()
+    assert host.vkh_segwit_decode(b"bc", b"bc1qw508d6qejxtdg4y5r3zarvary0c5xw7kv8f3t5", C.byref(ver), dec, 64) == -1
+
+
+def _render(host, tmp_path, d, mode, kind=0, source="src", transform="tf"):
+    path = str(tmp_path / f"o{mode}{kind}.txt")
+    assert host.vkh_render(bytes(d.raw), bytes(d.h160_c), bytes(d.h160_u), mode, kind, source.encode(), transform.encode(), path.encode()) == 0
+    return open(path).read()
+
+
+def test_record_and_console_formats(host, vko, tmp_path):
+    rnd = random.Random(22)
+    keys = [bytes(32), b"\xff" * 32, bytes.fromhex("c4bbcb1fbec99d65bf59d85c8cb62ee2db963f0fe106f483d9afa73bd4e39a8a")]
+    keys += [rnd.getrandbits(rnd.choice([256, 200, 9])).to_bytes(32, "big") for _ in range(12)]
+    for k in keys:
+        d = vko.derive(k)
+        s = lambda b: b.decode()
+        rec = _render(host, tmp_path, d, 3).split("|")
+        assert rec == [s(d.private_key_decimal), s(d.private_key_binary), str(d.bit_length), str(d.hamming_weight), str(d.leading_zeros),
+                       s(d.wif_compressed), s(d.wif_uncompressed), s(d.p2pkh_compressed), s(d.p2pkh_uncompressed), s(d.p2wpkh)]
+        # src/output/console.rs:77-81
+        assert _render(host, tmp_path, d, 0, source="12345", transform="sha256") == \
+            f"12345,sha256,{s(d.private_key_hex)},{s(d.p2pkh_compressed)}\n"
+        # src/output/console.rs:66-74
+        assert _render(host, tmp_path, d, 1) == (
+            f"---\nsource: src\ntransform: tf\nprivate_key: {s(d.private_key_hex)}\nwif_compressed: {s(d.wif_compressed)}\n"
+            f"wif_uncompressed: {s(d.wif_uncompressed)}\np2pkh_compressed: {s(d.p2pkh_compressed)}\n"
+            f"p2pkh_uncompressed: {s(d.p2pkh_uncompressed)}\np2wpkh: {s(d.p2wpkh)}\n")
+        # src/output/console.rs:96-113
+        for kind, (addr, nm) in enumerate([(d.p2pkh_compressed, "p2pkh_compressed"), (d.p2pkh_uncompressed, "p2pkh_uncompressed"),
+                                           (d.p2wpkh, "p2wpkh")]):
+            assert _render(host, tmp_path, d, 2, kind) == (
+                f"\n========== HIT ==========\nSource: src\nTransform: tf\nMatched: {s(addr)} ({nm})\n---\n"
+                f"Private Key: {s(d.private_key_hex)}\nWIF (compressed): {s(d.wif_compressed)}\nWIF (uncompressed): {s(d.wif_uncompressed)}\n"
+                f"---\nP2PKH (compressed): {s(d.p2pkh_compressed)}\nP2PKH (uncompressed): {s(d.p2pkh_uncompressed)}\nP2WPKH: {s(d.p2wpkh)}\n"
+                f"=========================\n")
+    # reference KAT through the C++ record builder (src/derive.rs:190-197)
+    d = vko.derive(keys[2])
+    assert "5KJvsngHeMpm884wtkJNzQGaCErckhHJBGFsvd3VyK5qMZXj3hS" in _render(host, tmp_path, d, 3)
+    assert "1JwSSubhmg6iPtRjtyqhUYYH7bZg3Lfy1T" in _render(host, tmp_path, d, 3)
+
+
+def test_matcher_load_check_and_device_form(host, vko, tmp_path):
+    d = vko.derive(bytes.fromhex("c4bbcb1fbec99d65bf59d85c8cb62ee2db963f0fe106f483d9afa73bd4e39a8a"))
+    c, u, w = d.p2pkh_compressed.decode(), d.p2pkh_uncompressed.decode(), d.p2wpkh.decode()
+    f = tmp_path / "t.txt"
+
+    def check(lines):
+        f.write_text("\n".join(lines) + "\n")
+        return host.vkh_matcher_check(str(f).encode(), bytes(d.raw), bytes(d.h160_c), bytes(d.h160_u))
+
+    assert check([u]) == 1                      # src/matcher.rs:117-138
+    assert check(["1NonExistentAddress"]) == -1  # src/matcher.rs:141-149
+    assert check([w, u, c]) == 0 and check([w, u]) == 1 and check([w]) == 2 and check([w.upper()]) == -1
+    lines = ["  " + c + " \r", "", "   ", "# " + u, c, "junk line", w, w.upper(), "3J98t1WpEZ73CNmQviecrnyiWrnqRhWNLy"]
+    f.write_text("\n".join(lines) + "\n")
+    h160 = C.create_string_buffer(20 * 16)
+    kind = C.create_string_buffer(16)
+    n = C.c_size_t()
+    cnt = host.vkh_matcher_load(str(f).encode(), h160, kind, 16, C.byref(n))
+    assert cnt == 5                              # unique trimmed non-comment lines (count() counts them all)
+    got = sorted((kind.raw[i], h160.raw[20 * i:20 * i + 20]) for i in range(n.value))
+    assert got == sorted([(0, bytes(d.h160_c)), (1, bytes(d.h160_c))])  # junk, upper-case bech32 and P2SH never match
+    assert host.vkh_matcher_load(b"/nonexistent/file", h160, kind, 16, C.byref(n)) == -1

@@ -1,0 +1,110 @@
+// capi.cpp -- small extern "C" test hooks over the host layer so pytest can drive the C++ code on a
+// machine without a GPU (parsers, labels, text codecs, record assembly, output formats, matcher).
+#include "vuke_host.hpp"
+
+#include <cstring>
+#include <stdexcept>
+
+using namespace vuke;
+
+static int put(const std::string &s, char *out, size_t cap)
+{
+    if (s.size() + 1 > cap) return -1;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+extern "C" {
+
+// parse a --transform value; on failure returns -1 and the reference-style message in err
+int vkh_parse_transform(const char *s, vk_transform_spec *spec, char *name, size_t name_cap, char *err, size_t err_cap)
+{
+    try {
+        Transform t = TransformType::from_str(s);
+        *spec = t.spec();
+        put(t.name(), name, name_cap);
+        return 0;
+    } catch (const std::exception &e) {
+        put(e.what(), err, err_cap);
+        return -1;
+    }
+}
+
+int vkh_label(const vk_transform_spec *spec, uint64_t seed, uint32_t sub, char *out, size_t cap) { return put(Transform(*spec).label(seed, sub), out, cap); }
+
+int vkh_base58check_encode(const uint8_t *p, size_t n, char *out, size_t cap) { return put(base58check_encode(p, n), out, cap); }
+int vkh_base58check_decode(const char *s, uint8_t *out, size_t cap)
+{
+    std::vector<uint8_t> v;
+    if (!base58check_decode(s, v) || v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size());
+    return (int)v.size();
+}
+int vkh_segwit_encode(const char *hrp, int ver, const uint8_t *p, size_t n, char *out, size_t cap) { return put(segwit_encode(hrp, ver, p, n), out, cap); }
+int vkh_segwit_decode(const char *hrp, const char *addr, int *ver, uint8_t *out, size_t cap)
+{
+    std::vector<uint8_t> v;
+    if (!segwit_decode(hrp, addr, *ver, v) || v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size());
+    return (int)v.size();
+}
+void vkh_sha256(const uint8_t *p, size_t n, uint8_t out[32]) { sha256(p, n, out); }
+
+// Assemble a DerivedKey from device outputs and render it: mode 0 compact line, 1 verbose block,
+// 2 HIT block (kind = address type), 3 "decimal|binary|bit_length|hamming|leading_zeros|wif_c|wif_u|c|u|w"
+int vkh_render(const uint8_t key[32], const uint8_t hc[20], const uint8_t hu[20], int mode, int kind, const char *source,
+               const char *transform, const char *path)
+{
+    try {
+        DerivedKey d = KeyDeriver::from_device(key, hc, hu);
+        auto out = ConsoleOutput::to_file(path, mode == 1);
+        if (mode == 0 || mode == 1) out->key(source, transform, d);
+        else if (mode == 2) {
+            MatchInfo mi{(AddressType)kind, *d.addresses()[kind]};
+            out->hit(source, transform, d, mi);
+        } else {
+            FILE *fp = fopen(path, "w");
+            if (!fp) return -1;
+            fprintf(fp, "%s|%s|%u|%u|%u|%s|%s|%s|%s|%s", d.private_key_decimal.c_str(), d.private_key_binary.c_str(), d.bit_length,
+                    d.hamming_weight, d.leading_zeros, d.wif_compressed.c_str(), d.wif_uncompressed.c_str(), d.p2pkh_compressed.c_str(),
+                    d.p2pkh_uncompressed.c_str(), d.p2wpkh.c_str());
+            fclose(fp);
+            return 0;
+        }
+        out->flush();
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+
+// Matcher::load on a file: returns count(), and writes the device form (n x 20 bytes, n kinds)
+long vkh_matcher_load(const char *path, uint8_t *h160, uint8_t *kind, size_t cap, size_t *n_device)
+{
+    try {
+        Matcher m = Matcher::load(path);
+        std::vector<uint8_t> h, k;
+        m.device_targets(h, k);
+        *n_device = k.size();
+        if (k.size() <= cap) {
+            memcpy(h160, h.data(), h.size());
+            memcpy(kind, k.data(), k.size());
+        }
+        return (long)m.count();
+    } catch (...) {
+        return -1;
+    }
+}
+
+// Matcher::check on a record assembled from (key, hc, hu): -1 none, else AddressType
+int vkh_matcher_check(const char *path, const uint8_t key[32], const uint8_t hc[20], const uint8_t hu[20])
+{
+    try {
+        Matcher m = Matcher::load(path);
+        auto r = m.check(KeyDeriver::from_device(key, hc, hu));
+        return r ? (int)r->address_type : -1;
+    } catch (...) {
+        return -2;
+    }
+}
+}

@@ -1,0 +1,130 @@
+// derive.cpp -- DerivedKey assembly (src/derive.rs:94-165) from what the device produced, and
+// Matcher (src/matcher.rs:45-108).
+#include "vuke_host.hpp"
+
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+
+namespace vuke {
+
+DerivedKey KeyDeriver::from_device(const uint8_t k[32], const uint8_t hc[20], const uint8_t hu[20])
+{
+    DerivedKey d;
+    memcpy(d.raw.data(), k, 32);
+    memcpy(d.h160_c, hc, 20);
+    memcpy(d.h160_u, hu, 20);
+    d.private_key_hex = hex_encode(k, 32);                   // :147
+    d.private_key_decimal = decimal_of_be(k);                // :121
+    d.private_key_binary.resize(256);                        // :124-131
+    int lz = -1, hw = 0;
+    for (int i = 0; i < 256; i++) {
+        int bit = (k[i / 8] >> (7 - i % 8)) & 1;
+        d.private_key_binary[i] = bit ? '1' : '0';
+        hw += bit;
+        if (bit && lz < 0) lz = i;
+    }
+    d.bit_length = (uint16_t)(256 - (lz < 0 ? 256 : lz));    // :134-141
+    d.hamming_weight = (uint16_t)hw;                         // :144
+    size_t l0 = 0;                                           // :148
+    while (l0 < 64 && d.private_key_hex[l0] == '0') l0++;
+    d.leading_zeros = (uint8_t)l0;
+    uint8_t buf[40];
+    buf[0] = 0x80;                                           // :102-105,159-160 (mainnet WIF)
+    memcpy(buf + 1, k, 32);
+    buf[33] = 0x01;
+    d.wif_compressed = base58check_encode(buf, 34);
+    d.wif_uncompressed = base58check_encode(buf, 33);
+    buf[0] = 0x00;                                           // :112-113 (mainnet P2PKH)
+    memcpy(buf + 1, hc, 20);
+    d.p2pkh_compressed = base58check_encode(buf, 21);
+    memcpy(buf + 1, hu, 20);
+    d.p2pkh_uncompressed = base58check_encode(buf, 21);
+    d.p2wpkh = segwit_encode("bc", 0, hc, 20);               // :116-118
+    return d;
+}
+
+std::vector<DerivedKey> KeyDeriver::derive(const std::vector<Key> &keys) const
+{
+    std::vector<DerivedKey> out;
+    if (keys.empty()) return out;
+    const size_t n = keys.size();
+    std::vector<uint8_t> in(n * 32), norm(n * 32), hc(n * 20), hu(n * 20);
+    for (size_t i = 0; i < n; i++) memcpy(&in[32 * i], keys[i].data(), 32);
+    check_rc(engine_, vk_derive_batch(engine_, in.data(), n, norm.data(), hc.data(), hu.data()));
+    out.reserve(n);
+    for (size_t i = 0; i < n; i++) out.push_back(from_device(&norm[32 * i], &hc[20 * i], &hu[20 * i]));
+    return out;
+}
+
+const char *address_type_str(AddressType t)
+{
+    switch (t) {
+    case AddressType::P2pkhCompressed: return "p2pkh_compressed";
+    case AddressType::P2pkhUncompressed: return "p2pkh_uncompressed";
+    default: return "p2wpkh";
+    }
+}
+
+static std::string trim(const std::string &s)
+{ // str::trim(): ASCII + the whitespace that can occur in address files
+    size_t a = 0, b = s.size();
+    auto ws = [](unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; };
+    while (a < b && ws((unsigned char)s[a])) a++;
+    while (b > a && ws((unsigned char)s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+
+Matcher Matcher::load(const std::string &path)
+{
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("cannot open targets file: " + path);
+    Matcher m;
+    std::string line;
+    while (std::getline(f, line)) {
+        std::string s = trim(line);
+        if (!s.empty() && s[0] != '#') m.targets_.insert(s);
+    }
+    return m;
+}
+
+Matcher Matcher::from_addresses(const std::vector<std::string> &a)
+{
+    Matcher m;
+    for (auto &s : a) m.targets_.insert(s);
+    return m;
+}
+
+std::optional<MatchInfo> Matcher::check(const DerivedKey &d) const
+{
+    if (targets_.count(d.p2pkh_compressed)) return MatchInfo{AddressType::P2pkhCompressed, d.p2pkh_compressed};
+    if (targets_.count(d.p2pkh_uncompressed)) return MatchInfo{AddressType::P2pkhUncompressed, d.p2pkh_uncompressed};
+    if (targets_.count(d.p2wpkh)) return MatchInfo{AddressType::P2wpkh, d.p2wpkh};
+    return std::nullopt;
+}
+
+void Matcher::device_targets(std::vector<uint8_t> &h160, std::vector<uint8_t> &kind) const
+{
+    h160.clear();
+    kind.clear();
+    for (const std::string &s : targets_) {
+        std::vector<uint8_t> raw;
+        // the reference compares strings: only the canonical spelling of an address can match, so
+        // re-encode and require identity (drops e.g. upper-case bech32, which never equals a derived one)
+        if (base58check_decode(s, raw) && raw.size() == 21 && raw[0] == 0x00) {
+            if (base58check_encode(raw.data(), raw.size()) != s) continue;
+            h160.insert(h160.end(), raw.begin() + 1, raw.end());
+            kind.push_back(VK_TARGET_P2PKH);
+            continue;
+        }
+        int ver = -1;
+        std::vector<uint8_t> prog;
+        if (segwit_decode("bc", s, ver, prog) && ver == 0 && prog.size() == 20) {
+            if (segwit_encode("bc", 0, prog.data(), 20) != s) continue;
+            h160.insert(h160.end(), prog.begin(), prog.end());
+            kind.push_back(VK_TARGET_P2WPKH);
+        }
+    }
+}
+
+} // namespace vuke

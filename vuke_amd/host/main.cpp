@@ -1,0 +1,141 @@
+// main.cpp -- `vuke-hip`: the generate / scan subcommands of the reference CLI (src/main.rs:85-434,
+// run_generate :602-768, run_scan :770-952) driving the GPU engine.  Same argument spelling for the
+// options on the hot path, same stderr status lines, same stdout formats.
+//
+//   vuke-hip generate [--transform T ...] [-v] [-o FILE] range --start A --end B
+//   vuke-hip scan --transform T ... --targets FILE [-o FILE] range --start A --end B
+//   vuke-hip single --transform T VALUE            (numeric VALUE; src/main.rs:954-992 format)
+// Extras: --device N, --window-bits W.
+#include "vuke_host.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+
+using namespace vuke;
+
+static int usage(const char *msg)
+{
+    if (msg) fprintf(stderr, "error: %s\n\n", msg);
+    fprintf(stderr, "Usage: vuke-hip <generate|scan|single> [OPTIONS] range --start <START> --end <END>\n"
+                    "  --transform <T>...   sha256 | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] | sha256_chain[:variant]\n"
+                    "  --targets <FILE>     (scan) one address per line\n"
+                    "  -v, --verbose        (generate) all key formats\n"
+                    "  -o, --output <FILE>  write to FILE instead of stdout\n"
+                    "  --network <N>        accepted and ignored, like the reference (src/main.rs:464,499)\n"
+                    "  --device <N>         GPU index (default 0)\n"
+                    "  --window-bits <W>    k*G table window width (default 24)\n");
+    return 2;
+}
+
+static uint64_t parse_u64(const char *s)
+{
+    char *end = nullptr;
+    errno = 0;
+    unsigned long long v = strtoull(s, &end, 10);
+    if (errno || !end || *end || s[0] == '-' || !s[0]) throw std::invalid_argument(std::string("invalid value '") + s + "' for a u64 argument");
+    return v;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return usage(nullptr);
+    const std::string cmd = argv[1];
+    if (cmd != "generate" && cmd != "scan" && cmd != "single") return usage("unknown subcommand");
+    std::vector<std::string> tnames;
+    std::string targets, outpath, single_value;
+    bool verbose = false, have_range = false, have_start = false, have_end = false;
+    uint64_t start = 0, end = 0;
+    int device = 0;
+    unsigned window_bits = 0;
+    try {
+        for (int i = 2; i < argc; i++) {
+            std::string a = argv[i];
+            auto need = [&](const char *opt) -> const char * {
+                if (i + 1 >= argc) throw std::invalid_argument(std::string("a value is required for '") + opt + "'");
+                return argv[++i];
+            };
+            if (a == "--transform") {
+                tnames.push_back(need("--transform"));
+                while (i + 1 < argc && argv[i + 1][0] != '-' && strcmp(argv[i + 1], "range") != 0) tnames.push_back(argv[++i]); // num_args = 1..
+            } else if (a == "--targets") targets = need("--targets");
+            else if (a == "-o" || a == "--output") outpath = need("--output");
+            else if (a == "-v" || a == "--verbose") verbose = true;
+            else if (a == "--network") (void)need("--network");
+            else if (a == "--device") device = atoi(need("--device"));
+            else if (a == "--window-bits") window_bits = (unsigned)atoi(need("--window-bits"));
+            else if (a == "range") have_range = true;
+            else if (a == "--start") { start = parse_u64(need("--start")); have_start = true; }
+            else if (a == "--end") { end = parse_u64(need("--end")); have_end = true; }
+            else if (cmd == "single" && single_value.empty() && a[0] != '-') single_value = a;
+            else throw std::invalid_argument("unexpected argument '" + a + "'");
+        }
+        if (cmd == "generate" && tnames.empty()) tnames.push_back("sha256"); // default_value, src/main.rs:107
+        if (tnames.empty()) throw std::invalid_argument("the following required arguments were not provided: --transform <TRANSFORM>...");
+        std::vector<Transform> transforms;
+        for (auto &n : tnames) transforms.push_back(TransformType::from_str(n));
+        if (cmd == "scan" && targets.empty()) throw std::invalid_argument("the following required arguments were not provided: --targets <TARGETS>");
+        if (cmd != "single" && (!have_range || !have_start || !have_end)) throw std::invalid_argument("only the `range --start A --end B` source is on the device path");
+        if (cmd != "single" && end < start) throw std::invalid_argument("--end must be >= --start");
+
+        vk_engine *engine = nullptr;
+        vk_engine_opts opts{};
+        opts.window_bits = window_bits;
+        int rc = vk_engine_create_ex(device, &opts, &engine);
+        if (rc != VK_OK) {
+            fprintf(stderr, "GPU engine unavailable: %s\n", vk_last_error(nullptr));
+            return 1;
+        }
+        struct Guard { vk_engine *e; ~Guard() { vk_engine_destroy(e); } } guard{engine};
+
+        if (cmd == "single") {
+            if (single_value.empty()) throw std::invalid_argument("single needs a numeric VALUE");
+            const uint64_t v = parse_u64(single_value.c_str());
+            KeyDeriver deriver(engine);
+            for (const Transform &t : transforms) {
+                std::vector<std::pair<std::string, Key>> out;
+                t.apply_batch(engine, {v}, out);
+                for (auto &[label, key] : out) {
+                    DerivedKey d = deriver.derive(key);
+                    printf("Passphrase: \"%s\"\nTransform: %s\nSource: %s\n---\nPrivate Key (hex): %s\nPrivate Key (decimal): %s\n"
+                           "Bit Length: %u\nHamming Weight: %u\nWIF (compressed): %s\nWIF (uncompressed): %s\n---\n"
+                           "P2PKH (compressed): %s\nP2PKH (uncompressed): %s\nP2WPKH: %s\n\n",
+                           single_value.c_str(), t.name(), label.c_str(), d.private_key_hex.c_str(), d.private_key_decimal.c_str(),
+                           d.bit_length, d.hamming_weight, d.wif_compressed.c_str(), d.wif_uncompressed.c_str(),
+                           d.p2pkh_compressed.c_str(), d.p2pkh_uncompressed.c_str(), d.p2wpkh.c_str());
+                }
+            }
+            return 0;
+        }
+
+        std::unique_ptr<ConsoleOutput> out;
+        if (!outpath.empty()) out = ConsoleOutput::to_file(outpath, verbose);
+        else if (verbose) out = ConsoleOutput::verbose();
+        else out = std::make_unique<ConsoleOutput>();
+        HipRangeSource source(engine, start, end);
+        ProcessStats stats;
+        if (cmd == "scan") {
+            fprintf(stderr, "Loading targets from \"%s\"...\n", targets.c_str());
+            Matcher m = Matcher::load(targets);
+            fprintf(stderr, "Loaded %zu targets.\n", m.count());
+            fprintf(stderr, "Scanning...\n");
+            stats = source.process(transforms, &m, *out);
+        } else {
+            fprintf(stderr, "Generating keys...\n");
+            stats = source.process(transforms, nullptr, *out);
+        }
+        out->flush();
+        fprintf(stderr, "Done. Inputs: %llu, Keys: %llu, Matches: %llu\n", (unsigned long long)stats.inputs_processed,
+                (unsigned long long)stats.keys_generated, (unsigned long long)stats.matches_found);
+        return 0;
+    } catch (const EngineError &e) {
+        fprintf(stderr, "Error: GPU engine failure (%d): %s\n", e.code, e.what());
+        return 1;
+    } catch (const std::invalid_argument &e) {
+        return usage(e.what());
+    } catch (const std::exception &e) {
+        fprintf(stderr, "Error: %s\n", e.what());
+        return 1;
+    }
+}

@@ -1,0 +1,81 @@
+// source.cpp -- HipRangeSource::process: the GPU replacement for RangeSource::process
+// (src/source/range.rs:26-79).  Scan mode = vk_sweep (fused transform -> k*G -> hash160 -> probe)
+// with the rare hits replayed through KeyDeriver + Output::hit on the host; generate mode =
+// vk_generate with one Output::key per emitted key.  Counters follow the reference exactly:
+// inputs = end - start + 1, keys = keys the transforms emitted, matches = keys that matched.
+#include "vuke_host.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace vuke {
+
+ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output)
+{
+    ProcessStats st;
+    st.inputs_processed = end - start + 1; // src/source/range.rs:32
+    const uint32_t flags = VK_F_COMPRESSED | VK_F_UNCOMPRESSED;
+    if (matcher) {
+        std::vector<uint8_t> h160, kind;
+        matcher->device_targets(h160, kind);
+        check_rc(engine_, vk_targets_set(engine_, h160.data(), kind.data(), kind.size()));
+        // the reference walks the range chunk by chunk and, inside a chunk, transform by transform;
+        // hits are rare, so here each transform sweeps a large block of the range in one launch
+        const uint64_t block = 1ull << 30;
+        for (uint64_t lo = start;; lo += block) {
+            const uint64_t hi = (end - lo < block - 1) ? end : lo + block - 1;
+            for (const Transform &t : transforms) {
+                std::vector<vk_hit> hits(1 << 16);
+                vk_sweep_stats ss;
+                for (;;) {
+                    check_rc(engine_, vk_sweep(engine_, &t.spec(), lo, hi, flags, hits.data(), hits.size(), &ss));
+                    if (!ss.hits_dropped) break;
+                    hits.resize(hits.size() + (size_t)ss.hits_dropped + 1024); // rerun with room for every hit
+                }
+                st.keys_generated += ss.keys;
+                st.matches_found += ss.matches;
+                hits.resize((size_t)ss.matches);
+                std::sort(hits.begin(), hits.end(), [](const vk_hit &a, const vk_hit &b) {
+                    return a.seed != b.seed ? a.seed < b.seed : a.sub_index < b.sub_index;
+                });
+                std::vector<Key> keys(hits.size());
+                for (size_t i = 0; i < hits.size(); i++) memcpy(keys[i].data(), hits[i].privkey, 32);
+                KeyDeriver deriver(engine_);
+                std::vector<DerivedKey> derived = deriver.derive(keys);
+                for (size_t i = 0; i < hits.size(); i++) {
+                    const DerivedKey &d = derived[i];
+                    MatchInfo mi;
+                    mi.address_type = hits[i].addr_kind == VK_ADDR_P2PKH_C   ? AddressType::P2pkhCompressed
+                                      : hits[i].addr_kind == VK_ADDR_P2PKH_U ? AddressType::P2pkhUncompressed
+                                                                             : AddressType::P2wpkh;
+                    mi.address = *d.addresses()[hits[i].addr_kind];
+                    output.hit(t.label(hits[i].seed, hits[i].sub_index), t.name(), d, mi);
+                }
+            }
+            if (hi == end) break;
+        }
+        check_rc(engine_, vk_targets_set(engine_, nullptr, nullptr, 0));
+    } else {
+        const uint64_t chunk = 1ull << 18; // inputs per vk_generate call (host buffers: 72 B per key)
+        for (uint64_t lo = start;; lo += chunk) {
+            const uint64_t hi = (end - lo < chunk - 1) ? end : lo + chunk - 1;
+            for (const Transform &t : transforms) {
+                const uint32_t k = t.slots();
+                const size_t n = (size_t)(hi - lo + 1) * k;
+                std::vector<uint8_t> priv(n * 32), hc(n * 20), hu(n * 20), valid(n);
+                vk_sweep_stats ss;
+                check_rc(engine_, vk_generate(engine_, &t.spec(), lo, hi, flags, priv.data(), hc.data(), hu.data(), valid.data(), &ss));
+                st.keys_generated += ss.keys;
+                for (size_t i = 0; i < n; i++) {
+                    if (!valid[i]) continue;
+                    DerivedKey d = KeyDeriver::from_device(&priv[32 * i], &hc[20 * i], &hu[20 * i]);
+                    output.key(t.label(lo + i / k, (uint32_t)(i % k)), t.name(), d);
+                }
+            }
+            if (hi == end) break;
+        }
+    }
+    return st;
+}
+
+} // namespace vuke

@@ -1,0 +1,191 @@
+// transform.cpp -- TransformType::from_str grammar, Transform::name(), labels and the device
+// apply_batch.  Mirrors src/transform/mod.rs:170-215, src/lcg.rs:247-277, src/xorshift.rs:334-357,
+// src/sha256_chain.rs:187-217 and the label formats of src/transform/{lcg,xorshift,sha256_chain}.rs.
+#include "vuke_host.hpp"
+
+#include <algorithm>
+#include <stdexcept>
+
+namespace vuke {
+
+static std::string lower(std::string s)
+{
+    std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+    return s;
+}
+static std::vector<std::string> split_colon(std::string s)
+{
+    while (!s.empty() && s.back() == ':') s.pop_back(); // trim_end_matches(':')
+    std::vector<std::string> parts;
+    size_t pos = 0;
+    for (;;) {
+        size_t q = s.find(':', pos);
+        parts.push_back(s.substr(pos, q == std::string::npos ? std::string::npos : q - pos));
+        if (q == std::string::npos) break;
+        pos = q + 1;
+    }
+    return parts;
+}
+
+static const char *LCG_NAMES[4] = {"glibc", "minstd", "msvc", "borland"};
+static const char *XS_NAMES[4] = {"xorshift64", "xorshift128", "xorshift128+", "xoroshiro128**"};
+static const char *CH_NAMES[4] = {"iterated", "indexed:be", "indexed:le", "counter"};
+
+static int lcg_variant(const std::string &v)
+{
+    for (int i = 0; i < 4; i++)
+        if (v == LCG_NAMES[i]) return i;
+    return -1;
+}
+static int lcg_endian(const std::string &v)
+{
+    if (v == "be" || v == "big") return 0;
+    if (v == "le" || v == "little") return 1;
+    return -1;
+}
+static int xs_variant(const std::string &v)
+{ // XorshiftVariant::from_str, src/xorshift.rs:46-56
+    if (v == "64" || v == "xorshift64") return 0;
+    if (v == "128" || v == "xorshift128") return 1;
+    if (v == "128plus" || v == "128+" || v == "plus" || v == "xorshift128+") return 2;
+    if (v == "xoroshiro" || v == "starstar" || v == "xoroshiro128**" || v == "xoroshiro128starstar") return 3;
+    return -1;
+}
+
+Transform TransformType::from_str(const std::string &raw)
+{
+    const std::string s = lower(raw);
+    vk_transform_spec sp{0, VK_VARIANT_ALL, 0, 10};
+    auto unsupported = [&](const char *name) -> Transform {
+        throw std::invalid_argument(std::string("transform '") + name + "' is outside the device hot path of this build (see DESIGN.md)");
+    };
+    if (s == "sha256") { sp.kind = VK_T_SHA256; return Transform(sp); }
+    if (s == "milksad") { sp.kind = VK_T_MILKSAD; return Transform(sp); }
+    if (s == "mt64") { sp.kind = VK_T_MT64; return Transform(sp); }
+    for (const char *n : {"direct", "double_sha256", "md5", "armory", "multibit", "electrum", "electrum:change", "bitimage"})
+        if (s == n) return unsupported(n);
+    if (s == "lcg" || s.rfind("lcg:", 0) == 0) { // LcgConfig::parse
+        auto parts = split_colon(s);
+        sp.kind = VK_T_LCG;
+        if (parts.size() == 1 && parts[0] == "lcg") return Transform(sp);
+        if (parts.size() == 2 && parts[0] == "lcg") {
+            int e = lcg_endian(parts[1]), v = lcg_variant(parts[1]);
+            if (e >= 0) { sp.endian = (uint32_t)e; return Transform(sp); }
+            if (v >= 0) { sp.variant = (uint32_t)v; return Transform(sp); }
+            throw std::invalid_argument("Invalid LCG variant or endian: '" + parts[1] +
+                                        "'. Valid variants: glibc, minstd, msvc, borland. Valid endian: be, le");
+        }
+        if (parts.size() == 3 && parts[0] == "lcg") {
+            int v = lcg_variant(parts[1]);
+            if (v < 0) throw std::invalid_argument("Invalid LCG variant: '" + parts[1] + "'. Valid: glibc, minstd, msvc, borland");
+            int e = lcg_endian(parts[2]);
+            if (e < 0) throw std::invalid_argument("Invalid endian: '" + parts[2] + "'. Valid: be, le");
+            sp.variant = (uint32_t)v;
+            sp.endian = (uint32_t)e;
+            return Transform(sp);
+        }
+        throw std::invalid_argument("Invalid LCG format. Use: lcg, lcg:variant, lcg:endian, lcg:variant:endian");
+    }
+    if (s == "xorshift" || s.rfind("xorshift:", 0) == 0) { // XorshiftConfig::parse
+        auto parts = split_colon(s);
+        sp.kind = VK_T_XORSHIFT;
+        if (parts.size() == 1 && parts[0] == "xorshift") return Transform(sp);
+        if (parts.size() == 2 && parts[0] == "xorshift") {
+            int v = xs_variant(parts[1]);
+            if (v < 0) throw std::invalid_argument("Invalid xorshift variant: '" + parts[1] + "'. Valid: 64, 128, 128plus, xoroshiro");
+            sp.variant = (uint32_t)v;
+            return Transform(sp);
+        }
+        throw std::invalid_argument("Invalid xorshift format. Use: xorshift, xorshift:64, xorshift:128, xorshift:128plus, xorshift:xoroshiro");
+    }
+    if (s == "sha256_chain" || s.rfind("sha256_chain:", 0) == 0) { // Sha256ChainConfig::parse
+        std::string t = s;
+        while (!t.empty() && t.back() == ':') t.pop_back();
+        auto parts = split_colon(s);
+        sp.kind = VK_T_SHA256_CHAIN;
+        if (parts.size() == 1 && parts[0] == "sha256_chain") return Transform(sp);
+        if (parts.size() == 2 && parts[0] == "sha256_chain") {
+            // Sha256ChainVariant::from_str sees a single segment here: "indexed:be" cannot occur
+            const std::string &v = parts[1];
+            if (v == "iterated") sp.variant = 0;
+            else if (v == "indexed") sp.variant = 1;
+            else if (v == "counter") sp.variant = 3;
+            else throw std::invalid_argument("Invalid SHA256 chain variant: '" + v + "'. Valid: iterated, indexed, counter");
+            return Transform(sp);
+        }
+        if (parts.size() == 3 && parts[0] == "sha256_chain" && parts[1] == "indexed") {
+            int e = lcg_endian(parts[2]);
+            if (e < 0) throw std::invalid_argument("Invalid endian: '" + parts[2] + "'. Valid: be, le");
+            sp.variant = e == 0 ? 1u : 2u;
+            return Transform(sp);
+        }
+        throw std::invalid_argument("Invalid SHA256 chain format: '" + t +
+                                    "'. Valid: sha256_chain, sha256_chain:iterated, sha256_chain:indexed[:be|:le], sha256_chain:counter");
+    }
+    throw std::invalid_argument("Unknown transform: " + raw +
+                                ". Valid: direct, sha256, double_sha256, md5, milksad, mt64, armory, multibit, electrum[:change], "
+                                "lcg[:variant][:endian], xorshift[:variant], sha256_chain[:variant], bitimage");
+}
+
+const char *Transform::name() const
+{
+    switch (spec_.kind) {
+    case VK_T_SHA256: return "sha256";
+    case VK_T_MILKSAD: return "milksad";
+    case VK_T_MT64: return "mt64";
+    case VK_T_LCG: return "lcg";
+    case VK_T_XORSHIFT: return "xorshift";
+    case VK_T_SHA256_CHAIN: // src/transform/sha256_chain.rs:46-58
+        switch (spec_.variant) {
+        case 0: return "sha256_chain:iterated";
+        case 1: return "sha256_chain:indexed:be";
+        case 2: return "sha256_chain:indexed:le";
+        case 3: return "sha256_chain:counter";
+        default: return "sha256_chain";
+        }
+    default: return "?";
+    }
+}
+
+std::string Transform::label(uint64_t seed, uint32_t sub) const
+{
+    const std::string s = std::to_string(seed); // Input::from_u64 string_val
+    const bool all = spec_.variant == VK_VARIANT_ALL;
+    switch (spec_.kind) {
+    case VK_T_LCG: // src/transform/lcg.rs:54-66
+        if (!all) return s;
+        return spec_.endian ? s + ":" + LCG_NAMES[sub & 3] + ":le" : s + ":" + LCG_NAMES[sub & 3];
+    case VK_T_XORSHIFT: // src/transform/xorshift.rs:43-47
+        return all ? s + ":" + XS_NAMES[sub & 3] : s;
+    case VK_T_SHA256_CHAIN: { // src/transform/sha256_chain.rs:67,88
+        const uint32_t nv = all ? 4u : 1u, d = spec_.chain_depth;
+        const uint32_t r = sub % (nv * d);
+        const uint32_t v = all ? r / d : spec_.variant, idx = r % d;
+        return s + "[" + CH_NAMES[v & 3] + ":" + std::to_string(idx) + "]";
+    }
+    default: return s;
+    }
+}
+
+void Transform::apply_batch(vk_engine *e, const std::vector<uint64_t> &inputs, std::vector<std::pair<std::string, Key>> &output) const
+{
+    const uint32_t k = slots();
+    if (inputs.empty() || k == 0) return;
+    std::vector<uint8_t> keys(inputs.size() * k * 32), valid(inputs.size() * k);
+    check_rc(e, vk_transform_batch(e, &spec_, inputs.data(), inputs.size(), keys.data(), valid.data()));
+    for (size_t i = 0; i < inputs.size(); i++)
+        for (uint32_t s = 0; s < k; s++) {
+            const size_t idx = i * k + s;
+            if (!valid[idx]) continue;
+            Key key;
+            std::copy(keys.begin() + 32 * idx, keys.begin() + 32 * idx + 32, key.begin());
+            output.emplace_back(label(inputs[i], s), key);
+        }
+}
+
+void check_rc(vk_engine *e, int rc)
+{
+    if (rc != VK_OK) throw EngineError(rc, vk_last_error(e));
+}
+
+} // namespace vuke

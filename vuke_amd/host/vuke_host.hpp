@@ -1,0 +1,169 @@
+// vuke_host.hpp -- host side above the C ABI (include/vuke_hip.h), mirroring the reference's
+// plugin interfaces for the hot path.  The reference is Rust and no Rust toolchain exists in this
+// pipeline, so the mirror is C++: same names, argument meaning and error behaviour as
+//   Transform / TransformType   src/transform/mod.rs:39-215
+//   Source / ProcessStats       src/source/mod.rs:23-39, RangeSource src/source/range.rs:14-79
+//   KeyDeriver / DerivedKey     src/derive.rs:12-165
+//   Matcher / MatchInfo         src/matcher.rs:13-108
+//   Output / ConsoleOutput      src/output/mod.rs:22-37, src/output/console.rs:14-122
+// All compute (transform, k*G, hash160, probing) happens on the GPU through libvuke_hip.so; this
+// layer only parses, formats text (hex / Base58Check / bech32 / decimal) and drives launches.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/vuke_hip.h"
+
+namespace vuke {
+
+using Key = std::array<uint8_t, 32>;
+
+// ---------------------------------------------------------------- text codecs (codecs.cpp)
+void sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
+std::string hex_encode(const uint8_t *b, size_t n);
+std::string base58check_encode(const uint8_t *payload, size_t len);
+bool base58check_decode(const std::string &s, std::vector<uint8_t> &out); // version byte + payload
+std::string segwit_encode(const std::string &hrp, int witver, const uint8_t *prog, size_t len);
+bool segwit_decode(const std::string &hrp, const std::string &addr, int &witver, std::vector<uint8_t> &prog);
+std::string decimal_of_be(const uint8_t be[32]);
+
+// ---------------------------------------------------------------- derive.rs
+struct DerivedKey { // src/derive.rs:12-41
+    Key raw{};
+    std::string private_key_hex, private_key_decimal, private_key_binary;
+    uint16_t bit_length = 0, hamming_weight = 0;
+    uint8_t leading_zeros = 0;
+    std::string pubkey_compressed, pubkey_uncompressed; // not produced by the device path (unused by console output)
+    std::string wif_compressed, wif_uncompressed;
+    std::string p2pkh_compressed, p2pkh_uncompressed, p2wpkh;
+    uint8_t h160_c[20]{}, h160_u[20]{};
+    std::array<const std::string *, 3> addresses() const { return {&p2pkh_compressed, &p2pkh_uncompressed, &p2wpkh}; }
+};
+
+// KeyDeriver: the k*G + hash160 half runs on the device (vk_derive_batch / vk_generate / hits);
+// this class assembles the reference's record from the device outputs (mainnet, src/derive.rs:62-67).
+class KeyDeriver {
+public:
+    explicit KeyDeriver(vk_engine *engine) : engine_(engine) {}
+    // derive(&[u8;32]) for arbitrary keys: normalisation + hash160s on the GPU, text on the host
+    std::vector<DerivedKey> derive(const std::vector<Key> &keys) const;
+    DerivedKey derive(const Key &key) const { return derive(std::vector<Key>{key})[0]; }
+    // assemble from values the device already produced
+    static DerivedKey from_device(const uint8_t normalised[32], const uint8_t h160_c[20], const uint8_t h160_u[20]);
+
+private:
+    vk_engine *engine_;
+};
+
+// ---------------------------------------------------------------- matcher.rs
+enum class AddressType { P2pkhCompressed, P2pkhUncompressed, P2wpkh };
+const char *address_type_str(AddressType t); // AddressType::as_str
+struct MatchInfo {
+    AddressType address_type;
+    std::string address;
+};
+
+class Matcher {
+public:
+    static Matcher load(const std::string &path);                     // src/matcher.rs:45-59 (throws std::runtime_error on I/O error)
+    static Matcher from_addresses(const std::vector<std::string> &a); // :62-66
+    std::optional<MatchInfo> check(const DerivedKey &d) const;        // :72-98
+    size_t count() const { return targets_.size(); }                  // :101-103
+    bool is_empty() const { return targets_.empty(); }
+    // Device form of the set: hash160 + kind for every line that is a valid mainnet P2PKH / P2WPKH
+    // address (any other line can never equal a derived address, so it cannot match in the reference).
+    void device_targets(std::vector<uint8_t> &h160, std::vector<uint8_t> &kind) const;
+    bool contains(const std::string &s) const { return targets_.count(s) != 0; }
+
+private:
+    std::unordered_set<std::string> targets_;
+};
+
+// ---------------------------------------------------------------- transform/mod.rs
+class Transform {
+public:
+    explicit Transform(const vk_transform_spec &s) : spec_(s) {}
+    const char *name() const;                              // Transform::name()
+    const vk_transform_spec &spec() const { return spec_; }
+    uint32_t slots() const { return vk_slots_per_input(&spec_); }
+    std::string label(uint64_t seed, uint32_t sub) const;  // the `source` string apply_batch pushes
+    bool supports_gpu() const { return true; }
+    // apply_batch for numeric inputs, on the device: appends (label, key) in the reference's order
+    void apply_batch(vk_engine *e, const std::vector<uint64_t> &inputs, std::vector<std::pair<std::string, Key>> &output) const;
+
+private:
+    vk_transform_spec spec_;
+};
+
+struct TransformType {
+    // TransformType::from_str (src/transform/mod.rs:170-215): throws std::invalid_argument with the
+    // reference's message for unknown names; transforms outside the device path (direct, md5, armory,
+    // multibit, electrum, bitimage, double_sha256) are recognised and rejected as unsupported.
+    static Transform from_str(const std::string &s);
+};
+
+// ---------------------------------------------------------------- output/
+class Output {
+public:
+    virtual ~Output() = default;
+    virtual void key(const std::string &source, const std::string &transform, const DerivedKey &d) = 0;
+    virtual void hit(const std::string &source, const std::string &transform, const DerivedKey &d, const MatchInfo &m) = 0;
+    virtual void flush() = 0;
+};
+
+class ConsoleOutput : public Output { // src/output/console.rs
+public:
+    ConsoleOutput() : fp_(stdout), own_(false), verbose_(false) {}
+    static std::unique_ptr<ConsoleOutput> verbose();
+    static std::unique_ptr<ConsoleOutput> to_file(const std::string &path, bool verbose = false); // throws on open failure
+    ~ConsoleOutput() override;
+    void key(const std::string &source, const std::string &transform, const DerivedKey &d) override;
+    void hit(const std::string &source, const std::string &transform, const DerivedKey &d, const MatchInfo &m) override;
+    void flush() override;
+
+private:
+    ConsoleOutput(FILE *fp, bool own, bool verbose) : fp_(fp), own_(own), verbose_(verbose) {}
+    FILE *fp_;
+    bool own_, verbose_;
+    std::mutex mu_;
+};
+
+// ---------------------------------------------------------------- source/
+struct ProcessStats { // src/source/mod.rs:35-39
+    uint64_t inputs_processed = 0, keys_generated = 0, matches_found = 0;
+};
+
+class Source {
+public:
+    virtual ~Source() = default;
+    // process(&[Box<dyn Transform>], Option<&Matcher>, &dyn Output) -> Result<ProcessStats>
+    virtual ProcessStats process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output) = 0;
+};
+
+// RangeSource on the GPU: inclusive [start, end] (src/source/range.rs:14-79).
+class HipRangeSource : public Source {
+public:
+    HipRangeSource(vk_engine *engine, uint64_t start, uint64_t end) : start(start), end(end), engine_(engine) {}
+    ProcessStats process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output) override;
+    uint64_t start, end;
+
+private:
+    vk_engine *engine_;
+};
+
+// error carrying the C ABI's code + message
+struct EngineError : std::runtime_error {
+    int code;
+    EngineError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+void check_rc(vk_engine *e, int rc);
+
+} // namespace vuke
