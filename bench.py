@@ -63,9 +63,13 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # table geometry of the flagship run: 9 signed-digit windows (120 GB of the 288 GB HBM, 8 point additions per
+    # key), 128 keys per lane per field inversion, 3 resident workgroups per CU.  --layout 0 --window-bits 24 is the
+    # library default (11.8 GB, 10 additions).
+    ap.add_argument("--layout", type=int, default=1)
     ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=0)
-    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--blocks-per-cu", type=int, default=3)
     args = ap.parse_args()
 
     import torch
@@ -89,7 +93,14 @@ def main():
     import vuke_amd
     from vuke_amd import _ffi as ffi
 
-    eng = vuke_amd.Engine(local_rank, window_bits=args.window_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu)
+    try:
+        eng = vuke_amd.Engine(local_rank, window_bits=args.window_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=args.layout)
+    except vuke_amd.VkError as exc:
+        if args.layout == 0 or exc.code != ffi.VK_E_HIP:
+            raise
+        # the 120 GB table did not fit (shared or smaller device): fall back to the library's default geometry
+        print(f"bench.py: layout {args.layout} unavailable ({exc}); using the default 24-bit uniform table", file=sys.stderr)
+        eng = vuke_amd.Engine(local_rank, batch=args.batch, blocks_per_cu=args.blocks_per_cu)
     spec = ffi.spec(ffi.T_MILKSAD)
 
     # synthetic targets: compressed P2PKH hash160 of 1024 known seeds, derived on the device
@@ -174,6 +185,8 @@ def main():
                             f"step = one 2^{BLOCK_LOG2}-seed block per GPU (16 blocks = full 2^32 sweep)",
                 "seeds_per_step_per_gpu": BLOCK,
                 "window_bits": eng.info()["window_bits"],
+                "windows": eng.info()["windows"],
+                "layout": eng.info()["layout"],
                 "table_gb": eng.info()["table_bytes"] / 1e9,
                 "table_build_seconds": eng.info()["table_build_seconds"],
                 "batch": eng.info()["batch"],

@@ -101,11 +101,15 @@ typedef struct vk_sweep_stats {
 
 typedef struct vk_engine vk_engine;
 
+/* table layouts */
+#define VK_LAYOUT_UNIFORM 0u
+#define VK_LAYOUT_SIGNED9 1u /* 9 signed-digit windows (4 x 29 + 5 x 28 bits): 8 additions per key, 120 GB table */
+
 typedef struct vk_engine_opts {
     uint32_t window_bits;  /* fixed-base window width of the k*G table: 4..26 (0 = default 24: 11.8 GB) */
     uint32_t batch;        /* keys per lane sharing one field inversion (0 = default) */
     uint32_t blocks_per_cu;/* resident 256-thread workgroups per CU to launch (0 = default) */
-    uint32_t _reserved;
+    uint32_t layout;       /* VK_LAYOUT_*: 0 = uniform unsigned window_bits-wide windows (default) */
     void *stream;          /* hipStream_t to run on (NULL = engine creates its own) */
 } vk_engine_opts;
 
@@ -116,7 +120,9 @@ typedef struct vk_engine_info_t {
     uint32_t windows;       /* ceil(256 / W) table lookups + (windows - 1) point additions per key */
     uint32_t batch;         /* keys per lane per field inversion */
     uint32_t blocks_per_cu;
-    uint64_t table_bytes;   /* windows * 2^W * 64 */
+    uint32_t layout;
+    uint32_t _pad;
+    uint64_t table_bytes;   /* table entries * 64 */
     double table_build_seconds;
 } vk_engine_info_t;
 

@@ -256,3 +256,46 @@ def test_other_window_widths(vko):
         ost, _ = vko.sweep(vko.spec(vko.T_MILKSAD), 1000, 1999, flags=3, nthreads=8)
         assert st["digest"] == ost["digest"] and st["keys"] == 1000, W
         e.close()
+
+
+def test_signed_nine_window_layout(eng, vko):
+    """VK_LAYOUT_SIGNED9: 9 signed-digit windows (8 additions per key, 120 GB table)."""
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+    e = vuke_amd.Engine(0, layout=ffi.LAYOUT_SIGNED9, batch=16)
+    info = e.info()
+    assert info["layout"] == 1 and info["windows"] == 9 and info["table_bytes"] == (4 * 2**28 + 4 * 2**27 + 2**28 + 9) * 64
+    # table entries: window i covers bits off_i.., entry d = (d << off_i) * G; the top entry 2^28 is 2^256 mod n
+    offs = [0, 29, 58, 87, 116, 144, 172, 200, 228]
+    tbs = [28, 28, 28, 28, 27, 27, 27, 27, 28]
+    rnd = random.Random(31)
+    picks = [(i, d) for i in range(9) for d in (1, 2, 7, 8, 9, (1 << tbs[i]) - 1, 1 << tbs[i], (1 << (tbs[i] // 2)), (3 << (tbs[i] // 2)) | 5)]
+    picks += [(i, rnd.randrange(1, (1 << tbs[i]) + 1)) for i in range(9) for _ in range(6)]
+    for i, d in picks:
+        k = (d << offs[i]) % N if (d << offs[i]) >> 256 else d << offs[i]
+        if (d << offs[i]) >> 256 and not (i == 8 and d == 1 << 28):
+            continue
+        _, p65 = vko.pubkey(be(k))
+        x, y = e.table_entry(i, d)
+        assert x + y == p65[1:], (i, d)
+    # keys that drive the recoding through every corner: digits exactly half, half+1, all ones, carries into the top window
+    keys = [be(1), be(N - 1), be(N - 2), be(2**256 - 1), be(N), bytes(32), be(2**255), be(2**228), be(2**228 - 1),
+            be((1 << 28) | 1), be(1 << 28), be((1 << 28) + 1), be((1 << 29) - 1), be(1 << 29), be(((1 << 28) + 1) << 29),
+            be(int("1" * 256, 2) >> 1), be(int("10" * 128, 2)), be(int("01" * 128, 2)), be(0xFFFFFFF << 200), be((0x8000001 << 200) | (1 << 199))]
+    for i in range(9):
+        half = 1 << (tbs[i] if i < 8 else 27)
+        keys += [be((half << offs[i]) % N or 1), be(((half + 1) << offs[i]) % N or 1), be(((half - 1) << offs[i]) | 1)]
+    keys += [be(rnd.getrandbits(256)) for _ in range(3000)]
+    norm, hc, hu = e.derive_batch(keys)
+    rn, rc, ru = eng.derive_batch(keys)          # default layout, itself checked against the oracle elsewhere
+    assert (norm, hc, hu) == (rn, rc, ru)
+    for k, c, u in list(zip(keys, hc, hu))[:60]:
+        assert (c, u) == vko.derive_h160(k), k.hex()
+    # sweeps: digest parity with the oracle (small) and with the default layout (large)
+    st, _ = e.sweep(ffi.spec(ffi.T_MILKSAD), 1000, 2999, flags=3)
+    ost, _ = vko.sweep(vko.spec(vko.T_MILKSAD), 1000, 2999, flags=3, nthreads=8)
+    assert st["digest"] == ost["digest"] and st["keys"] == 2000
+    a, _ = e.sweep(ffi.spec(ffi.T_XORSHIFT), 7 * 10**9, 7 * 10**9 + 2**21 - 1, flags=3)
+    b, _ = eng.sweep(ffi.spec(ffi.T_XORSHIFT), 7 * 10**9, 7 * 10**9 + 2**21 - 1, flags=3)
+    assert a["digest"] == b["digest"] and a["keys"] == b["keys"] == 4 * 2**21
+    e.close()

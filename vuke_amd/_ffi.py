@@ -16,6 +16,7 @@ VARIANT_ALL = 0xFFFFFFFF
 F_COMPRESSED, F_UNCOMPRESSED = 1, 2
 ADDR_P2PKH_C, ADDR_P2PKH_U, ADDR_P2WPKH = 0, 1, 2
 TARGET_P2PKH, TARGET_P2WPKH = 0, 1
+LAYOUT_UNIFORM, LAYOUT_SIGNED9 = 0, 1
 
 
 class TransformSpec(C.Structure):
@@ -34,12 +35,13 @@ class SweepStats(C.Structure):
 
 class EngineOpts(C.Structure):
     _fields_ = [("window_bits", C.c_uint32), ("batch", C.c_uint32), ("blocks_per_cu", C.c_uint32),
-                ("_reserved", C.c_uint32), ("stream", C.c_void_p)]
+                ("layout", C.c_uint32), ("stream", C.c_void_p)]
 
 
 class EngineInfo(C.Structure):
     _fields_ = [("device", C.c_int32), ("cu_count", C.c_uint32), ("window_bits", C.c_uint32), ("windows", C.c_uint32),
-                ("batch", C.c_uint32), ("blocks_per_cu", C.c_uint32), ("table_bytes", C.c_uint64),
+                ("batch", C.c_uint32), ("blocks_per_cu", C.c_uint32), ("layout", C.c_uint32), ("_pad", C.c_uint32),
+                ("table_bytes", C.c_uint64),
                 ("table_build_seconds", C.c_double)]
 
 
@@ -92,11 +94,11 @@ class VkError(RuntimeError):
 class Engine:
     """One engine per GPU (vk_engine).  Raises VkError when no gfx950 device is usable."""
 
-    def __init__(self, device=0, window_bits=0, batch=0, blocks_per_cu=0, stream=None):
+    def __init__(self, device=0, window_bits=0, batch=0, blocks_per_cu=0, stream=None, layout=0):
         L = load()
         self._L = L
         self._e = C.c_void_p()
-        opts = EngineOpts(window_bits, batch, blocks_per_cu, 0, stream)
+        opts = EngineOpts(window_bits, batch, blocks_per_cu, layout, stream)
         rc = L.vk_engine_create_ex(device, C.byref(opts), C.byref(self._e))
         if rc != VK_OK:
             raise VkError(rc, (L.vk_last_error(None) or b"").decode())

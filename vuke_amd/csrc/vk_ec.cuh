@@ -78,9 +78,21 @@ VK_DEV void table_load(fe &x, fe &y, const uint4 *__restrict__ p)
     y.v[4] = d.x; y.v[5] = d.y; y.v[6] = d.z; y.v[7] = d.w;
 }
 
+// ---- window layout -------------------------------------------------------------------------
+// Window i covers scalar bits [off, off + bits).  Unsigned windows use the digit as it is; in a
+// signed layout a digit above 2^(bits-1) is replaced by its negative (table entry 2^bits - d, y
+// negated) and a carry of one into the next window, so a window needs only 2^(bits-1) + 1 entries.
+// The last window is always unsigned (it absorbs the final carry; its entry 2^bits, i.e. the
+// scalar 2^256, is stored as (2^256 mod n) * G).  Entry d of window i lives at table[base + d].
+#define VK_MAX_WIN 64
+struct vk_win_desc {
+    u64 base;
+    u32 off, bits, sgn, tb; // tb = index bits of the window's table = bits - sgn
+};
+
 VK_DEV u32 scalar_digit(const u32 k[8], u32 bitpos, u32 W)
 {
-    // W <= 20 bits starting at bitpos (may straddle two limbs)
+    // W <= 31 bits starting at bitpos (may straddle two limbs)
     u32 limb = bitpos >> 5, sh = bitpos & 31;
     u32 lo = 0, hi = 0;
 #pragma unroll
@@ -92,26 +104,56 @@ VK_DEV u32 scalar_digit(const u32 k[8], u32 bitpos, u32 W)
     return (u32)(both >> sh) & ((1u << W) - 1u);
 }
 
-// acc = k*G, k in [1, n).  Returns Jacobian (z = 1 possible).  table: [nwin][2^W] entries.
-VK_DEV void ecmult_table(jac &acc, const u32 k[8], const uint4 *__restrict__ table, u32 W, u32 nwin)
+// digit of window wd (magnitude), updating the running carry; neg = take the point's negative
+VK_DEV u32 window_digit(const u32 k[8], const vk_win_desc &wd, u32 &carry, bool &neg)
+{
+    u32 raw = scalar_digit(k, wd.off, wd.bits) + carry;
+    const u32 half = 1u << (wd.bits - 1);
+    neg = (wd.sgn != 0) && (raw > half);
+    carry = neg ? 1u : 0u;
+    return neg ? (1u << wd.bits) - raw : raw;
+}
+
+// y = p - y for lanes with neg (y canonical and non-zero for table points)
+VK_DEV void fe_cond_negate(fe &y, bool neg)
+{
+    const u32 pl[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    u64 bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 d = (u64)pl[i] - y.v[i] - bw;
+        bw = (d >> 32) & 1;
+        y.v[i] = neg ? (u32)d : y.v[i];
+    }
+}
+
+// acc = k*G, k in [1, n).  Returns Jacobian (z = 1 possible).
+// No special cases are needed in the adder: after windows 0..i-1 the accumulator is s*G with
+// |s| < 2^off_i (s != 0 unless all digits so far were zero, in which case it is still "infinity"),
+// the addend is t*G with |t| >= 2^off_i, so s != +-t, and |s + t| < n.
+VK_DEV void ecmult_table(jac &acc, const u32 k[8], const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin)
 {
     bool inf = true;
     fe_set_zero(acc.x);
     fe_set_zero(acc.y);
     fe_set_one(acc.z);
     // software prefetch of the next window's entry
-    u32 d = scalar_digit(k, 0, W);
+    u32 carry = 0;
+    bool neg;
+    u32 d = window_digit(k, wins[0], carry, neg);
     fe qx, qy;
-    table_load(qx, qy, table + ((size_t)d << 2));
+    table_load(qx, qy, table + ((wins[0].base + d) << 2));
 #pragma unroll 1
     for (u32 w = 0; w < nwin; w++) {
         fe cx = qx, cy = qy;
-        u32 cd = d;
+        const u32 cd = d;
+        const bool cneg = neg;
         if (w + 1 < nwin) {
-            d = scalar_digit(k, (w + 1) * W, W);
-            table_load(qx, qy, table + ((((size_t)(w + 1) << W) + d) << 2));
+            d = window_digit(k, wins[w + 1], carry, neg);
+            table_load(qx, qy, table + ((wins[w + 1].base + d) << 2));
         }
         if (cd != 0) {
+            fe_cond_negate(cy, cneg);
             if (inf) {
                 acc.x = cx;
                 acc.y = cy;

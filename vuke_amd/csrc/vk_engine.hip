@@ -24,6 +24,9 @@ struct vk_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int cu_count = 0;
     u32 W = 24, nwin = 11; // default: 11 windows x 2^24 entries x 64 B = 11.8 GB of the 288 GB HBM
+    u32 layout = 0;        // 0 uniform unsigned W-bit windows, 1 nine signed windows (VK_LAYOUT_SIGNED9)
+    vk_win_desc wins[VK_MAX_WIN];
+    u64 table_entries = 0;
     double table_build_seconds = 0.0;
     u32 batch = 32;
     u32 blocks_per_cu = 0;
@@ -127,10 +130,41 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     }
     e->cu_count = prop.multiProcessorCount;
     if (opts && opts->window_bits) {
-        if (opts->window_bits < 4 || opts->window_bits > 26) return fail(e, VK_E_INVALID_ARG, "window_bits must be in 4..26");
+        if (opts->window_bits < 4 || opts->window_bits > 28) return fail(e, VK_E_INVALID_ARG, "window_bits must be in 4..28");
         e->W = opts->window_bits;
     }
-    e->nwin = (256 + e->W - 1) / e->W;
+    if (opts && opts->layout > VK_LAYOUT_SIGNED9) return fail(e, VK_E_INVALID_ARG, "unknown table layout");
+    e->layout = opts ? opts->layout : 0;
+    memset(e->wins, 0, sizeof e->wins);
+    if (e->layout == VK_LAYOUT_SIGNED9) {
+        // 4 x 29 + 5 x 28 = 256 bits; windows 0..7 signed (2^(bits-1) + 1 entries), window 8 unsigned with the
+        // inclusive top entry: (4*2^28 + 4*2^27 + 2^28 + 9) * 64 B = 120 GB
+        e->nwin = 9;
+        e->W = 29;
+        u32 off = 0;
+        u64 base = 0;
+        for (u32 i = 0; i < 9; i++) {
+            vk_win_desc &w = e->wins[i];
+            w.bits = i < 4 ? 29 : 28;
+            w.sgn = i < 8 ? 1 : 0;
+            w.tb = w.bits - w.sgn;
+            w.off = off;
+            w.base = base;
+            off += w.bits;
+            base += (1ull << w.tb) + 1;
+        }
+        e->table_entries = base;
+    } else {
+        e->nwin = (256 + e->W - 1) / e->W;
+        for (u32 i = 0; i < e->nwin; i++) {
+            vk_win_desc &w = e->wins[i];
+            w.bits = w.tb = e->W;
+            w.sgn = 0;
+            w.off = i * e->W;
+            w.base = (u64)i << e->W;
+        }
+        e->table_entries = (u64)e->nwin << e->W;
+    }
     if (opts && opts->batch) {
         if (opts->batch > 1024) return fail(e, VK_E_INVALID_ARG, "batch must be <= 1024");
         e->batch = opts->batch;
@@ -153,23 +187,27 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
         HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vk_sweep_kernel<VK_T_MILKSAD>, VK_BLOCK, 0));
         e->blocks_per_cu = (u32)std::max(1, std::min(occ, 4));
     }
-    // the k*G table: nwin x 2^W affine points (64 B each), built on the device in two phases
-    const size_t entries = (size_t)e->nwin << e->W;
-    HIPCHK(e, hipMalloc(&e->table, entries * 64));
-    {
-        u32 h = e->W / 2;
+    // the k*G table: affine points (64 B each), built on the device window by window in two phases
+    HIPCHK(e, hipMalloc(&e->table, e->table_entries * 64));
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    for (u32 i = 0; i < e->nwin; i++) {
+        const vk_win_desc &w = e->wins[i];
+        u32 h = w.tb / 2;
         if (h < 3) h = 3; // the combine kernel walks VK_TBL_K = 8 low digits per lane
-        const u64 seeds = (u64)e->nwin * ((1ull << h) + (1ull << (e->W - h)));
-        const u64 runs = (u64)e->nwin * (1ull << (e->W - h)) * ((1ull << h) / VK_TBL_K);
-        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-        hipLaunchKernelGGL(vk_table_seed_kernel, dim3((u32)((seeds + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, e->table,
-                           e->W, e->nwin, h);
+        const u32 with_max = e->layout == VK_LAYOUT_SIGNED9 ? 1u : 0u;
+        const u64 seeds = (1ull << h) + (1ull << (w.tb - h)) + with_max;
+        const u64 runs = (1ull << (w.tb - h)) * ((1ull << h) / VK_TBL_K);
+        uint4 *win = e->table + w.base * 4;
+        hipLaunchKernelGGL(vk_table_seed_kernel, dim3((u32)((seeds + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, win, w.off,
+                           w.tb, h, with_max);
         HIPCHK(e, hipGetLastError());
-        hipLaunchKernelGGL(vk_table_combine_kernel, dim3((u32)((runs + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, e->table,
-                           e->W, e->nwin, h);
+        hipLaunchKernelGGL(vk_table_combine_kernel, dim3((u32)((runs + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, win, w.off,
+                           w.tb, h);
         HIPCHK(e, hipGetLastError());
-        HIPCHK(e, hipEventRecord(e->ev1, e->stream));
-        HIPCHK(e, hipStreamSynchronize(e->stream));
+    }
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    {
         float ms = 0.f;
         HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
         e->table_build_seconds = (double)ms * 1e-3;
@@ -205,7 +243,8 @@ extern "C" int vk_engine_info(const vk_engine *e, vk_engine_info_t *out)
     out->windows = e->nwin;
     out->batch = e->batch;
     out->blocks_per_cu = e->blocks_per_cu;
-    out->table_bytes = ((uint64_t)e->nwin << e->W) * 64;
+    out->table_bytes = e->table_entries * 64;
+    out->layout = e->layout;
     out->table_build_seconds = e->table_build_seconds;
     return VK_OK;
 }
@@ -313,8 +352,8 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     p.slots = slots;
     p.R = R;
     p.flags = flags;
-    p.W = e->W;
     p.nwin = e->nwin;
+    memcpy(p.wins, e->wins, sizeof p.wins);
     p.table = e->table;
     p.tgt = e->tgt;
     p.tgt_mask = e->tgt_cap ? e->tgt_cap - 1 : 0;
@@ -598,10 +637,15 @@ extern "C" int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digi
 {
     if (!e || !xy) return VK_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
-    if (window >= e->nwin || digit >= (1u << e->W)) return fail(e, VK_E_INVALID_ARG, "table index out of range");
+    if (window >= e->nwin) return fail(e, VK_E_INVALID_ARG, "table index out of range");
+    {
+        const vk_win_desc &w = e->wins[window];
+        const u64 count = (window + 1 < e->nwin ? e->wins[window + 1].base : e->table_entries) - w.base;
+        if (digit >= count) return fail(e, VK_E_INVALID_ARG, "table index out of range");
+    }
     HIPCHK(e, hipSetDevice(e->device));
     u32 raw[16];
-    HIPCHK(e, hipMemcpy(raw, e->table + (((size_t)window << e->W) + digit) * 4, 64, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(raw, e->table + (e->wins[window].base + digit) * 4, 64, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) {
         u32 xv = raw[7 - i], yv = raw[8 + 7 - i];
         xy[4 * i] = (uint8_t)(xv >> 24); xy[4 * i + 1] = (uint8_t)(xv >> 16); xy[4 * i + 2] = (uint8_t)(xv >> 8); xy[4 * i + 3] = (uint8_t)xv;

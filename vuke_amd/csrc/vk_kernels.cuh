@@ -45,7 +45,7 @@ struct vk_sweep_params {
     u32 slots;      // slots per input
     u32 R;          // inputs per lane per tile
     u32 flags;
-    u32 W, nwin;
+    u32 nwin, pad1;
     u32 tgt_mask;   // capacity - 1 (power of two), valid when tgt != nullptr
     u32 hit_cap;
     u32 pad0;
@@ -59,6 +59,7 @@ struct vk_sweep_params {
     u32 *out_h160c;    // n_items x 5 words
     u32 *out_h160u;
     unsigned char *out_valid;
+    vk_win_desc wins[VK_MAX_WIN];
 };
 
 VK_DEV u32 probe_targets(const uint4 *__restrict__ tgt, u32 mask, const u32 h[5])
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
 #pragma unroll
                 for (int i = 0; i < 8; i++) k[i] = kw[7 - i];
                 scalar_normalize(k);
-                ecmult_table(P, k, p.table, p.W, p.nwin);
+                ecmult_table(P, k, p.table, p.wins, p.nwin);
             } else { // (0, 0, 1) marks "no key here"; (0,0) is not on the curve
                 fe_set_zero(P.x);
                 fe_set_zero(P.y);
@@ -287,10 +288,20 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
 //            window, each by a generic double-and-add (a few 10^4 scalar multiplications);
 //   combine  every other entry is T[i << h] + T[j]: one affine + affine addition, eight of them
 //            per lane sharing one field inversion (Montgomery's trick).
-VK_DEV bool table_scalar(u32 s[8], u32 d, u32 shift)
+VK_DEV bool table_scalar(u32 s[8], u32 d, u32 shift, bool allow_2p256 = false)
 {
     const u32 dbits = 32 - __builtin_clz(d | 1u);
-    if (d == 0 || shift + dbits > 256) return false;
+    if (d == 0) return false;
+    if (shift + dbits > 256) {
+        // the one scalar beyond 256 bits that can occur: 2^256 (final carry of a signed layout) = 2^256 mod n
+        if (allow_2p256 && shift + dbits == 257 && (d & (d - 1)) == 0) {
+            const u32 r[8] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 1u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = r[i];
+            return true;
+        }
+        return false;
+    }
     const u32 limb = shift >> 5, sh = shift & 31;
     const u64 wide = (u64)d << sh;
 #pragma unroll
@@ -311,18 +322,21 @@ VK_DEV void table_store(uint4 *dst, const fe &x, const fe &y)
     dst[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
 }
 
-// seed phase: idx enumerates, per window, the 2^h low digits then the 2^(W-h) high digits
-__global__ void __launch_bounds__(VK_BLOCK) vk_table_seed_kernel(uint4 *table, u32 W, u32 nwin, u32 h)
+// seed phase for one window (`win` -> its entry 0, scalar shift `off`, `tb` index bits): the 2^h low
+// digits, the 2^(tb-h) high digits i << h, and (with_max) the single entry 2^tb.
+__global__ void __launch_bounds__(VK_BLOCK) vk_table_seed_kernel(uint4 *win, u32 off, u32 tb, u32 h, u32 with_max)
 {
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
-    const u32 nlo = 1u << h, nhi = 1u << (W - h), per = nlo + nhi;
-    if (idx >= (u64)nwin * per) return;
-    const u32 w = (u32)(idx / per), r = (u32)(idx % per);
-    if (r == nlo) return; // high digit 0 is entry 0 again
-    const u32 d = r < nlo ? r : (r - nlo) << h;
-    uint4 *dst = table + (((u64)w << W) + d) * 4;
+    const u32 nlo = 1u << h, nhi = 1u << (tb - h);
+    if (idx >= (u64)nlo + nhi + with_max) return;
+    u32 d;
+    if (idx < nlo) d = (u32)idx;
+    else if (idx < (u64)nlo + nhi) d = (u32)(idx - nlo) << h;
+    else d = 1u << tb;
+    if (idx == nlo) return; // high digit 0 is entry 0 again
+    uint4 *dst = win + (u64)d * 4;
     u32 s[8];
-    if (!table_scalar(s, d, W * w)) {
+    if (!table_scalar(s, d, off, with_max && d == (1u << tb))) {
         dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(0, 0, 0, 0);
         return;
     }
@@ -335,21 +349,18 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_table_seed_kernel(uint4 *table, u
 }
 
 #define VK_TBL_K 8
-// combine phase: one lane = one (window, high digit i >= 1) and VK_TBL_K consecutive low digits
-__global__ void __launch_bounds__(VK_BLOCK) vk_table_combine_kernel(uint4 *table, u32 W, u32 nwin, u32 h)
+// combine phase for one window: one lane = one high digit i >= 1 and VK_TBL_K consecutive low digits
+__global__ void __launch_bounds__(VK_BLOCK) vk_table_combine_kernel(uint4 *win, u32 off, u32 tb, u32 h)
 {
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
-    const u32 nlo = 1u << h, nhi = 1u << (W - h), runs = nlo / VK_TBL_K;
-    if (idx >= (u64)nwin * nhi * runs) return;
-    const u32 run = (u32)(idx % runs);
-    const u32 i = (u32)((idx / runs) % nhi), w = (u32)(idx / ((u64)runs * nhi));
+    const u32 nlo = 1u << h, nhi = 1u << (tb - h), runs = nlo / VK_TBL_K;
+    if (idx >= (u64)nhi * runs) return;
+    const u32 run = (u32)(idx % runs), i = (u32)(idx / runs);
     if (i == 0) return; // those are the seeded low multiples themselves
-    uint4 *win = table + ((u64)w << W) * 4;
-    const u32 shift = W * w;
     const u32 hi_d = i << h;
     // digits whose scalar does not fit 256 bits are never looked up: leave them zero
     u32 tmp[8];
-    const bool hi_ok = table_scalar(tmp, hi_d, shift);
+    const bool hi_ok = table_scalar(tmp, hi_d, off);
     fe xi, yi;
     table_load(xi, yi, win + (u64)hi_d * 4);
     fe c[VK_TBL_K]; // running products of the x differences

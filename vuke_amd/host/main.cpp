@@ -25,7 +25,8 @@ static int usage(const char *msg)
                     "  -o, --output <FILE>  write to FILE instead of stdout\n"
                     "  --network <N>        accepted and ignored, like the reference (src/main.rs:464,499)\n"
                     "  --device <N>         GPU index (default 0)\n"
-                    "  --window-bits <W>    k*G table window width (default 24)\n");
+                    "  --window-bits <W>    k*G table window width (default 24)\n"
+                    "  --layout <L>         uniform (default) | signed9 (120 GB table, 8 additions per key)\n");
     return 2;
 }
 
@@ -48,7 +49,7 @@ int main(int argc, char **argv)
     bool verbose = false, have_range = false, have_start = false, have_end = false;
     uint64_t start = 0, end = 0;
     int device = 0;
-    unsigned window_bits = 0;
+    unsigned window_bits = 0, layout = VK_LAYOUT_UNIFORM;
     try {
         for (int i = 2; i < argc; i++) {
             std::string a = argv[i];
@@ -65,6 +66,7 @@ int main(int argc, char **argv)
             else if (a == "--network") (void)need("--network");
             else if (a == "--device") device = atoi(need("--device"));
             else if (a == "--window-bits") window_bits = (unsigned)atoi(need("--window-bits"));
+            else if (a == "--layout") layout = std::string(need("--layout")) == "signed9" ? VK_LAYOUT_SIGNED9 : VK_LAYOUT_UNIFORM;
             else if (a == "range") have_range = true;
             else if (a == "--start") { start = parse_u64(need("--start")); have_start = true; }
             else if (a == "--end") { end = parse_u64(need("--end")); have_end = true; }
@@ -82,6 +84,7 @@ int main(int argc, char **argv)
         vk_engine *engine = nullptr;
         vk_engine_opts opts{};
         opts.window_bits = window_bits;
+        opts.layout = layout;
         int rc = vk_engine_create_ex(device, &opts, &engine);
         if (rc != VK_OK) {
             fprintf(stderr, "GPU engine unavailable: %s\n", vk_last_error(nullptr));
