@@ -54,6 +54,8 @@ extern "C" {
 #define VK_T_LCG 3u          /* src/lcg.rs:68-128; variants 0 glibc, 1 minstd, 2 msvc, 3 borland */
 #define VK_T_XORSHIFT 4u     /* src/xorshift.rs:69-74; 0 xorshift64, 1 xorshift128, 2 128+, 3 xoroshiro128** */
 #define VK_T_SHA256_CHAIN 5u /* src/sha256_chain.rs:74-79; 0 iterated, 1 indexed:be, 2 indexed:le, 3 counter */
+#define VK_T_ELECTRUM 6u     /* src/electrum.rs, src/transform/electrum.rs: STRING inputs only (vk_transform_strings);
+                                variant = 0 receiving / 1 change chain, chain_depth = derivation count (reference: 20) */
 #define VK_VARIANT_ALL 0xFFFFFFFFu
 
 typedef struct vk_transform_spec {
@@ -161,6 +163,17 @@ int vk_derive_batch(vk_engine *e, const uint8_t *keys /* n*32 */, size_t n, uint
 /* Transform::apply_batch for numeric inputs: keys_out = n*slots*32, valid = n*slots. */
 int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, const uint64_t *seeds, size_t n,
                        uint8_t *keys_out, uint8_t *valid);
+
+/* Transform::apply_batch for string inputs (Input::from_string; wordlist / stdin sources).  String i is
+ * data[offsets[i] .. offsets[i+1]).  Supported kinds: VK_T_ELECTRUM (strings up to 64 bytes; longer ones
+ * return VK_E_UNSUPPORTED).  keys_out = n*slots*32, valid = n*slots, slot order = emit order. */
+int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
+                         uint8_t *keys_out, uint8_t *valid);
+
+/* KeyDeriver::derive + Matcher::check over keys the caller already holds (string-input sources): like
+ * vk_sweep, with hit.seed = index of the key in `keys` and hit.sub_index = 0. */
+int vk_scan_keys(vk_engine *e, const uint8_t *keys /* n*32 */, size_t n, uint32_t flags, vk_hit *hits, size_t hit_cap,
+                 vk_sweep_stats *out);
 
 /* Slots one input occupies under `t` (0 if the spec is invalid). */
 uint32_t vk_slots_per_input(const vk_transform_spec *t);

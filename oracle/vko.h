@@ -79,6 +79,12 @@ int vko_transform_label(const vko_spec *spec, uint64_t seed, uint32_t sub_index,
 /* Transform::name() */
 const char *vko_transform_name(const vko_spec *spec);
 
+/* Electrum v1 (src/electrum.rs, src/transform/electrum.rs); rounds = 100000 in the reference */
+void vko_electrum_stretch(const uint8_t *seed, size_t len, uint32_t rounds, uint8_t out[32]);
+int vko_electrum_keys(const uint8_t *seed, size_t len, uint32_t for_change, uint32_t count, uint32_t rounds,
+                      uint8_t *keys, uint8_t *valid, uint8_t mpk_out[64]);
+int vko_electrum_label(const char *seed, uint32_t for_change, uint32_t index, char *out, size_t cap);
+
 /* ------------------------------------------------------- secp256k1/derive */
 /* src/derive.rs:79-93: valid iff 1 <= k < n, else k mod n, 0 -> 1. */
 void vko_normalize_key(const uint8_t in[32], uint8_t out[32]);

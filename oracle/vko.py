@@ -95,6 +95,9 @@ def lib():
         L.vko_base58check_decode.argtypes = [cp, cp, sz]
         L.vko_segwit_encode.argtypes = [cp, C.c_int, cp, sz, cp, sz]
         L.vko_segwit_decode.argtypes = [cp, cp, C.POINTER(C.c_int), cp, C.POINTER(sz)]
+        L.vko_electrum_stretch.argtypes = [cp, sz, u32, cp]
+        L.vko_electrum_keys.argtypes = [cp, sz, u32, u32, u32, cp, cp, cp]
+        L.vko_electrum_label.argtypes = [cp, u32, u32, cp, sz]
         _ = (u8p, u64)
         _lib = L
     return _lib
@@ -174,6 +177,26 @@ def transform_apply(sp, seed):
         if k is not None:
             out.append((transform_label(sp, seed, sub), k))
     return out
+
+
+def electrum_stretch(seed, rounds=100000):
+    o = _out(32)
+    lib().vko_electrum_stretch(seed, len(seed), rounds, o)
+    return o.raw
+
+
+def electrum_keys(seed, for_change=False, count=20, rounds=100000):
+    """ElectrumTransform::apply_batch for one string input: (mpk or None, [(label, key)])."""
+    keys, valid, mpk = _out(32 * count), _out(count), _out(64)
+    if not lib().vko_electrum_keys(seed, len(seed), 1 if for_change else 0, count, rounds, keys, valid, mpk):
+        return None, []
+    out = []
+    for i in range(count):
+        if valid.raw[i]:
+            lab = _out(160)
+            lib().vko_electrum_label(seed, 1 if for_change else 0, i, lab, 160)
+            out.append((lab.value.decode(), keys.raw[32 * i:32 * i + 32]))
+    return mpk.raw, out
 
 
 def normalize_key(k): o = _out(32); lib().vko_normalize_key(k, o); return o.raw

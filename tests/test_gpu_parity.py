@@ -299,3 +299,38 @@ def test_signed_nine_window_layout(eng, vko):
     b, _ = eng.sweep(ffi.spec(ffi.T_XORSHIFT), 7 * 10**9, 7 * 10**9 + 2**21 - 1, flags=3)
     assert a["digest"] == b["digest"] and a["keys"] == b["keys"] == 4 * 2**21
     e.close()
+
+
+def test_electrum_strings_and_scan_keys(eng, vko):
+    """Electrum v1 chain (100 000-round stretch, mpk, sequence, child keys) on the device."""
+    from vuke_amd import _ffi as ffi
+    rnd = random.Random(41)
+    seeds = [b"acb740e454c3134901d7c8f16497cc1c", b"", b"0", b"7", b"12345678901234567890", b"not_valid_hex!", b"ABCDEF", b"abcdeg",
+             b"f" * 23, b"f" * 24, b"0bbe2537d7527f2d7376d4bb9de8ac42ca202dbae310471b88f2cbb0492e6e73"]
+    seeds += [("%032x" % rnd.getrandbits(128)).encode() for _ in range(40)] + [str(rnd.getrandbits(40)).encode() for _ in range(10)]
+    for change in (0, 1):
+        spec = ffi.spec(ffi.T_ELECTRUM, change, 0, 20)
+        got = eng.transform_strings(spec, seeds)
+        for s, row in zip(seeds, got):
+            _, exp = vko.electrum_keys(s, for_change=bool(change))
+            assert [k for k in row if k is not None] == [k for _, k in exp], (s, change)
+    # reference vectors through the device (src/electrum.rs:218-221)
+    row = eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), [seeds[0]])[0]
+    _, _, hu = eng.derive_batch([row[0]])
+    assert pyref.b58check(b"\0" + hu[0]) == "1FJEEB8ihPMbzs2SkLmr37dHyRFzakqUmo"
+    row = eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 1, 0, 3), [seeds[0]])[0]
+    _, _, hu = eng.derive_batch([row[0]])
+    assert pyref.b58check(b"\0" + hu[0]) == "1KRW8pH6HFHZh889VDq6fEKvmrsmApwNfe"
+    # scan_keys: derive + probe over caller-held keys, hit.index = position
+    keys = [k for r in eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), seeds[:6]) for k in r if k is not None]
+    d5, d17 = vko.derive(keys[5]), vko.derive(keys[17])
+    eng.targets_set([bytes(d5.h160_u), bytes(d17.h160_c)], [ffi.TARGET_P2PKH, ffi.TARGET_P2WPKH])
+    st, hits = eng.scan_keys(keys)
+    eng.targets_set([], [])
+    assert (st["inputs"], st["keys"], st["matches"]) == (len(keys), len(keys), 2)
+    assert [(h["index"], h["addr_kind"]) for h in hits] == [(5, 1), (17, 2)] and hits[0]["privkey"] == keys[5]
+    import vuke_amd
+    with pytest.raises(vuke_amd.VkError):
+        eng.sweep(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), 0, 10)          # string transform: not a range sweep
+    with pytest.raises(vuke_amd.VkError):
+        eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), [b"a" * 65])

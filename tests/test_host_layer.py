@@ -65,6 +65,8 @@ def test_transform_grammar_reference_cases(host):
     assert parse(host, "sha256_chain:iterated:le")[1].startswith("Invalid SHA256 chain format")
     assert parse(host, "nothing")[1].startswith("Unknown transform: nothing. Valid: direct, sha256,")
     assert parse(host, "md5")[0] is None and "outside the device hot path" in parse(host, "md5")[1]
+    assert parse(host, "electrum") == ((6, 0, 0, 20), "electrum")                 # src/transform/mod.rs:180-181
+    assert parse(host, "electrum:change") == ((6, 1, 0, 20), "electrum:change")
 
 
 def test_labels_match_oracle(host, vko):

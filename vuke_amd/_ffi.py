@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvuke_hip.so")
 
 VK_OK = 0
 VK_E_NO_DEVICE, VK_E_HIP, VK_E_INVALID_ARG, VK_E_UNSUPPORTED, VK_E_NOMEM = -1, -2, -3, -4, -5
-T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN = range(6)
+T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM = range(7)
 VARIANT_ALL = 0xFFFFFFFF
 F_COMPRESSED, F_UNCOMPRESSED = 1, 2
 ADDR_P2PKH_C, ADDR_P2PKH_U, ADDR_P2WPKH = 0, 1, 2
@@ -48,6 +48,7 @@ class EngineInfo(C.Structure):
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
     "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_transform_batch",
+    "vk_transform_strings", "vk_scan_keys",
     "vk_slots_per_input", "vk_debug_table_entry", "vk_debug_field",
 ]
 
@@ -77,6 +78,8 @@ def load():
     L.vk_generate.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, vp, vp, vp, vp, C.POINTER(SweepStats)]
     L.vk_derive_batch.argtypes = [vp, cp, sz, vp, vp, vp]
     L.vk_transform_batch.argtypes = [vp, C.POINTER(TransformSpec), C.POINTER(u64), sz, vp, vp]
+    L.vk_transform_strings.argtypes = [vp, C.POINTER(TransformSpec), cp, C.POINTER(u32), sz, vp, vp]
+    L.vk_scan_keys.argtypes = [vp, cp, sz, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_slots_per_input.argtypes = [C.POINTER(TransformSpec)]
     L.vk_slots_per_input.restype = u32
     L.vk_debug_table_entry.argtypes = [vp, u32, u32, vp]
@@ -166,6 +169,27 @@ class Engine:
             out.append([(keys.raw[32 * (i * slots + s):32 * (i * slots + s) + 32] if valid.raw[i * slots + s] else None)
                         for s in range(slots)])
         return out
+
+    def transform_strings(self, spec, strings):
+        """Transform::apply_batch for string inputs: per input a list of keys (None where nothing is emitted)."""
+        n = len(strings)
+        slots = self._L.vk_slots_per_input(C.byref(spec))
+        offs = (C.c_uint32 * (n + 1))()
+        for i, s in enumerate(strings):
+            offs[i + 1] = offs[i] + len(s)
+        keys, valid = C.create_string_buffer(max(1, n * slots * 32)), C.create_string_buffer(max(1, n * slots))
+        self._chk(self._L.vk_transform_strings(self._e, C.byref(spec), b"".join(strings), offs, n, keys, valid))
+        return [[(keys.raw[32 * (i * slots + s):32 * (i * slots + s) + 32] if valid.raw[i * slots + s] else None) for s in range(slots)]
+                for i in range(n)]
+
+    def scan_keys(self, keys, flags=F_COMPRESSED | F_UNCOMPRESSED, hit_cap=4096):
+        hits = (Hit * max(hit_cap, 1))()
+        st = SweepStats()
+        self._chk(self._L.vk_scan_keys(self._e, b"".join(keys), len(keys), flags, hits, hit_cap, C.byref(st)))
+        n = min(st.matches, hit_cap)
+        hl = sorted((dict(index=h.seed, addr_kind=h.addr_kind, privkey=bytes(h.privkey), h160=bytes(h.h160)) for h in hits[:n]),
+                    key=lambda h: h["index"])
+        return dict(inputs=st.inputs, keys=st.keys, matches=st.matches, digest=tuple(st.digest)), hl
 
     def table_entry(self, window, digit):
         xy = C.create_string_buffer(64)

@@ -4,6 +4,7 @@
 // linked into this library).
 #include "../../include/vuke_hip.h"
 #include "vk_kernels.cuh"
+#include "vk_electrum.cuh"
 
 #include <algorithm>
 #include <cstdio>
@@ -27,6 +28,7 @@ struct vk_engine {
     u32 layout = 0;        // 0 uniform unsigned W-bit windows, 1 nine signed windows (VK_LAYOUT_SIGNED9)
     vk_win_desc wins[VK_MAX_WIN];
     u64 table_entries = 0;
+    vk_win_desc *d_wins = nullptr; // device copy of wins (kernels that take the layout by pointer)
     double table_build_seconds = 0.0;
     u32 batch = 32;
     u32 blocks_per_cu = 0;
@@ -85,14 +87,20 @@ extern "C" uint32_t vk_slots_per_input(const vk_transform_spec *t)
         if (t->variant != VK_VARIANT_ALL && t->variant > 3) return 0;
         if (t->chain_depth == 0 || t->chain_depth > 4096) return 0;
         return 2u * (t->variant == VK_VARIANT_ALL ? 4u : 1u) * t->chain_depth;
+    case VK_T_ELECTRUM:
+        if (t->variant > 1 || t->chain_depth == 0 || t->chain_depth > 1000) return 0;
+        return t->chain_depth;
     default: return 0;
     }
 }
 
-static int validate_spec(vk_engine *e, const vk_transform_spec *t)
+static int validate_spec(vk_engine *e, const vk_transform_spec *t, bool strings = false)
 {
     if (!t) return fail(e, VK_E_INVALID_ARG, "transform spec is NULL");
     if (vk_slots_per_input(t) == 0) return fail(e, VK_E_INVALID_ARG, "invalid transform spec (kind / variant / chain_depth)");
+    if (!strings && t->kind == VK_T_ELECTRUM)
+        return fail(e, VK_E_UNSUPPORTED, "electrum takes string inputs: use vk_transform_strings + vk_scan_keys");
+    if (strings && t->kind != VK_T_ELECTRUM) return fail(e, VK_E_UNSUPPORTED, "only electrum is built for string inputs");
     if (t->kind == VK_T_LCG && t->endian > 1) return fail(e, VK_E_INVALID_ARG, "lcg endian must be 0 (big) or 1 (little)");
     return VK_OK;
 }
@@ -109,6 +117,7 @@ extern "C" void vk_engine_destroy(vk_engine *e)
     if (e->d_hits) (void)hipFree(e->d_hits);
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->work) (void)hipFree(e->work);
+    if (e->d_wins) (void)hipFree(e->d_wins);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -187,6 +196,8 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
         HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vk_sweep_kernel<VK_T_MILKSAD>, VK_BLOCK, 0));
         e->blocks_per_cu = (u32)std::max(1, std::min(occ, 4));
     }
+    HIPCHK(e, hipMalloc(&e->d_wins, sizeof e->wins));
+    HIPCHK(e, hipMemcpy(e->d_wins, e->wins, sizeof e->wins, hipMemcpyHostToDevice));
     // the k*G table: affine points (64 B each), built on the device window by window in two phases
     HIPCHK(e, hipMalloc(&e->table, e->table_entries * 64));
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
@@ -629,6 +640,83 @@ extern "C" int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, cons
         e->err = std::string("vk_transform_batch: ") + hipGetErrorString(c);
         return VK_E_HIP;
     }
+    return VK_OK;
+}
+
+extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
+                                    uint8_t *keys_out, uint8_t *valid)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int rc = validate_spec(e, t, true);
+    if (rc) return rc;
+    if (n == 0) return VK_OK;
+    if (!data || !offsets || !keys_out || !valid) return fail(e, VK_E_INVALID_ARG, "data / offsets / keys_out / valid is NULL");
+    const u32 slots = vk_slots_per_input(t);
+    if ((u64)n * slots > (1ull << 28)) return fail(e, VK_E_INVALID_ARG, "too many keys for one vk_transform_strings call (max 2^28)");
+    for (size_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(e, VK_E_INVALID_ARG, "offsets must be non-decreasing");
+        if (offsets[i + 1] - offsets[i] > VK_ELECTRUM_MAX_SEED) return fail(e, VK_E_UNSUPPORTED, "string longer than 64 bytes");
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t bytes = offsets[n], items = n * slots;
+    unsigned char *d_data = nullptr, *d_valid = nullptr;
+    u32 *d_offs = nullptr, *d_keys = nullptr;
+    hipError_t c = hipMalloc(&d_data, bytes ? bytes : 1);
+    if (c == hipSuccess) c = hipMalloc(&d_offs, (n + 1) * 4);
+    if (c == hipSuccess) c = hipMalloc(&d_keys, items * 32);
+    if (c == hipSuccess) c = hipMalloc(&d_valid, items);
+    if (c == hipSuccess && bytes) c = hipMemcpy(d_data, data, bytes, hipMemcpyHostToDevice);
+    if (c == hipSuccess) c = hipMemcpy(d_offs, offsets, (n + 1) * 4, hipMemcpyHostToDevice);
+    if (c == hipSuccess) c = hipMemsetAsync(d_keys, 0, items * 32, e->stream);
+    if (c == hipSuccess) c = hipMemsetAsync(d_valid, 0, items, e->stream);
+    if (c == hipSuccess) {
+        hipLaunchKernelGGL(vk_electrum_kernel, dim3((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_data, d_offs, (u64)n,
+                           t->variant, t->chain_depth, 100000u, e->table, e->d_wins, e->nwin, d_keys, d_valid);
+        c = hipGetLastError();
+    }
+    if (c == hipSuccess) c = hipStreamSynchronize(e->stream);
+    if (c == hipSuccess) c = hipMemcpy(keys_out, d_keys, items * 32, hipMemcpyDeviceToHost);
+    if (c == hipSuccess) c = hipMemcpy(valid, d_valid, items, hipMemcpyDeviceToHost);
+    (void)hipFree(d_data);
+    (void)hipFree(d_offs);
+    (void)hipFree(d_keys);
+    (void)hipFree(d_valid);
+    if (c != hipSuccess) {
+        e->err = std::string("vk_transform_strings: ") + hipGetErrorString(c);
+        return VK_E_HIP;
+    }
+    return VK_OK;
+}
+
+extern "C" int vk_scan_keys(vk_engine *e, const uint8_t *keys, size_t n, uint32_t flags, vk_hit *hits, size_t hit_cap, vk_sweep_stats *out)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!out) return fail(e, VK_E_INVALID_ARG, "stats out pointer is NULL");
+    if (!(flags & (VK_F_COMPRESSED | VK_F_UNCOMPRESSED)) || (flags & ~(VK_F_COMPRESSED | VK_F_UNCOMPRESSED)))
+        return fail(e, VK_E_INVALID_ARG, "flags must be a non-empty subset of VK_F_COMPRESSED | VK_F_UNCOMPRESSED");
+    memset(out, 0, sizeof *out);
+    if (n == 0) return VK_OK;
+    if (!keys) return fail(e, VK_E_INVALID_ARG, "keys is NULL");
+    HIPCHK(e, hipSetDevice(e->device));
+    u32 *d_in = nullptr;
+    HIPCHK(e, hipMalloc(&d_in, n * 32));
+    hipError_t c = hipMemcpy(d_in, keys, n * 32, hipMemcpyHostToDevice);
+    int rc = VK_OK;
+    if (c != hipSuccess) rc = fail(e, VK_E_HIP, "hipMemcpy H2D failed in vk_scan_keys");
+    if (rc == VK_OK) {
+        launch_io io;
+        io.in_keys = d_in;
+        io.hits = hits;
+        io.hit_cap = hits ? hit_cap : 0;
+        vk_spec_dev spec = {VK_T_RAWKEYS, 0, 0, 0};
+        rc = run_range(e, spec, VK_T_RAWKEYS, 1, 0, n - 1, flags, io, out);
+    }
+    (void)hipFree(d_in);
+    if (rc) return rc;
+    out->inputs = n;
+    out->hits_dropped = out->matches > (hits ? hit_cap : 0) ? out->matches - (hits ? hit_cap : 0) : 0;
     return VK_OK;
 }
 

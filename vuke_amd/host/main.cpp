@@ -19,7 +19,8 @@ static int usage(const char *msg)
 {
     if (msg) fprintf(stderr, "error: %s\n\n", msg);
     fprintf(stderr, "Usage: vuke-hip <generate|scan|single> [OPTIONS] range --start <START> --end <END>\n"
-                    "  --transform <T>...   sha256 | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] | sha256_chain[:variant]\n"
+                    "  --transform <T>...   sha256 | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] | sha256_chain[:variant] | electrum[:change]\n"
+                    "  sources: range --start A --end B | wordlist --file F (string transforms: electrum[:change])\n"
                     "  --targets <FILE>     (scan) one address per line\n"
                     "  -v, --verbose        (generate) all key formats\n"
                     "  -o, --output <FILE>  write to FILE instead of stdout\n"
@@ -46,7 +47,8 @@ int main(int argc, char **argv)
     if (cmd != "generate" && cmd != "scan" && cmd != "single") return usage("unknown subcommand");
     std::vector<std::string> tnames;
     std::string targets, outpath, single_value;
-    bool verbose = false, have_range = false, have_start = false, have_end = false;
+    bool verbose = false, have_range = false, have_start = false, have_end = false, have_wordlist = false;
+    std::string wordlist_file;
     uint64_t start = 0, end = 0;
     int device = 0;
     unsigned window_bits = 0, layout = VK_LAYOUT_UNIFORM;
@@ -68,6 +70,8 @@ int main(int argc, char **argv)
             else if (a == "--window-bits") window_bits = (unsigned)atoi(need("--window-bits"));
             else if (a == "--layout") layout = std::string(need("--layout")) == "signed9" ? VK_LAYOUT_SIGNED9 : VK_LAYOUT_UNIFORM;
             else if (a == "range") have_range = true;
+            else if (a == "wordlist") have_wordlist = true;
+            else if (a == "--file") wordlist_file = need("--file");
             else if (a == "--start") { start = parse_u64(need("--start")); have_start = true; }
             else if (a == "--end") { end = parse_u64(need("--end")); have_end = true; }
             else if (cmd == "single" && single_value.empty() && a[0] != '-') single_value = a;
@@ -78,8 +82,10 @@ int main(int argc, char **argv)
         std::vector<Transform> transforms;
         for (auto &n : tnames) transforms.push_back(TransformType::from_str(n));
         if (cmd == "scan" && targets.empty()) throw std::invalid_argument("the following required arguments were not provided: --targets <TARGETS>");
-        if (cmd != "single" && (!have_range || !have_start || !have_end)) throw std::invalid_argument("only the `range --start A --end B` source is on the device path");
-        if (cmd != "single" && end < start) throw std::invalid_argument("--end must be >= --start");
+        if (cmd != "single" && have_wordlist && wordlist_file.empty()) throw std::invalid_argument("wordlist needs --file <FILE>");
+        if (cmd != "single" && !have_wordlist && (!have_range || !have_start || !have_end))
+            throw std::invalid_argument("sources on the device path: `range --start A --end B` and `wordlist --file F`");
+        if (cmd != "single" && have_range && end < start) throw std::invalid_argument("--end must be >= --start");
 
         vk_engine *engine = nullptr;
         vk_engine_opts opts{};
@@ -98,7 +104,7 @@ int main(int argc, char **argv)
             KeyDeriver deriver(engine);
             for (const Transform &t : transforms) {
                 std::vector<std::pair<std::string, Key>> out;
-                t.apply_batch(engine, {v}, out);
+                t.apply_batch(engine, std::vector<uint64_t>{v}, out);
                 for (auto &[label, key] : out) {
                     DerivedKey d = deriver.derive(key);
                     printf("Passphrase: \"%s\"\nTransform: %s\nSource: %s\n---\nPrivate Key (hex): %s\nPrivate Key (decimal): %s\n"
@@ -116,7 +122,10 @@ int main(int argc, char **argv)
         if (!outpath.empty()) out = ConsoleOutput::to_file(outpath, verbose);
         else if (verbose) out = ConsoleOutput::verbose();
         else out = std::make_unique<ConsoleOutput>();
-        HipRangeSource source(engine, start, end);
+        std::unique_ptr<Source> source_ptr;
+        if (have_wordlist) source_ptr = std::make_unique<HipWordlistSource>(engine, wordlist_file);
+        else source_ptr = std::make_unique<HipRangeSource>(engine, start, end);
+        Source &source = *source_ptr;
         ProcessStats stats;
         if (cmd == "scan") {
             fprintf(stderr, "Loading targets from \"%s\"...\n", targets.c_str());

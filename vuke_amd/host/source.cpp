@@ -7,8 +7,78 @@
 
 #include <algorithm>
 #include <cstring>
+#include <fstream>
 
 namespace vuke {
+
+// shared by the string-capable paths: keys (with labels) -> derive on the device -> match / emit
+static void emit_keys(vk_engine *engine, const Transform &t, const std::vector<std::pair<std::string, Key>> &batch, const Matcher *matcher,
+                      Output &output, ProcessStats &st)
+{
+    if (batch.empty()) return;
+    st.keys_generated += batch.size();
+    std::vector<Key> keys;
+    for (auto &lk : batch) keys.push_back(lk.second);
+    KeyDeriver deriver(engine);
+    if (matcher) {
+        std::vector<uint8_t> flat(keys.size() * 32);
+        for (size_t i = 0; i < keys.size(); i++) memcpy(&flat[32 * i], keys[i].data(), 32);
+        std::vector<vk_hit> hits(keys.size());
+        vk_sweep_stats ss;
+        check_rc(engine, vk_scan_keys(engine, flat.data(), keys.size(), VK_F_COMPRESSED | VK_F_UNCOMPRESSED, hits.data(), hits.size(), &ss));
+        hits.resize((size_t)ss.matches);
+        std::sort(hits.begin(), hits.end(), [](const vk_hit &a, const vk_hit &b) { return a.seed < b.seed; });
+        st.matches_found += ss.matches;
+        std::vector<Key> hk;
+        for (auto &h : hits) hk.push_back(keys[(size_t)h.seed]);
+        std::vector<DerivedKey> derived = deriver.derive(hk);
+        for (size_t i = 0; i < hits.size(); i++) {
+            MatchInfo mi;
+            mi.address_type = hits[i].addr_kind == VK_ADDR_P2PKH_C   ? AddressType::P2pkhCompressed
+                              : hits[i].addr_kind == VK_ADDR_P2PKH_U ? AddressType::P2pkhUncompressed
+                                                                     : AddressType::P2wpkh;
+            mi.address = *derived[i].addresses()[hits[i].addr_kind];
+            output.hit(batch[(size_t)hits[i].seed].first, t.name(), derived[i], mi);
+        }
+    } else {
+        std::vector<DerivedKey> derived = deriver.derive(keys);
+        for (size_t i = 0; i < keys.size(); i++) output.key(batch[i].first, t.name(), derived[i]);
+    }
+}
+
+ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output)
+{
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("cannot open wordlist: " + path);
+    for (const Transform &t : transforms)
+        if (!t.takes_strings()) throw std::invalid_argument(std::string("transform '") + t.name() + "' is not built for string inputs on the device path");
+    ProcessStats st;
+    if (matcher) {
+        std::vector<uint8_t> h160, kind;
+        matcher->device_targets(h160, kind);
+        check_rc(engine_, vk_targets_set(engine_, h160.data(), kind.data(), kind.size()));
+    }
+    std::vector<std::string> lines;
+    auto flush = [&]() {
+        for (const Transform &t : transforms) {
+            std::vector<std::pair<std::string, Key>> batch;
+            t.apply_batch(engine_, lines, batch);
+            emit_keys(engine_, t, batch, matcher, output, st);
+        }
+        st.inputs_processed += lines.size();
+        lines.clear();
+    };
+    std::string line;
+    while (std::getline(f, line)) { // src/source/wordlist.rs: lines are taken as they are, empty ones skipped
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        lines.push_back(line);
+        if (lines.size() == 262144) flush(); // enough lanes to fill the chip (256 CUs x 1024)
+    }
+    if (!lines.empty()) flush();
+    if (matcher) check_rc(engine_, vk_targets_set(engine_, nullptr, nullptr, 0));
+    return st;
+}
 
 ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output)
 {
@@ -25,6 +95,18 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
         for (uint64_t lo = start;; lo += block) {
             const uint64_t hi = (end - lo < block - 1) ? end : lo + block - 1;
             for (const Transform &t : transforms) {
+                if (t.takes_strings()) { // e.g. electrum over a numeric range: the decimal string is the seed
+                    for (uint64_t a = lo;; a += 16384) {
+                        const uint64_t b = (hi - a < 16383) ? hi : a + 16383;
+                        std::vector<uint64_t> inputs;
+                        for (uint64_t v = a;; v++) { inputs.push_back(v); if (v == b) break; }
+                        std::vector<std::pair<std::string, Key>> batch;
+                        t.apply_batch(engine_, inputs, batch);
+                        emit_keys(engine_, t, batch, matcher, output, st);
+                        if (b == hi) break;
+                    }
+                    continue;
+                }
                 std::vector<vk_hit> hits(1 << 16);
                 vk_sweep_stats ss;
                 for (;;) {
@@ -60,6 +142,14 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
         for (uint64_t lo = start;; lo += chunk) {
             const uint64_t hi = (end - lo < chunk - 1) ? end : lo + chunk - 1;
             for (const Transform &t : transforms) {
+                if (t.takes_strings()) {
+                    std::vector<uint64_t> inputs;
+                    for (uint64_t v = lo;; v++) { inputs.push_back(v); if (v == hi) break; }
+                    std::vector<std::pair<std::string, Key>> batch;
+                    t.apply_batch(engine_, inputs, batch);
+                    emit_keys(engine_, t, batch, nullptr, output, st);
+                    continue;
+                }
                 const uint32_t k = t.slots();
                 const size_t n = (size_t)(hi - lo + 1) * k;
                 std::vector<uint8_t> priv(n * 32), hc(n * 20), hu(n * 20), valid(n);

@@ -62,7 +62,13 @@ Transform TransformType::from_str(const std::string &raw)
     if (s == "sha256") { sp.kind = VK_T_SHA256; return Transform(sp); }
     if (s == "milksad") { sp.kind = VK_T_MILKSAD; return Transform(sp); }
     if (s == "mt64") { sp.kind = VK_T_MT64; return Transform(sp); }
-    for (const char *n : {"direct", "double_sha256", "md5", "armory", "multibit", "electrum", "electrum:change", "bitimage"})
+    if (s == "electrum" || s == "electrum:change") { // src/transform/mod.rs:180-181; 20 indices (src/transform/electrum.rs:12)
+        sp.kind = VK_T_ELECTRUM;
+        sp.variant = s == "electrum" ? 0u : 1u;
+        sp.chain_depth = 20;
+        return Transform(sp);
+    }
+    for (const char *n : {"direct", "double_sha256", "md5", "armory", "multibit", "bitimage"})
         if (s == n) return unsupported(n);
     if (s == "lcg" || s.rfind("lcg:", 0) == 0) { // LcgConfig::parse
         auto parts = split_colon(s);
@@ -135,6 +141,7 @@ const char *Transform::name() const
     case VK_T_MT64: return "mt64";
     case VK_T_LCG: return "lcg";
     case VK_T_XORSHIFT: return "xorshift";
+    case VK_T_ELECTRUM: return spec_.variant ? "electrum:change" : "electrum"; // src/transform/electrum.rs:36-42
     case VK_T_SHA256_CHAIN: // src/transform/sha256_chain.rs:46-58
         switch (spec_.variant) {
         case 0: return "sha256_chain:iterated";
@@ -167,8 +174,49 @@ std::string Transform::label(uint64_t seed, uint32_t sub) const
     }
 }
 
+std::string Transform::label(const std::string &input, uint32_t sub) const
+{
+    if (spec_.kind == VK_T_ELECTRUM) { // "{truncate_seed(seed)}[{chain}/{i}]", src/transform/electrum.rs:58-62, src/electrum.rs:199-211
+        std::string shown = input;
+        if (input.size() > 20) shown = input.substr(0, 8) + "..." + input.substr(input.size() - 8); // hex seeds are ASCII
+        return shown + "[" + (spec_.variant ? "1" : "0") + "/" + std::to_string(sub) + "]";
+    }
+    return input;
+}
+
+void Transform::apply_batch(vk_engine *e, const std::vector<std::string> &inputs, std::vector<std::pair<std::string, Key>> &output) const
+{
+    const uint32_t k = slots();
+    if (inputs.empty() || k == 0) return;
+    // strings the device entry point cannot take (longer than 64 bytes) can still be valid hex seeds in the
+    // reference; they are reported, not silently dropped
+    std::vector<uint8_t> data;
+    std::vector<uint32_t> offs{0};
+    for (const std::string &s : inputs) {
+        if (s.size() > 64) throw std::invalid_argument("electrum seed longer than 64 characters is not supported on the device path");
+        data.insert(data.end(), s.begin(), s.end());
+        offs.push_back((uint32_t)data.size());
+    }
+    std::vector<uint8_t> keys(inputs.size() * k * 32), valid(inputs.size() * k);
+    check_rc(e, vk_transform_strings(e, &spec_, data.data(), offs.data(), inputs.size(), keys.data(), valid.data()));
+    for (size_t i = 0; i < inputs.size(); i++)
+        for (uint32_t s = 0; s < k; s++) {
+            const size_t idx = i * k + s;
+            if (!valid[idx]) continue;
+            Key key;
+            std::copy(keys.begin() + 32 * idx, keys.begin() + 32 * idx + 32, key.begin());
+            output.emplace_back(label(inputs[i], s), key);
+        }
+}
+
 void Transform::apply_batch(vk_engine *e, const std::vector<uint64_t> &inputs, std::vector<std::pair<std::string, Key>> &output) const
 {
+    if (takes_strings()) { // numeric sources hand string transforms the decimal string (Input::from_u64)
+        std::vector<std::string> strs;
+        for (uint64_t v : inputs) strs.push_back(std::to_string(v));
+        apply_batch(e, strs, output);
+        return;
+    }
     const uint32_t k = slots();
     if (inputs.empty() || k == 0) return;
     std::vector<uint8_t> keys(inputs.size() * k * 32), valid(inputs.size() * k);

@@ -95,6 +95,10 @@ public:
     const vk_transform_spec &spec() const { return spec_; }
     uint32_t slots() const { return vk_slots_per_input(&spec_); }
     std::string label(uint64_t seed, uint32_t sub) const;  // the `source` string apply_batch pushes
+    std::string label(const std::string &input, uint32_t sub) const; // same for Input::from_string inputs
+    bool takes_strings() const { return spec_.kind == VK_T_ELECTRUM; }
+    // apply_batch for string inputs (wordlist / stdin sources), on the device
+    void apply_batch(vk_engine *e, const std::vector<std::string> &inputs, std::vector<std::pair<std::string, Key>> &output) const;
     bool supports_gpu() const { return true; }
     // apply_batch for numeric inputs, on the device: appends (label, key) in the reference's order
     void apply_batch(vk_engine *e, const std::vector<uint64_t> &inputs, std::vector<std::pair<std::string, Key>> &output) const;
@@ -154,6 +158,18 @@ public:
     HipRangeSource(vk_engine *engine, uint64_t start, uint64_t end) : start(start), end(end), engine_(engine) {}
     ProcessStats process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output) override;
     uint64_t start, end;
+
+private:
+    vk_engine *engine_;
+};
+
+// WordlistSource on the GPU (src/source/wordlist.rs): one passphrase per line, Input::from_string.
+// Built for the string-input transforms of the device path (electrum).
+class HipWordlistSource : public Source {
+public:
+    HipWordlistSource(vk_engine *engine, std::string path) : path(std::move(path)), engine_(engine) {}
+    ProcessStats process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output) override;
+    std::string path;
 
 private:
     vk_engine *engine_;
