@@ -155,8 +155,9 @@ class Engine:
         n = len(keys)
         norm, hc, hu = C.create_string_buffer(n * 32), C.create_string_buffer(n * 20), C.create_string_buffer(n * 20)
         self._chk(self._L.vk_derive_batch(self._e, b"".join(keys), n, norm, hc, hu))
-        return ([norm.raw[32 * i:32 * i + 32] for i in range(n)], [hc.raw[20 * i:20 * i + 20] for i in range(n)],
-                [hu.raw[20 * i:20 * i + 20] for i in range(n)])
+        rn, rc, ru = norm.raw, hc.raw, hu.raw  # .raw copies the whole buffer: take it once
+        return ([rn[32 * i:32 * i + 32] for i in range(n)], [rc[20 * i:20 * i + 20] for i in range(n)],
+                [ru[20 * i:20 * i + 20] for i in range(n)])
 
     def transform_batch(self, spec, seeds):
         n = len(seeds)
@@ -164,11 +165,9 @@ class Engine:
         arr = (C.c_uint64 * n)(*seeds)
         keys, valid = C.create_string_buffer(n * slots * 32), C.create_string_buffer(n * slots)
         self._chk(self._L.vk_transform_batch(self._e, C.byref(spec), arr, n, keys, valid))
-        out = []
-        for i in range(n):
-            out.append([(keys.raw[32 * (i * slots + s):32 * (i * slots + s) + 32] if valid.raw[i * slots + s] else None)
-                        for s in range(slots)])
-        return out
+        rk, rv = keys.raw, valid.raw
+        return [[(rk[32 * (i * slots + s):32 * (i * slots + s) + 32] if rv[i * slots + s] else None) for s in range(slots)]
+                for i in range(n)]
 
     def transform_strings(self, spec, strings):
         """Transform::apply_batch for string inputs: per input a list of keys (None where nothing is emitted)."""
@@ -179,7 +178,8 @@ class Engine:
             offs[i + 1] = offs[i] + len(s)
         keys, valid = C.create_string_buffer(max(1, n * slots * 32)), C.create_string_buffer(max(1, n * slots))
         self._chk(self._L.vk_transform_strings(self._e, C.byref(spec), b"".join(strings), offs, n, keys, valid))
-        return [[(keys.raw[32 * (i * slots + s):32 * (i * slots + s) + 32] if valid.raw[i * slots + s] else None) for s in range(slots)]
+        rk, rv = keys.raw, valid.raw
+        return [[(rk[32 * (i * slots + s):32 * (i * slots + s) + 32] if rv[i * slots + s] else None) for s in range(slots)]
                 for i in range(n)]
 
     def scan_keys(self, keys, flags=F_COMPRESSED | F_UNCOMPRESSED, hit_cap=4096):
@@ -200,7 +200,8 @@ class Engine:
         n = len(a_list)
         out = C.create_string_buffer(n * 32)
         self._chk(self._L.vk_debug_field(self._e, op, b"".join(a_list), b"".join(b_list) if b_list else None, n, out))
-        return [out.raw[32 * i:32 * i + 32] for i in range(n)]
+        ro = out.raw
+        return [ro[32 * i:32 * i + 32] for i in range(n)]
 
 
 def spec(kind, variant=VARIANT_ALL, endian=0, chain_depth=10):
