@@ -85,6 +85,12 @@ int vko_electrum_keys(const uint8_t *seed, size_t len, uint32_t for_change, uint
                       uint8_t *keys, uint8_t *valid, uint8_t mpk_out[64]);
 int vko_electrum_label(const char *seed, uint32_t for_change, uint32_t index, char *out, size_t cap);
 
+/* MultiBit HD seed-as-entropy chain (src/multibit.rs, src/transform/multibit.rs); wl = 2048 words, caller-supplied */
+size_t vko_multibit_buggy_mnemonic(const char *const *wl, const uint8_t seed[64], char *out, size_t cap);
+int vko_multibit_keys(const char *const *wl, const uint8_t *mnemonic, size_t len, uint32_t count, uint8_t *keys, uint8_t *valid,
+                      uint8_t seed1_out[64], uint8_t seed2_out[64]);
+int vko_multibit_label(const char *mnemonic, uint32_t index, char *out, size_t cap);
+
 /* ------------------------------------------------------- secp256k1/derive */
 /* src/derive.rs:79-93: valid iff 1 <= k < n, else k mod n, 0 -> 1. */
 void vko_normalize_key(const uint8_t in[32], uint8_t out[32]);

@@ -98,6 +98,10 @@ def lib():
         L.vko_electrum_stretch.argtypes = [cp, sz, u32, cp]
         L.vko_electrum_keys.argtypes = [cp, sz, u32, u32, u32, cp, cp, cp]
         L.vko_electrum_label.argtypes = [cp, u32, u32, cp, sz]
+        L.vko_multibit_buggy_mnemonic.argtypes = [C.POINTER(cp), cp, cp, sz]
+        L.vko_multibit_buggy_mnemonic.restype = sz
+        L.vko_multibit_keys.argtypes = [C.POINTER(cp), cp, sz, u32, cp, cp, cp, cp]
+        L.vko_multibit_label.argtypes = [cp, u32, cp, sz]
         _ = (u8p, u64)
         _lib = L
     return _lib
@@ -197,6 +201,36 @@ def electrum_keys(seed, for_change=False, count=20, rounds=100000):
             lib().vko_electrum_label(seed, 1 if for_change else 0, i, lab, 160)
             out.append((lab.value.decode(), keys.raw[32 * i:32 * i + 32]))
     return mpk.raw, out
+
+
+class Wordlist:
+    """A caller-supplied 2048-word BIP-39 list in the form the oracle takes."""
+
+    def __init__(self, words):
+        assert len(words) == 2048
+        self.words = [w.encode() if isinstance(w, str) else w for w in words]
+        self.arr = (C.c_char_p * 2048)(*self.words)
+
+
+def multibit_buggy_mnemonic(wl, seed64):
+    o = _out(600)
+    n = lib().vko_multibit_buggy_mnemonic(wl.arr, seed64, o, 600)
+    return o.raw[:n].decode()
+
+
+def multibit_keys(wl, mnemonic, count=20):
+    """MultibitTransform::apply_batch for one string input: (seed1, seed2, [(label, key)]) or None if skipped."""
+    m = mnemonic.encode() if isinstance(mnemonic, str) else mnemonic
+    keys, valid, s1, s2 = _out(32 * count), _out(count), _out(64), _out(64)
+    if not lib().vko_multibit_keys(wl.arr, m, len(m), count, keys, valid, s1, s2):
+        return None
+    out = []
+    for i in range(count):
+        if valid.raw[i]:
+            lab = _out(700)
+            lib().vko_multibit_label(m, i, lab, 700)
+            out.append((lab.value.decode(), keys.raw[32 * i:32 * i + 32]))
+    return s1.raw, s2.raw, out
 
 
 def normalize_key(k): o = _out(32); lib().vko_normalize_key(k, o); return o.raw
