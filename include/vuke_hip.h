@@ -56,6 +56,8 @@ extern "C" {
 #define VK_T_SHA256_CHAIN 5u /* src/sha256_chain.rs:74-79; 0 iterated, 1 indexed:be, 2 indexed:le, 3 counter */
 #define VK_T_ELECTRUM 6u     /* src/electrum.rs, src/transform/electrum.rs: STRING inputs only (vk_transform_strings);
                                 variant = 0 receiving / 1 change chain, chain_depth = derivation count (reference: 20) */
+#define VK_T_MULTIBIT 7u     /* src/multibit.rs, src/transform/multibit.rs: STRING inputs only; chain_depth = derivation
+                                count (reference: 20); needs vk_bip39_wordlist_set first */
 #define VK_VARIANT_ALL 0xFFFFFFFFu
 
 typedef struct vk_transform_spec {
@@ -164,9 +166,14 @@ int vk_derive_batch(vk_engine *e, const uint8_t *keys /* n*32 */, size_t n, uint
 int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, const uint64_t *seeds, size_t n,
                        uint8_t *keys_out, uint8_t *valid);
 
+/* The 2048-word BIP-39 list the multibit transform validates against and rebuilds mnemonics from: words = 2048 x 8
+ * bytes, each word zero padded to 8 bytes (the English list has no longer word).  The list is an input of the
+ * caller; the library embeds none. */
+int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words /* 16384 bytes */);
+
 /* Transform::apply_batch for string inputs (Input::from_string; wordlist / stdin sources).  String i is
- * data[offsets[i] .. offsets[i+1]).  Supported kinds: VK_T_ELECTRUM (strings up to 64 bytes; longer ones
- * return VK_E_UNSUPPORTED).  keys_out = n*slots*32, valid = n*slots, slot order = emit order. */
+ * data[offsets[i] .. offsets[i+1]).  Supported kinds: VK_T_ELECTRUM (strings up to 64 bytes) and
+ * VK_T_MULTIBIT (up to 256 bytes); longer strings return VK_E_UNSUPPORTED.  keys_out = n*slots*32, valid = n*slots, slot order = emit order. */
 int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
                          uint8_t *keys_out, uint8_t *valid);
 

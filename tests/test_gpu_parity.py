@@ -334,3 +334,27 @@ def test_electrum_strings_and_scan_keys(eng, vko):
         eng.sweep(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), 0, 10)          # string transform: not a range sweep
     with pytest.raises(vuke_amd.VkError):
         eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), [b"a" * 65])
+
+
+def test_multibit_chain(eng, vko):
+    """MultiBit-HD seed-as-entropy chain (2 x PBKDF2-HMAC-SHA512, BIP-39 repacking, BIP32 CKD)
+    on the device, against the oracle, on a synthetic 2048-word list (the real list is a caller-supplied input)."""
+    from tests.test_oracle_multibit import synthetic_wordlist
+    from vuke_amd import _ffi as ffi
+    import vuke_amd
+    words = synthetic_wordlist()
+    wl = vko.Wordlist(words)
+    spec = ffi.spec(ffi.T_MULTIBIT, 0, 0, 20)
+    with pytest.raises(vuke_amd.VkError):
+        eng.transform_strings(spec, [b"x"])              # no word list loaded yet
+    eng.bip39_wordlist_set(words)
+    rnd = random.Random(51)
+    ms = [" ".join(rnd.choice(words) for _ in range(n)) for n in (12, 15, 18, 21, 24) for _ in range(4)]
+    ms += ["  " + ms[0].replace(" ", "\t", 2) + " \n", " ".join(words[:11]), " ".join(words[:12]) + " zzzzzzzzz", "", " ".join(words[:13]),
+           " ".join(words[:11]) + " " + words[5][:-1]]
+    got = eng.transform_strings(spec, [m.encode() for m in ms])
+    for m, row in zip(ms, got):
+        exp = vko.multibit_keys(wl, m)
+        want = [k for _, k in exp[2]] if exp else []
+        assert [k for k in row if k is not None] == want, m
+    assert sum(1 for r in got for k in r if k is not None) == 21 * 20

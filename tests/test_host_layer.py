@@ -67,6 +67,7 @@ def test_transform_grammar_reference_cases(host):
     assert parse(host, "md5")[0] is None and "outside the device hot path" in parse(host, "md5")[1]
     assert parse(host, "electrum") == ((6, 0, 0, 20), "electrum")                 # src/transform/mod.rs:180-181
     assert parse(host, "electrum:change") == ((6, 1, 0, 20), "electrum:change")
+    assert parse(host, "multibit") == ((7, 0, 0, 20), "multibit")                 # src/transform/mod.rs:178
 
 
 def test_labels_match_oracle(host, vko):

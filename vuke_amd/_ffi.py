@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvuke_hip.so")
 
 VK_OK = 0
 VK_E_NO_DEVICE, VK_E_HIP, VK_E_INVALID_ARG, VK_E_UNSUPPORTED, VK_E_NOMEM = -1, -2, -3, -4, -5
-T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM = range(7)
+T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM, T_MULTIBIT = range(8)
 VARIANT_ALL = 0xFFFFFFFF
 F_COMPRESSED, F_UNCOMPRESSED = 1, 2
 ADDR_P2PKH_C, ADDR_P2PKH_U, ADDR_P2WPKH = 0, 1, 2
@@ -48,7 +48,7 @@ class EngineInfo(C.Structure):
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
     "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_transform_batch",
-    "vk_transform_strings", "vk_scan_keys",
+    "vk_transform_strings", "vk_scan_keys", "vk_bip39_wordlist_set",
     "vk_slots_per_input", "vk_debug_table_entry", "vk_debug_field",
 ]
 
@@ -79,6 +79,7 @@ def load():
     L.vk_derive_batch.argtypes = [vp, cp, sz, vp, vp, vp]
     L.vk_transform_batch.argtypes = [vp, C.POINTER(TransformSpec), C.POINTER(u64), sz, vp, vp]
     L.vk_transform_strings.argtypes = [vp, C.POINTER(TransformSpec), cp, C.POINTER(u32), sz, vp, vp]
+    L.vk_bip39_wordlist_set.argtypes = [vp, cp]
     L.vk_scan_keys.argtypes = [vp, cp, sz, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_slots_per_input.argtypes = [C.POINTER(TransformSpec)]
     L.vk_slots_per_input.restype = u32
@@ -168,6 +169,12 @@ class Engine:
         rk, rv = keys.raw, valid.raw
         return [[(rk[32 * (i * slots + s):32 * (i * slots + s) + 32] if rv[i * slots + s] else None) for s in range(slots)]
                 for i in range(n)]
+
+    def bip39_wordlist_set(self, words):
+        """words: 2048 byte strings of <= 8 bytes each."""
+        assert len(words) == 2048
+        blob = b"".join((w if isinstance(w, bytes) else w.encode()).ljust(8, b"\0") for w in words)
+        self._chk(self._L.vk_bip39_wordlist_set(self._e, blob))
 
     def transform_strings(self, spec, strings):
         """Transform::apply_batch for string inputs: per input a list of keys (None where nothing is emitted)."""

@@ -13,6 +13,7 @@
 #pragma once
 #include "vk_ec.cuh"
 #include "vk_hash.cuh"
+#include "vk_scalar.cuh"
 
 #define VK_ELECTRUM_MAX_SEED 64 /* bytes; longer strings are rejected by the host entry point */
 
@@ -98,14 +99,10 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_electrum_kernel(const unsigned ch
         for (int i = 0; i < 8; i++) x[i] = st[i];
     }
     // ---- master key: SecretKey::from_slice accepts 1 <= x < n only
-    u32 m[8], t[8];
+    u32 m[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) m[i] = t[i] = x[7 - i];
-    scalar_normalize(t);
-    u32 diff = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) diff |= t[i] ^ m[i];
-    if (diff != 0) return; // 0 or >= n
+    for (int i = 0; i < 8; i++) m[i] = x[7 - i];
+    if (!scalar_is_key(m)) return; // 0 or >= n
     jac P;
     ecmult_table(P, m, table, wins, nwin);
     fe zi, ax, ay;
@@ -143,44 +140,12 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_electrum_kernel(const unsigned ch
         sha256_private(d1, buf, pl + 64);
         sha256_of_digest(seq, d1);
         // Scalar::from_be_bytes: seq must be < n (zero allowed)
-        u32 s[8], sn[8];
+        u32 s[8], c[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = sn[j] = seq[7 - j];
-        scalar_normalize(sn); // changes s iff s == 0 or s >= n
-        u32 sdiff = 0, sor = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            sdiff |= sn[j] ^ s[j];
-            sor |= s[j];
-        }
-        if (sdiff != 0 && sor != 0) continue; // seq >= n
+        for (int j = 0; j < 8; j++) s[j] = seq[7 - j];
+        if (!scalar_lt_n(s)) continue;
         // child = master + seq mod n; a zero result is rejected by add_tweak
-        u32 c[8];
-        u64 cy = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            cy += (u64)m[j] + s[j];
-            c[j] = (u32)cy;
-            cy >>= 32;
-        }
-        // reduce: (cy, c) < 2n, subtract n if >= n
-        const u32 nl[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        u32 d[8];
-        u64 bw = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            u64 q = (u64)c[j] - nl[j] - bw;
-            d[j] = (u32)q;
-            bw = (q >> 32) & 1;
-        }
-        const bool ge = cy != 0 || bw == 0;
-        u32 any = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c[j] = ge ? d[j] : c[j];
-            any |= c[j];
-        }
-        if (any == 0) continue;
+        if (!scalar_add_mod_n(c, m, s)) continue;
 #pragma unroll
         for (int j = 0; j < 8; j++) kout[i * 8 + j] = bswap32(c[7 - j]);
         vout[i] = 1;

@@ -5,6 +5,7 @@
 #include "../../include/vuke_hip.h"
 #include "vk_kernels.cuh"
 #include "vk_electrum.cuh"
+#include "vk_multibit.cuh"
 
 #include <algorithm>
 #include <cstdio>
@@ -28,6 +29,7 @@ struct vk_engine {
     u32 layout = 0;        // 0 uniform unsigned W-bit windows, 1 nine signed windows (VK_LAYOUT_SIGNED9)
     vk_win_desc wins[VK_MAX_WIN];
     u64 table_entries = 0;
+    u64 *d_wordlist = nullptr;     // BIP-39 list, 2048 x 8 bytes (vk_bip39_wordlist_set)
     vk_win_desc *d_wins = nullptr; // device copy of wins (kernels that take the layout by pointer)
     double table_build_seconds = 0.0;
     u32 batch = 32;
@@ -90,6 +92,9 @@ extern "C" uint32_t vk_slots_per_input(const vk_transform_spec *t)
     case VK_T_ELECTRUM:
         if (t->variant > 1 || t->chain_depth == 0 || t->chain_depth > 1000) return 0;
         return t->chain_depth;
+    case VK_T_MULTIBIT:
+        if (t->chain_depth == 0 || t->chain_depth > 1000) return 0;
+        return t->chain_depth;
     default: return 0;
     }
 }
@@ -98,9 +103,12 @@ static int validate_spec(vk_engine *e, const vk_transform_spec *t, bool strings 
 {
     if (!t) return fail(e, VK_E_INVALID_ARG, "transform spec is NULL");
     if (vk_slots_per_input(t) == 0) return fail(e, VK_E_INVALID_ARG, "invalid transform spec (kind / variant / chain_depth)");
-    if (!strings && t->kind == VK_T_ELECTRUM)
-        return fail(e, VK_E_UNSUPPORTED, "electrum takes string inputs: use vk_transform_strings + vk_scan_keys");
-    if (strings && t->kind != VK_T_ELECTRUM) return fail(e, VK_E_UNSUPPORTED, "only electrum is built for string inputs");
+    const bool string_kind = t->kind == VK_T_ELECTRUM || t->kind == VK_T_MULTIBIT;
+    if (!strings && string_kind)
+        return fail(e, VK_E_UNSUPPORTED, "electrum / multibit take string inputs: use vk_transform_strings + vk_scan_keys");
+    if (strings && !string_kind) return fail(e, VK_E_UNSUPPORTED, "only electrum and multibit are built for string inputs");
+    if (strings && t->kind == VK_T_MULTIBIT && !e->d_wordlist)
+        return fail(e, VK_E_INVALID_ARG, "multibit needs the BIP-39 word list: call vk_bip39_wordlist_set first");
     if (t->kind == VK_T_LCG && t->endian > 1) return fail(e, VK_E_INVALID_ARG, "lcg endian must be 0 (big) or 1 (little)");
     return VK_OK;
 }
@@ -118,6 +126,7 @@ extern "C" void vk_engine_destroy(vk_engine *e)
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->work) (void)hipFree(e->work);
     if (e->d_wins) (void)hipFree(e->d_wins);
+    if (e->d_wordlist) (void)hipFree(e->d_wordlist);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -643,6 +652,27 @@ extern "C" int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, cons
     return VK_OK;
 }
 
+extern "C" int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!words) return fail(e, VK_E_INVALID_ARG, "words is NULL");
+    for (int i = 0; i < 2048; i++) {
+        const uint8_t *w = words + 8 * i;
+        if (w[0] == 0) return fail(e, VK_E_INVALID_ARG, "empty word in the BIP-39 list");
+        bool ended = false;
+        for (int j = 0; j < 8; j++) {
+            if (w[j] == 0) ended = true;
+            else if (ended || w[j] == ' ' || w[j] == '\t' || w[j] == '\n' || w[j] == '\r' || w[j] == 0x0b || w[j] == 0x0c)
+                return fail(e, VK_E_INVALID_ARG, "BIP-39 words must be zero padded and free of whitespace");
+        }
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    if (!e->d_wordlist) HIPCHK(e, hipMalloc(&e->d_wordlist, 2048 * 8));
+    HIPCHK(e, hipMemcpy(e->d_wordlist, words, 2048 * 8, hipMemcpyHostToDevice));
+    return VK_OK;
+}
+
 extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
                                     uint8_t *keys_out, uint8_t *valid)
 {
@@ -654,9 +684,10 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
     if (!data || !offsets || !keys_out || !valid) return fail(e, VK_E_INVALID_ARG, "data / offsets / keys_out / valid is NULL");
     const u32 slots = vk_slots_per_input(t);
     if ((u64)n * slots > (1ull << 28)) return fail(e, VK_E_INVALID_ARG, "too many keys for one vk_transform_strings call (max 2^28)");
+    const u32 max_len = t->kind == VK_T_MULTIBIT ? VK_MULTIBIT_MAX_MNEMONIC : VK_ELECTRUM_MAX_SEED;
     for (size_t i = 0; i < n; i++) {
         if (offsets[i + 1] < offsets[i]) return fail(e, VK_E_INVALID_ARG, "offsets must be non-decreasing");
-        if (offsets[i + 1] - offsets[i] > VK_ELECTRUM_MAX_SEED) return fail(e, VK_E_UNSUPPORTED, "string longer than 64 bytes");
+        if (offsets[i + 1] - offsets[i] > max_len) return fail(e, VK_E_UNSUPPORTED, "string too long for this transform on the device (electrum 64, multibit 256 bytes)");
     }
     HIPCHK(e, hipSetDevice(e->device));
     const size_t bytes = offsets[n], items = n * slots;
@@ -671,8 +702,12 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
     if (c == hipSuccess) c = hipMemsetAsync(d_keys, 0, items * 32, e->stream);
     if (c == hipSuccess) c = hipMemsetAsync(d_valid, 0, items, e->stream);
     if (c == hipSuccess) {
-        hipLaunchKernelGGL(vk_electrum_kernel, dim3((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_data, d_offs, (u64)n,
-                           t->variant, t->chain_depth, 100000u, e->table, e->d_wins, e->nwin, d_keys, d_valid);
+        if (t->kind == VK_T_MULTIBIT)
+            hipLaunchKernelGGL(vk_multibit_kernel, dim3((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_data, d_offs, (u64)n,
+                               t->chain_depth, e->d_wordlist, e->table, e->d_wins, e->nwin, d_keys, d_valid);
+        else
+            hipLaunchKernelGGL(vk_electrum_kernel, dim3((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_data, d_offs, (u64)n,
+                               t->variant, t->chain_depth, 100000u, e->table, e->d_wins, e->nwin, d_keys, d_valid);
         c = hipGetLastError();
     }
     if (c == hipSuccess) c = hipStreamSynchronize(e->stream);

@@ -19,12 +19,13 @@ static int usage(const char *msg)
 {
     if (msg) fprintf(stderr, "error: %s\n\n", msg);
     fprintf(stderr, "Usage: vuke-hip <generate|scan|single> [OPTIONS] range --start <START> --end <END>\n"
-                    "  --transform <T>...   sha256 | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] | sha256_chain[:variant] | electrum[:change]\n"
+                    "  --transform <T>...   sha256 | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] | sha256_chain[:variant] | electrum[:change] | multibit\n"
                     "  sources: range --start A --end B | wordlist --file F (string transforms: electrum[:change])\n"
                     "  --targets <FILE>     (scan) one address per line\n"
                     "  -v, --verbose        (generate) all key formats\n"
                     "  -o, --output <FILE>  write to FILE instead of stdout\n"
                     "  --network <N>        accepted and ignored, like the reference (src/main.rs:464,499)\n"
+                    "  --bip39-wordlist <F> 2048-word BIP-39 list (required by --transform multibit)\n"
                     "  --device <N>         GPU index (default 0)\n"
                     "  --window-bits <W>    k*G table window width (default 24)\n"
                     "  --layout <L>         uniform (default) | signed9 (120 GB table, 8 additions per key)\n");
@@ -48,7 +49,7 @@ int main(int argc, char **argv)
     std::vector<std::string> tnames;
     std::string targets, outpath, single_value;
     bool verbose = false, have_range = false, have_start = false, have_end = false, have_wordlist = false;
-    std::string wordlist_file;
+    std::string wordlist_file, bip39_file;
     uint64_t start = 0, end = 0;
     int device = 0;
     unsigned window_bits = 0, layout = VK_LAYOUT_UNIFORM;
@@ -72,6 +73,7 @@ int main(int argc, char **argv)
             else if (a == "range") have_range = true;
             else if (a == "wordlist") have_wordlist = true;
             else if (a == "--file") wordlist_file = need("--file");
+            else if (a == "--bip39-wordlist") bip39_file = need("--bip39-wordlist");
             else if (a == "--start") { start = parse_u64(need("--start")); have_start = true; }
             else if (a == "--end") { end = parse_u64(need("--end")); have_end = true; }
             else if (cmd == "single" && single_value.empty() && a[0] != '-') single_value = a;
@@ -97,6 +99,12 @@ int main(int argc, char **argv)
             return 1;
         }
         struct Guard { vk_engine *e; ~Guard() { vk_engine_destroy(e); } } guard{engine};
+        for (const Transform &t : transforms)
+            if (t.spec().kind == VK_T_MULTIBIT) {
+                if (bip39_file.empty()) throw std::invalid_argument("multibit needs --bip39-wordlist <FILE> (the 2048-word BIP-39 English list)");
+                load_bip39_wordlist(engine, bip39_file);
+                break;
+            }
 
         if (cmd == "single") {
             if (single_value.empty()) throw std::invalid_argument("single needs a numeric VALUE");

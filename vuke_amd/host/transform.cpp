@@ -4,6 +4,8 @@
 #include "vuke_host.hpp"
 
 #include <algorithm>
+#include <cstring>
+#include <fstream>
 #include <stdexcept>
 
 namespace vuke {
@@ -68,7 +70,13 @@ Transform TransformType::from_str(const std::string &raw)
         sp.chain_depth = 20;
         return Transform(sp);
     }
-    for (const char *n : {"direct", "double_sha256", "md5", "armory", "multibit", "bitimage"})
+    if (s == "multibit") { // src/transform/mod.rs:178; 20 indices, empty passphrase (src/transform/multibit.rs:15-21)
+        sp.kind = VK_T_MULTIBIT;
+        sp.variant = 0;
+        sp.chain_depth = 20;
+        return Transform(sp);
+    }
+    for (const char *n : {"direct", "double_sha256", "md5", "armory", "bitimage"})
         if (s == n) return unsupported(n);
     if (s == "lcg" || s.rfind("lcg:", 0) == 0) { // LcgConfig::parse
         auto parts = split_colon(s);
@@ -142,6 +150,7 @@ const char *Transform::name() const
     case VK_T_LCG: return "lcg";
     case VK_T_XORSHIFT: return "xorshift";
     case VK_T_ELECTRUM: return spec_.variant ? "electrum:change" : "electrum"; // src/transform/electrum.rs:36-42
+    case VK_T_MULTIBIT: return "multibit";
     case VK_T_SHA256_CHAIN: // src/transform/sha256_chain.rs:46-58
         switch (spec_.variant) {
         case 0: return "sha256_chain:iterated";
@@ -181,7 +190,35 @@ std::string Transform::label(const std::string &input, uint32_t sub) const
         if (input.size() > 20) shown = input.substr(0, 8) + "..." + input.substr(input.size() - 8); // hex seeds are ASCII
         return shown + "[" + (spec_.variant ? "1" : "0") + "/" + std::to_string(sub) + "]";
     }
+    if (spec_.kind == VK_T_MULTIBIT) { // "{truncate_mnemonic(m)}[m/0'/0/{i}]", src/transform/multibit.rs:52, src/multibit.rs:352-360
+        std::vector<std::string> w;
+        size_t i = 0;
+        auto ws = [](unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == 0x0b || c == 0x0c; };
+        while (i < input.size()) {
+            while (i < input.size() && ws((unsigned char)input[i])) i++;
+            size_t s0 = i;
+            while (i < input.size() && !ws((unsigned char)input[i])) i++;
+            if (i > s0) w.push_back(input.substr(s0, i - s0));
+        }
+        std::string shown = w.size() <= 4 ? input : w[0] + " " + w[1] + "..." + w[w.size() - 2] + " " + w[w.size() - 1];
+        return shown + "[m/0'/0/" + std::to_string(sub) + "]";
+    }
     return input;
+}
+
+void load_bip39_wordlist(vk_engine *e, const std::string &path)
+{
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("cannot open BIP-39 word list: " + path);
+    std::vector<uint8_t> blob(2048 * 8, 0);
+    std::string w;
+    size_t n = 0;
+    while (f >> w) {
+        if (n >= 2048 || w.size() > 8) throw std::invalid_argument("BIP-39 word list must hold 2048 words of at most 8 bytes");
+        memcpy(&blob[8 * n++], w.data(), w.size());
+    }
+    if (n != 2048) throw std::invalid_argument("BIP-39 word list must hold exactly 2048 words");
+    check_rc(e, vk_bip39_wordlist_set(e, blob.data()));
 }
 
 void Transform::apply_batch(vk_engine *e, const std::vector<std::string> &inputs, std::vector<std::pair<std::string, Key>> &output) const
@@ -193,7 +230,8 @@ void Transform::apply_batch(vk_engine *e, const std::vector<std::string> &inputs
     std::vector<uint8_t> data;
     std::vector<uint32_t> offs{0};
     for (const std::string &s : inputs) {
-        if (s.size() > 64) throw std::invalid_argument("electrum seed longer than 64 characters is not supported on the device path");
+        if (s.size() > (spec_.kind == VK_T_MULTIBIT ? 256u : 64u))
+            throw std::invalid_argument("input string too long for the device path (electrum 64, multibit 256 bytes)");
         data.insert(data.end(), s.begin(), s.end());
         offs.push_back((uint32_t)data.size());
     }

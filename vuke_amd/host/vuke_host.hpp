@@ -96,7 +96,7 @@ public:
     uint32_t slots() const { return vk_slots_per_input(&spec_); }
     std::string label(uint64_t seed, uint32_t sub) const;  // the `source` string apply_batch pushes
     std::string label(const std::string &input, uint32_t sub) const; // same for Input::from_string inputs
-    bool takes_strings() const { return spec_.kind == VK_T_ELECTRUM; }
+    bool takes_strings() const { return spec_.kind == VK_T_ELECTRUM || spec_.kind == VK_T_MULTIBIT; }
     // apply_batch for string inputs (wordlist / stdin sources), on the device
     void apply_batch(vk_engine *e, const std::vector<std::string> &inputs, std::vector<std::pair<std::string, Key>> &output) const;
     bool supports_gpu() const { return true; }
@@ -174,6 +174,9 @@ public:
 private:
     vk_engine *engine_;
 };
+
+// Load a BIP-39 word list file (2048 whitespace-separated words of <= 8 bytes) into the engine (multibit transform).
+void load_bip39_wordlist(vk_engine *e, const std::string &path);
 
 // error carrying the C ABI's code + message
 struct EngineError : std::runtime_error {
