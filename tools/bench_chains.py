@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Config 5 on one GPU: throughput of the MultiBit-HD and Electrum v1 key-chain kernels
+(inputs/s and keys/s, host packing included), with canonical op rates per SURVEY 8(d)."""
+import json, os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vuke_amd
+from vuke_amd import _ffi as ffi
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+e = vuke_amd.Engine(0)
+rnd = random.Random(5489)
+# synthetic inputs only: a pseudo-random 2048-word list and mnemonics / hex seeds drawn from a fixed RNG
+words = sorted({"".join(rnd.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(rnd.randrange(3, 9))) for _ in range(4000)})[:2048]
+e.bip39_wordlist_set(words)
+mn = [" ".join(rnd.choice(words) for _ in range(12)).encode() for _ in range(n)]
+spec = ffi.spec(ffi.T_MULTIBIT, 0, 0, 20)
+e.transform_strings(spec, mn[:1024])
+t = time.perf_counter(); rows = e.transform_strings(spec, mn); dt = time.perf_counter() - t
+keys = sum(1 for r in rows for k in r if k is not None)
+ops = 2 * 2048 * 2 * 5520 + 40 * 213000
+print(json.dumps({"chain": "multibit", "inputs": n, "seconds": dt, "inputs_per_s": n / dt, "keys_per_s": keys / dt,
+                  "canonical_tops": n / dt * ops / 1e12}))
+seeds = [("%032x" % rnd.getrandbits(128)).encode() for _ in range(n)]
+spec = ffi.spec(ffi.T_ELECTRUM, 0, 0, 20)
+e.transform_strings(spec, seeds[:1024])
+t = time.perf_counter(); rows = e.transform_strings(spec, seeds); dt = time.perf_counter() - t
+keys = sum(1 for r in rows for k in r if k is not None)
+ops = 200000 * 2168 + 21 * 213000
+print(json.dumps({"chain": "electrum", "inputs": n, "seconds": dt, "inputs_per_s": n / dt, "keys_per_s": keys / dt,
+                  "canonical_tops": n / dt * ops / 1e12}))
