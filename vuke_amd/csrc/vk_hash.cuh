@@ -10,6 +10,13 @@ VK_DEV u32 rotr32(u32 x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
 VK_DEV u32 rotl32(u32 x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
 VK_DEV u32 bswap32(u32 x) { return __builtin_bswap32(x); }
 
+// v_bitop3_b32: any 3-input boolean function in one instruction.  The table is the function evaluated on
+// a = 0xF0, b = 0xCC, c = 0xAA.
+#define VK_BITOP3(a, b, c, tbl) __builtin_amdgcn_bitop3_b32((a), (b), (c), (tbl))
+VK_DEV u32 xor3(u32 a, u32 b, u32 c) { return VK_BITOP3(a, b, c, 0x96); }
+VK_DEV u32 bool_ch(u32 e, u32 f, u32 g) { return VK_BITOP3(e, f, g, 0xCA); }   // (e & f) ^ (~e & g)
+VK_DEV u32 bool_maj(u32 a, u32 b, u32 c) { return VK_BITOP3(a, b, c, 0xE8); }  // majority
+
 __device__ __constant__ const u32 VK_K256[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5,
     0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
@@ -30,15 +37,15 @@ VK_DEV void sha256_compress(u32 st[8], u32 w[16])
     for (int i = 0; i < 64; i++) {
         if (i >= 16) {
             u32 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            u32 s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-            u32 s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+            u32 s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+            u32 s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
             w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
         }
-        u32 S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
-        u32 ch = g ^ (e & (f ^ g));
+        u32 S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
+        u32 ch = bool_ch(e, f, g);
         u32 t1 = h + S1 + ch + VK_K256[i] + w[i & 15];
-        u32 S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
-        u32 mj = (a & b) | (c & (a | b));
+        u32 S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
+        u32 mj = bool_maj(a, b, c);
         u32 t2 = S0 + mj;
         h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
@@ -106,11 +113,11 @@ VK_DEV void sha256_pub65(u32 out[8], const fe &x, const fe &y)
 }
 
 // ------------------------------------------------------------------ RIPEMD-160
-VK_DEV u32 rmd_f1(u32 x, u32 y, u32 z) { return x ^ y ^ z; }
-VK_DEV u32 rmd_f2(u32 x, u32 y, u32 z) { return z ^ (x & (y ^ z)); }       // (x&y)|(~x&z)
-VK_DEV u32 rmd_f3(u32 x, u32 y, u32 z) { return (x | ~y) ^ z; }
-VK_DEV u32 rmd_f4(u32 x, u32 y, u32 z) { return y ^ (z & (x ^ y)); }       // (x&z)|(y&~z)
-VK_DEV u32 rmd_f5(u32 x, u32 y, u32 z) { return x ^ (y | ~z); }
+VK_DEV u32 rmd_f1(u32 x, u32 y, u32 z) { return xor3(x, y, z); }
+VK_DEV u32 rmd_f2(u32 x, u32 y, u32 z) { return VK_BITOP3(x, y, z, 0xCA); } // (x&y)|(~x&z)
+VK_DEV u32 rmd_f3(u32 x, u32 y, u32 z) { return VK_BITOP3(x, y, z, 0x59); } // (x|~y)^z
+VK_DEV u32 rmd_f4(u32 x, u32 y, u32 z) { return VK_BITOP3(x, y, z, 0xE4); } // (x&z)|(y&~z)
+VK_DEV u32 rmd_f5(u32 x, u32 y, u32 z) { return VK_BITOP3(x, y, z, 0x2D); } // x^(y|~z)
 
 // Message-word order and rotate amounts of the two lines (RIPEMD-160 paper, tables r, r', s, s').
 // The loops below are fully unrolled, so every table lookup folds to an immediate.

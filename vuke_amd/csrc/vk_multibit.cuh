@@ -39,7 +39,38 @@ __device__ __constant__ const u64 VK_K512[80] = {
 #define VK_SHA512_IV {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull, \
                       0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull}
 
-VK_DEV u64 rotr64(u64 x, int n) { return (x >> n) | (x << (64 - n)); }
+// 64-bit rotate as two v_alignbit_b32 (the compiler's own lowering of (x >> n) | (x << (64 - n)) is
+// v_lshrrev_b64 + v_lshlrev_b64 + 2 x v_or: five issue slots instead of two)
+template <int N>
+VK_DEV u64 rotr64(u64 x)
+{
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    u32 rl, rh;
+    if constexpr (N < 32) {
+        rl = __builtin_amdgcn_alignbit(hi, lo, N);
+        rh = __builtin_amdgcn_alignbit(lo, hi, N);
+    } else if constexpr (N == 32) {
+        rl = hi;
+        rh = lo;
+    } else {
+        rl = __builtin_amdgcn_alignbit(lo, hi, N - 32);
+        rh = __builtin_amdgcn_alignbit(hi, lo, N - 32);
+    }
+    return ((u64)rh << 32) | rl;
+}
+
+VK_DEV u64 xor3_64(u64 a, u64 b, u64 c)
+{
+    return ((u64)xor3((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32)) << 32) | xor3((u32)a, (u32)b, (u32)c);
+}
+VK_DEV u64 ch64(u64 e, u64 f, u64 g)
+{
+    return ((u64)bool_ch((u32)(e >> 32), (u32)(f >> 32), (u32)(g >> 32)) << 32) | bool_ch((u32)e, (u32)f, (u32)g);
+}
+VK_DEV u64 maj64(u64 a, u64 b, u64 c)
+{
+    return ((u64)bool_maj((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32)) << 32) | bool_maj((u32)a, (u32)b, (u32)c);
+}
 
 // one SHA-512 compression; w[16] is consumed as the rolling schedule
 VK_DEV void sha512_compress(u64 st[8], u64 w[16])
@@ -49,15 +80,15 @@ VK_DEV void sha512_compress(u64 st[8], u64 w[16])
     for (int i = 0; i < 80; i++) {
         if (i >= 16) {
             u64 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            u64 s0 = rotr64(w15, 1) ^ rotr64(w15, 8) ^ (w15 >> 7);
-            u64 s1 = rotr64(w2, 19) ^ rotr64(w2, 61) ^ (w2 >> 6);
+            u64 s0 = xor3_64(rotr64<1>(w15), rotr64<8>(w15), w15 >> 7);
+            u64 s1 = xor3_64(rotr64<19>(w2), rotr64<61>(w2), w2 >> 6);
             w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
         }
-        u64 S1 = rotr64(e, 14) ^ rotr64(e, 18) ^ rotr64(e, 41);
-        u64 ch = g ^ (e & (f ^ g));
+        u64 S1 = xor3_64(rotr64<14>(e), rotr64<18>(e), rotr64<41>(e));
+        u64 ch = ch64(e, f, g);
         u64 t1 = h + S1 + ch + VK_K512[i] + w[i & 15];
-        u64 S0 = rotr64(a, 28) ^ rotr64(a, 34) ^ rotr64(a, 39);
-        u64 mj = (a & b) | (c & (a | b));
+        u64 S0 = xor3_64(rotr64<28>(a), rotr64<34>(a), rotr64<39>(a));
+        u64 mj = maj64(a, b, c);
         u64 t2 = S0 + mj;
         h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
