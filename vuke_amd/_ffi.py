@@ -176,16 +176,23 @@ class Engine:
         blob = b"".join((w if isinstance(w, bytes) else w.encode()).ljust(8, b"\0") for w in words)
         self._chk(self._L.vk_bip39_wordlist_set(self._e, blob))
 
-    def transform_strings(self, spec, strings):
-        """Transform::apply_batch for string inputs: per input a list of keys (None where nothing is emitted)."""
+    def transform_strings(self, spec, strings, raw=False):
+        """Transform::apply_batch for string inputs: per input a list of keys (None where nothing is emitted).
+        raw=True returns (keys bytes, valid bytes, seconds inside the library call) without per-key unpacking."""
         n = len(strings)
         slots = self._L.vk_slots_per_input(C.byref(spec))
         offs = (C.c_uint32 * (n + 1))()
         for i, s in enumerate(strings):
             offs[i + 1] = offs[i] + len(s)
         keys, valid = C.create_string_buffer(max(1, n * slots * 32)), C.create_string_buffer(max(1, n * slots))
-        self._chk(self._L.vk_transform_strings(self._e, C.byref(spec), b"".join(strings), offs, n, keys, valid))
+        blob = b"".join(strings)
+        import time
+        t0 = time.perf_counter()
+        self._chk(self._L.vk_transform_strings(self._e, C.byref(spec), blob, offs, n, keys, valid))
+        dt = time.perf_counter() - t0
         rk, rv = keys.raw, valid.raw
+        if raw:
+            return rk, rv, dt
         return [[(rk[32 * (i * slots + s):32 * (i * slots + s) + 32] if rv[i * slots + s] else None) for s in range(slots)]
                 for i in range(n)]
 
