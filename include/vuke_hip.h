@@ -182,6 +182,33 @@ int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t
 int vk_scan_keys(vk_engine *e, const uint8_t *keys /* n*32 */, size_t n, uint32_t flags, vk_hit *hits, size_t hit_cap,
                  vk_sweep_stats *out);
 
+/* ---- analyzer brute force (reference src/analyze/{milksad,lcg,mt64}.rs) -------------------
+ * Smallest seed in [seed_lo, seed_hi] whose generated key(s) satisfy the target.  Kinds: VK_T_MILKSAD, VK_T_MT64,
+ * VK_T_LCG (one variant: spec.variant 0..3, spec.endian).  The reference reports whichever matching seed a worker
+ * thread finds first; this search reports the smallest, which is one of the reference's possible answers. */
+#define VK_SEARCH_EXACT 0u   /* key == target.key                                     (analyze_exact) */
+#define VK_SEARCH_MASKED 1u  /* ((last 8 key bytes, BE) & (2^bits-1)) | 2^(bits-1) == last 8 bytes of target.key  (analyze_masked) */
+#define VK_SEARCH_CASCADE 2u /* draws j = 0..n-1 of one generator instance: masked(draw j, bits[j]) == targets[j]  (analyze_cascading) */
+typedef struct vk_search_target {
+    uint32_t mode;        /* VK_SEARCH_* */
+    uint32_t n_cascade;   /* cascade: 1..8 draws */
+    uint8_t key[32];      /* exact / masked target key */
+    uint32_t mask_bits;   /* masked: 1..64 */
+    uint32_t _pad;
+    uint8_t bits[8];      /* cascade: mask width per draw, 1..64 */
+    uint64_t targets[8];  /* cascade: masked target per draw */
+} vk_search_target;
+typedef struct vk_search_result {
+    uint32_t found;
+    uint32_t n_keys;        /* draws stored in keys: 1, or n_cascade */
+    uint64_t seed;
+    uint64_t seeds_checked; /* whole range when nothing was found */
+    double kernel_seconds;
+    uint8_t keys[8][32];    /* the generated key(s) of the reported seed */
+} vk_search_result;
+int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_t seed_hi_inclusive,
+              const vk_search_target *target, vk_search_result *out);
+
 /* Slots one input occupies under `t` (0 if the spec is invalid). */
 uint32_t vk_slots_per_input(const vk_transform_spec *t);
 

@@ -279,3 +279,79 @@ const char *vko_transform_name(const vko_spec *s)
     default: return "?";
     }
 }
+
+/* ---------------------------------------------------------------- analyzer search (oracle)
+ * Successive 32-byte draws of one generator instance, as the cascade analyzers consume them
+ * (src/analyze/milksad.rs:269-288: rng.fill_bytes(&mut key) per target; src/analyze/mt64.rs:175-192). */
+void vko_milksad_draws(uint32_t seed, uint32_t ndraws, uint8_t *out /* ndraws*32 */)
+{
+    uint32_t mt[624];
+    mt[0] = seed;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    int idx = 624;
+    for (uint32_t o = 0; o < ndraws * 8; o++) {
+        if (idx >= 624) {
+            for (int k = 0; k < 624; k++) {
+                uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        out[4 * o] = (uint8_t)y; out[4 * o + 1] = (uint8_t)(y >> 8); out[4 * o + 2] = (uint8_t)(y >> 16); out[4 * o + 3] = (uint8_t)(y >> 24);
+    }
+}
+
+void vko_mt64_draws(uint64_t seed, uint32_t ndraws, uint8_t *out)
+{
+    uint64_t mt[312];
+    mt[0] = seed;
+    for (int i = 1; i < 312; i++) mt[i] = 6364136223846793005ULL * (mt[i - 1] ^ (mt[i - 1] >> 62)) + (uint64_t)i;
+    int idx = 312;
+    for (uint32_t o = 0; o < ndraws * 4; o++) {
+        if (idx >= 312) {
+            for (int k = 0; k < 312; k++) {
+                uint64_t x = (mt[k] & 0xFFFFFFFF80000000ULL) | (mt[(k + 1) % 312] & 0x7FFFFFFFULL);
+                mt[k] = mt[(k + 156) % 312] ^ (x >> 1) ^ ((x & 1ULL) ? 0xB5026F5AA96619E9ULL : 0ULL);
+            }
+            idx = 0;
+        }
+        uint64_t x = mt[idx++];
+        x ^= (x >> 29) & 0x5555555555555555ULL; x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+        x ^= (x << 37) & 0xFFF7EEE000000000ULL; x ^= x >> 43;
+        for (int j = 0; j < 8; j++) out[8 * o + j] = (uint8_t)(x >> (8 * j));
+    }
+}
+
+static uint64_t last8_be(const uint8_t *k) { uint64_t v = 0; for (int i = 24; i < 32; i++) v = (v << 8) | k[i]; return v; }
+static int masked_eq(const uint8_t *k, uint32_t bits, uint64_t target)
+{ /* (key & (2^bits - 1)) | 2^(bits-1), src/analyze/milksad.rs:147-150,191-192 */
+    uint64_t mask = bits >= 64 ? ~0ULL : (1ULL << bits) - 1, high = 1ULL << (bits - 1);
+    return ((last8_be(k) & mask) | high) == target;
+}
+
+/* smallest seed in [lo, hi] matching; mode 0 exact (key), 1 masked (key, bits[0]), 2 cascade (n, bits, targets).
+ * kind: VKO_T_MILKSAD, VKO_T_MT64, VKO_T_LCG (spec->variant single, spec->endian).  Returns 1 and *seed when found. */
+int vko_search(const vko_spec *spec, uint64_t lo, uint64_t hi, uint32_t mode, const uint8_t key[32], uint32_t n,
+               const uint8_t *bits, const uint64_t *targets, uint64_t *seed_out, uint8_t *keys_out /* n*32 */)
+{
+    uint32_t nd = mode == 2 ? n : 1;
+    for (uint64_t s = lo;; s++) {
+        uint8_t d[8 * 32];
+        int have = 1;
+        if (spec->kind == VKO_T_MILKSAD) { if (s > 0xFFFFFFFFULL) have = 0; else vko_milksad_draws((uint32_t)s, nd, d); }
+        else if (spec->kind == VKO_T_MT64) vko_mt64_draws(s, nd, d);
+        else if (spec->kind == VKO_T_LCG) have = vko_lcg_key(s, spec->variant, spec->endian, d);
+        else return -1;
+        if (have) {
+            int ok = 1;
+            if (mode == 0) ok = memcmp(d, key, 32) == 0;
+            else if (mode == 1) ok = masked_eq(d, bits[0], last8_be(key));
+            else for (uint32_t j = 0; j < n && ok; j++) ok = masked_eq(d + 32 * j, bits[j], targets[j]);
+            if (ok) { *seed_out = s; if (keys_out) memcpy(keys_out, d, 32 * nd); return 1; }
+        }
+        if (s == hi) break;
+    }
+    return 0;
+}

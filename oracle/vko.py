@@ -102,6 +102,9 @@ def lib():
         L.vko_multibit_buggy_mnemonic.restype = sz
         L.vko_multibit_keys.argtypes = [C.POINTER(cp), cp, sz, u32, cp, cp, cp, cp]
         L.vko_multibit_label.argtypes = [cp, u32, cp, sz]
+        L.vko_milksad_draws.argtypes = [u32, u32, cp]
+        L.vko_mt64_draws.argtypes = [u64, u32, cp]
+        L.vko_search.argtypes = [C.POINTER(Spec), u64, u64, u32, cp, u32, cp, C.POINTER(u64), C.POINTER(u64), cp]
         _ = (u8p, u64)
         _lib = L
     return _lib
@@ -201,6 +204,36 @@ def electrum_keys(seed, for_change=False, count=20, rounds=100000):
             lib().vko_electrum_label(seed, 1 if for_change else 0, i, lab, 160)
             out.append((lab.value.decode(), keys.raw[32 * i:32 * i + 32]))
     return mpk.raw, out
+
+
+def milksad_draws(seed, n):
+    o = _out(32 * n)
+    lib().vko_milksad_draws(seed, n, o)
+    return [o.raw[32 * i:32 * i + 32] for i in range(n)]
+
+
+def mt64_draws(seed, n):
+    o = _out(32 * n)
+    lib().vko_mt64_draws(seed, n, o)
+    return [o.raw[32 * i:32 * i + 32] for i in range(n)]
+
+
+def search(sp, lo, hi, key=None, mask_bits=None, cascade=None):
+    """Analyzer brute force on the CPU: (seed, [keys]) of the smallest matching seed in [lo, hi], or None."""
+    if cascade is not None:
+        mode, n = 2, len(cascade)
+        bits = bytes(b for b, _ in cascade)
+        targets = (C.c_uint64 * n)(*[t for _, t in cascade])
+        key = bytes(32)
+    else:
+        mode, n = (1 if mask_bits else 0), 1
+        bits = bytes([mask_bits or 0])
+        targets = (C.c_uint64 * 1)(0)
+    seed, keys = C.c_uint64(), _out(32 * 8)
+    r = lib().vko_search(C.byref(sp), lo, hi, mode, key, n, bits, targets, C.byref(seed), keys)
+    if r != 1:
+        return None
+    return seed.value, [keys.raw[32 * i:32 * i + 32] for i in range(n)]
 
 
 class Wordlist:

@@ -358,3 +358,53 @@ def test_multibit_chain(eng, vko):
         want = [k for _, k in exp[2]] if exp else []
         assert [k for k in row if k is not None] == want, m
     assert sum(1 for r in got for k in r if k is not None) == 21 * 20
+
+
+def test_analyzer_search(eng, vko):
+    """analyzer brute force (exact / masked / cascade) for milksad, lcg, mt64 on the device."""
+    from vuke_amd import _ffi as ffi
+
+    def masked(key, bits):
+        k = int.from_bytes(key[24:], "big")
+        return (k & ((1 << bits) - 1)) | (1 << (bits - 1))
+
+    ms, os_ = ffi.spec(ffi.T_MILKSAD), vko.spec(vko.T_MILKSAD)
+    # README.md:424-441: cascade 5:0x16,10:0x273,15:0x7a85 -> seed 100, with the three full keys it prints
+    r = eng.search(ms, 0, 2**32 - 1, cascade=[(5, 0x16), (10, 0x273), (15, 0x7a85)])
+    assert r["found"] and r["seed"] == 100
+    assert [k.hex() for k in r["keys"]] == ["08961c8b18dbd0ab4337434767df7b69572fad6c4f00c186b03f43d88af70a26",
+                                            "5e413501b4371e2862271f1f3550bc2f4236b6abe29ec9350e166bd322c3e673",
+                                            "f133ff22f0aac1de185139938f664d10e4ac2de46be7d29f3c458e353a1efa85"]
+    # exact: the whole 2^32 space, the planted seed near the end
+    key = vko.milksad_key(4_123_456_789)
+    r = eng.search(ms, 0, 2**32 - 1, key=key)
+    assert r["found"] and r["seed"] == 4_123_456_789 and r["keys"] == [key]
+    r = eng.search(ms, 0, 2**32 - 1, key=bytes(31) + b"\x01")
+    assert not r["found"] and r["seeds_checked"] == 2**32
+    # masked / cascade / exact against the oracle on small ranges (smallest matching seed)
+    for lo, hi in ((0, 300000), (10**9, 10**9 + 200000)):
+        for bits, target in ((5, 0x15), (10, 0x202), (17, 0x1abcd), (64, int.from_bytes(vko.milksad_key(lo + 777)[24:], "big"))):
+            want = vko.search(os_, lo, hi, key=target.to_bytes(32, "big"), mask_bits=bits)
+            got = eng.search(ms, lo, hi, key=target.to_bytes(32, "big"), mask_bits=bits)
+            assert (got["found"], got["seed"] if got["found"] else None) == (want is not None, want[0] if want else None), (lo, bits)
+            if want:
+                assert got["keys"] == want[1] and masked(got["keys"][0], bits) == target
+        d = vko.milksad_draws(lo + 4242, 8)
+        casc = [(4 + 3 * j, masked(d[j], 4 + 3 * j)) for j in range(8)]
+        for n in (1, 2, 8):
+            assert eng.search(ms, lo, hi, cascade=casc[:n])["seed"] == vko.search(os_, lo, hi, cascade=casc[:n])[0]
+    # lcg (src/analyze/lcg.rs tests): known seeds per variant / endian, wrong endian not found, masked
+    for variant, le in ((0, 0), (1, 0), (2, 1), (3, 0)):
+        ls, lo_ = ffi.spec(ffi.T_LCG, variant, le), vko.spec(vko.T_LCG, variant, le)
+        k = vko.lcg_key(1234567, variant, bool(le))
+        r = eng.search(ls, 0, 2**32 - 1, key=k)
+        assert r["found"] and r["seed"] == 1234567 and r["keys"] == [k]
+        got = eng.search(ls, 0, 10**6, key=(0x2bc).to_bytes(32, "big"), mask_bits=10)
+        want = vko.search(lo_, 0, 10**6, key=(0x2bc).to_bytes(32, "big"), mask_bits=10)
+        assert got["seed"] == want[0] and got["keys"] == want[1]
+    assert not eng.search(ffi.spec(ffi.T_LCG, 0, 1), 0, 2**31, key=vko.lcg_key(1234567, 0, False))["found"]
+    # mt64 cascade (src/analyze/mt64.rs:286-336)
+    d = vko.mt64_draws(2**40 + 99, 3)
+    casc = [(8, masked(d[0], 8)), (16, masked(d[1], 16)), (24, masked(d[2], 24))]
+    r = eng.search(ffi.spec(ffi.T_MT64), 2**40, 2**40 + 10**6, cascade=casc)
+    assert r["found"] and r["seed"] == 2**40 + 99 and r["keys"] == d

@@ -170,3 +170,35 @@ def test_matcher_load_check_and_device_form(host, vko, tmp_path):
     got = sorted((kind.raw[i], h160.raw[20 * i:20 * i + 20]) for i in range(n.value))
     assert got == sorted([(0, bytes(d.h160_c)), (1, bytes(d.h160_c))])  # junk, upper-case bech32 and P2SH never match
     assert host.vkh_matcher_load(b"/nonexistent/file", h160, kind, 16, C.byref(n)) == -1
+
+
+def test_analyze_key_and_cascade_parsers(host):
+    # src/analyze/key_parser.rs tests (:232-400)
+    def key(s):
+        out = C.create_string_buffer(32)
+        return out.raw if host.vkh_parse_key(s.encode(), out) == 0 else None
+
+    chbs = "c4bbcb1fbec99d65bf59d85c8cb62ee2db963f0fe106f483d9afa73bd4e39a8a"
+    assert key(chbs).hex() == chbs and key("0x" + chbs).hex() == chbs
+    assert key("0x15") == bytes(31) + b"\x15" and key("0x202")[30:] == b"\x02\x02" and key("0xd2c55")[29:] == b"\x0d\x2c\x55"
+    assert key("1f") == bytes(31) + b"\x1f"
+    assert key("5KJvsngHeMpm884wtkJNzQGaCErckhHJBGFsvd3VyK5qMZXj3hS").hex() == chbs
+    assert key("L3p8oAcQTtuokSCRHQ7i4MhjWc9zornvpJLfmg62sYpLRJF9woSu").hex() == chbs
+    assert key("1") == bytes(31) + b"\x01"
+    n_minus_1 = "115792089237316195423570985008687907852837564279074904382605163141518161494336"
+    assert int.from_bytes(key(n_minus_1), "big") == int(n_minus_1)
+    assert key("115792089237316195423570985008687907852837564279074904382605163141518161494337") is None
+    assert key("not a key") is None and key("") is None and key("zzzz") is None
+
+    def casc(s):
+        bits, tg, err = C.create_string_buffer(16), (C.c_uint64 * 16)(), C.create_string_buffer(256)
+        n = host.vkh_parse_cascade(s.encode(), bits, tg, 16, err, 256)
+        return [(bits.raw[i], tg[i]) for i in range(n)] if n >= 0 else err.value.decode()
+
+    assert casc("5:0x15,10:0x202") == [(5, 0x15), (10, 0x202)]
+    assert casc("5:21,10:514") == [(5, 21), (10, 514)]
+    assert casc("5:0x15,10:514,20:0xd2c55") == [(5, 0x15), (10, 514), (20, 0xd2c55)]
+    assert casc("20:0xd2c55,5:0x15,10:0x202") == [(5, 0x15), (10, 0x202), (20, 0xd2c55)]   # sorted by bits
+    assert "at least 2 targets" in casc("5:0x15") and "empty input" in casc("  ")
+    assert "exceeds 5-bit maximum" in casc("5:0x25,10:0x202") and "bits must be 1-64" in casc("0:1,5:0x15")
+    assert "duplicate target" in casc("5:0x15,5:0x15") and "expected 'bits:target'" in casc("5-0x15,10:0x202")

@@ -45,10 +45,22 @@ class EngineInfo(C.Structure):
                 ("table_build_seconds", C.c_double)]
 
 
+class SearchTarget(C.Structure):
+    _fields_ = [("mode", C.c_uint32), ("n_cascade", C.c_uint32), ("key", C.c_uint8 * 32), ("mask_bits", C.c_uint32), ("_pad", C.c_uint32),
+                ("bits", C.c_uint8 * 8), ("targets", C.c_uint64 * 8)]
+
+
+class SearchResult(C.Structure):
+    _fields_ = [("found", C.c_uint32), ("n_keys", C.c_uint32), ("seed", C.c_uint64), ("seeds_checked", C.c_uint64),
+                ("kernel_seconds", C.c_double), ("keys", (C.c_uint8 * 32) * 8)]
+
+
+SEARCH_EXACT, SEARCH_MASKED, SEARCH_CASCADE = 0, 1, 2
+
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
     "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_transform_batch",
-    "vk_transform_strings", "vk_scan_keys", "vk_bip39_wordlist_set",
+    "vk_transform_strings", "vk_scan_keys", "vk_bip39_wordlist_set", "vk_search",
     "vk_slots_per_input", "vk_debug_table_entry", "vk_debug_field",
 ]
 
@@ -80,6 +92,7 @@ def load():
     L.vk_transform_batch.argtypes = [vp, C.POINTER(TransformSpec), C.POINTER(u64), sz, vp, vp]
     L.vk_transform_strings.argtypes = [vp, C.POINTER(TransformSpec), cp, C.POINTER(u32), sz, vp, vp]
     L.vk_bip39_wordlist_set.argtypes = [vp, cp]
+    L.vk_search.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, C.POINTER(SearchTarget), C.POINTER(SearchResult)]
     L.vk_scan_keys.argtypes = [vp, cp, sz, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_slots_per_input.argtypes = [C.POINTER(TransformSpec)]
     L.vk_slots_per_input.restype = u32
@@ -204,6 +217,22 @@ class Engine:
         hl = sorted((dict(index=h.seed, addr_kind=h.addr_kind, privkey=bytes(h.privkey), h160=bytes(h.h160)) for h in hits[:n]),
                     key=lambda h: h["index"])
         return dict(inputs=st.inputs, keys=st.keys, matches=st.matches, digest=tuple(st.digest)), hl
+
+    def search(self, spec, lo, hi, key=None, mask_bits=None, cascade=None):
+        """Analyzer brute force: smallest matching seed in [lo, hi] (exact key, masked key, or cascade [(bits, target)])."""
+        tg = SearchTarget()
+        if cascade is not None:
+            tg.mode, tg.n_cascade = SEARCH_CASCADE, len(cascade)
+            for j, (b, t) in enumerate(cascade):
+                tg.bits[j], tg.targets[j] = b, t
+        else:
+            tg.mode = SEARCH_MASKED if mask_bits else SEARCH_EXACT
+            tg.mask_bits = mask_bits or 0
+            tg.key[:] = key
+        r = SearchResult()
+        self._chk(self._L.vk_search(self._e, C.byref(spec), lo, hi, C.byref(tg), C.byref(r)))
+        return dict(found=bool(r.found), seed=r.seed, seeds_checked=r.seeds_checked, kernel_seconds=r.kernel_seconds,
+                    keys=[bytes(r.keys[j]) for j in range(r.n_keys)])
 
     def table_entry(self, window, digit):
         xy = C.create_string_buffer(64)

@@ -6,6 +6,7 @@
 #include "vk_kernels.cuh"
 #include "vk_electrum.cuh"
 #include "vk_multibit.cuh"
+#include "vk_search.cuh"
 
 #include <algorithm>
 #include <cstdio>
@@ -752,6 +753,104 @@ extern "C" int vk_scan_keys(vk_engine *e, const uint8_t *keys, size_t n, uint32_
     if (rc) return rc;
     out->inputs = n;
     out->hits_dropped = out->matches > (hits ? hit_cap : 0) ? out->matches - (hits ? hit_cap : 0) : 0;
+    return VK_OK;
+}
+
+// ------------------------------------------------------------------------- analyzer search
+template <u32 KIND, int ND>
+static void launch_search(const vk_search_params &p, u32 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((vk_search_kernel<KIND, ND>), dim3(grid), dim3(VK_BLOCK), 0, s, p);
+}
+template <u32 KIND, int ND>
+static void launch_emit(const vk_spec_dev &spec, u64 seed, u32 *out, hipStream_t s)
+{
+    hipLaunchKernelGGL((vk_search_emit_kernel<KIND, ND>), dim3(1), dim3(64), 0, s, spec, seed, out);
+}
+
+extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const vk_search_target *tg, vk_search_result *out)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!t || !tg || !out) return fail(e, VK_E_INVALID_ARG, "spec / target / out is NULL");
+    if (hi < lo) return fail(e, VK_E_INVALID_ARG, "seed_hi < seed_lo");
+    if (t->kind != VK_T_MILKSAD && t->kind != VK_T_MT64 && t->kind != VK_T_LCG)
+        return fail(e, VK_E_UNSUPPORTED, "vk_search is built for milksad, mt64 and lcg");
+    if (t->kind == VK_T_LCG && (t->variant > 3 || t->endian > 1)) return fail(e, VK_E_INVALID_ARG, "lcg search takes one variant (0..3) and an endian");
+    if (tg->mode > VK_SEARCH_CASCADE) return fail(e, VK_E_INVALID_ARG, "unknown search mode");
+    if (tg->mode == VK_SEARCH_MASKED && (tg->mask_bits < 1 || tg->mask_bits > 64)) return fail(e, VK_E_INVALID_ARG, "mask_bits must be 1..64");
+    if (tg->mode == VK_SEARCH_CASCADE) {
+        if (tg->n_cascade < 1 || tg->n_cascade > VK_SEARCH_MAX_DRAWS) return fail(e, VK_E_INVALID_ARG, "n_cascade must be 1..8");
+        if (t->kind == VK_T_LCG) return fail(e, VK_E_UNSUPPORTED, "the lcg analyzer has no cascade mode");
+        for (u32 j = 0; j < tg->n_cascade; j++)
+            if (tg->bits[j] < 1 || tg->bits[j] > 64) return fail(e, VK_E_INVALID_ARG, "cascade bits must be 1..64");
+    }
+    memset(out, 0, sizeof *out);
+    HIPCHK(e, hipSetDevice(e->device));
+    vk_search_params p;
+    memset(&p, 0, sizeof p);
+    p.spec = to_dev(t);
+    p.mode = tg->mode;
+    p.ndraws = tg->mode == VK_SEARCH_CASCADE ? tg->n_cascade : 1;
+    for (int i = 0; i < 8; i++)
+        p.key[i] = ((u32)tg->key[4 * i] << 24) | ((u32)tg->key[4 * i + 1] << 16) | ((u32)tg->key[4 * i + 2] << 8) | tg->key[4 * i + 3];
+    if (tg->mode == VK_SEARCH_MASKED) {
+        p.bits[0] = tg->mask_bits;
+        p.targets[0] = ((u64)p.key[6] << 32) | p.key[7];
+    } else if (tg->mode == VK_SEARCH_CASCADE) {
+        for (u32 j = 0; j < tg->n_cascade; j++) {
+            p.bits[j] = tg->bits[j];
+            p.targets[j] = tg->targets[j];
+        }
+    }
+    u64 *d_best = e->d_stats + 7; // spare counter slot
+    p.best = d_best;
+    const bool wide = tg->mode == VK_SEARCH_CASCADE && tg->n_cascade > 1;
+    const u64 per = 1ull << 30;
+    const u32 grid = (u32)e->cu_count * 8;
+    u64 cur = lo, best = ~0ull, checked = 0;
+    for (;;) {
+        const u64 left = hi - cur, span = std::min<u64>(left, per - 1);
+        const u64 init = ~0ull;
+        HIPCHK(e, hipMemcpyAsync(d_best, &init, 8, hipMemcpyHostToDevice, e->stream));
+        p.lo = cur;
+        p.span = span;
+        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+        if (t->kind == VK_T_MILKSAD) wide ? launch_search<VK_T_MILKSAD, 8>(p, grid, e->stream) : launch_search<VK_T_MILKSAD, 1>(p, grid, e->stream);
+        else if (t->kind == VK_T_MT64) wide ? launch_search<VK_T_MT64, 8>(p, grid, e->stream) : launch_search<VK_T_MT64, 1>(p, grid, e->stream);
+        else launch_search<VK_T_LCG, 1>(p, grid, e->stream);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+        HIPCHK(e, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        out->kernel_seconds += (double)ms * 1e-3;
+        checked += span + 1;
+        if (best != ~0ull || span == left) break;
+        cur += span + 1;
+    }
+    out->seeds_checked = checked;
+    if (best == ~0ull) return VK_OK;
+    out->found = 1;
+    out->seed = best;
+    out->n_keys = p.ndraws;
+    u32 *d_out = nullptr;
+    HIPCHK(e, hipMalloc(&d_out, 8 * 32));
+    hipError_t c = hipMemsetAsync(d_out, 0, 8 * 32, e->stream);
+    if (c == hipSuccess) {
+        if (t->kind == VK_T_MILKSAD) launch_emit<VK_T_MILKSAD, 8>(p.spec, best, d_out, e->stream);
+        else if (t->kind == VK_T_MT64) launch_emit<VK_T_MT64, 8>(p.spec, best, d_out, e->stream);
+        else launch_emit<VK_T_LCG, 1>(p.spec, best, d_out, e->stream);
+        c = hipGetLastError();
+    }
+    if (c == hipSuccess) c = hipStreamSynchronize(e->stream);
+    if (c == hipSuccess) c = hipMemcpy(out->keys, d_out, 8 * 32, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (c != hipSuccess) {
+        e->err = std::string("vk_search: ") + hipGetErrorString(c);
+        return VK_E_HIP;
+    }
     return VK_OK;
 }
 

@@ -108,3 +108,33 @@ int vkh_matcher_check(const char *path, const uint8_t key[32], const uint8_t hc[
     }
 }
 }
+
+extern "C" {
+// parse_private_key (src/analyze/key_parser.rs:32-48): 0 on success
+int vkh_parse_key(const char *s, uint8_t out[32])
+{
+    try {
+        Key k = parse_private_key(s);
+        memcpy(out, k.data(), 32);
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+// parse_cascade (:131-166): number of targets, or -1 with the message in err
+int vkh_parse_cascade(const char *s, uint8_t *bits, uint64_t *targets, size_t cap, char *err, size_t err_cap)
+{
+    try {
+        auto t = parse_cascade(s);
+        if (t.size() > cap) return -1;
+        for (size_t i = 0; i < t.size(); i++) {
+            bits[i] = t[i].first;
+            targets[i] = t[i].second;
+        }
+        return (int)t.size();
+    } catch (const std::exception &e) {
+        put(e.what(), err, err_cap);
+        return -1;
+    }
+}
+}

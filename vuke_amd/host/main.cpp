@@ -19,6 +19,7 @@ static int usage(const char *msg)
 {
     if (msg) fprintf(stderr, "error: %s\n\n", msg);
     fprintf(stderr, "Usage: vuke-hip <generate|scan|single> [OPTIONS] range --start <START> --end <END>\n"
+                    "       vuke-hip analyze <KEY> [--mask BITS] [--cascade b:t,b:t,...] [--analyzer milksad|lcg[:variant][:endian]|mt64]...\n"
                     "  --transform <T>...   sha256 | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] | sha256_chain[:variant] | electrum[:change] | multibit\n"
                     "  sources: range --start A --end B | wordlist --file F (string transforms: electrum[:change])\n"
                     "  --targets <FILE>     (scan) one address per line\n"
@@ -32,6 +33,9 @@ static int usage(const char *msg)
     return 2;
 }
 
+static uint64_t parse_u64(const char *s);
+static int run_analyze(int argc, char **argv);
+
 static uint64_t parse_u64(const char *s)
 {
     char *end = nullptr;
@@ -41,10 +45,71 @@ static uint64_t parse_u64(const char *s)
     return v;
 }
 
+// `vuke analyze KEY [--mask N] [--cascade b:t,...] [--analyzer milksad|lcg[:variant][:endian]|mt64]...` (src/main.rs:307-360)
+static int run_analyze(int argc, char **argv)
+{
+    std::string key_s, cascade_s;
+    std::vector<std::string> names;
+    std::optional<uint8_t> mask;
+    int device = 0;
+    uint64_t mt64_limit = (1ull << 40) - 1;
+    try {
+        for (int i = 2; i < argc; i++) {
+            std::string a = argv[i];
+            auto need = [&](const char *opt) -> const char * {
+                if (i + 1 >= argc) throw std::invalid_argument(std::string("a value is required for '") + opt + "'");
+                return argv[++i];
+            };
+            if (a == "--mask") {
+                int m = atoi(need("--mask"));
+                if (m < 1 || m > 64) throw std::invalid_argument("--mask must be 1..64");
+                mask = (uint8_t)m;
+            } else if (a == "--cascade") cascade_s = need("--cascade");
+            else if (a == "--analyzer") names.push_back(need("--analyzer"));
+            else if (a == "--device") device = atoi(need("--device"));
+            else if (a == "--mt64-limit") mt64_limit = parse_u64(need("--mt64-limit"));
+            else if (key_s.empty() && a[0] != '-') key_s = a;
+            else throw std::invalid_argument("unexpected argument '" + a + "'");
+        }
+        if (key_s.empty()) throw std::invalid_argument("analyze needs a KEY (hex, WIF or decimal)");
+        if (names.empty()) names = {"milksad", "lcg"};
+        Key key = parse_private_key(key_s);
+        AnalysisConfig cfg;
+        cfg.mask_bits = mask;
+        if (!cascade_s.empty()) cfg.cascade_targets = parse_cascade(cascade_s);
+        vk_engine *engine = nullptr;
+        vk_engine_opts opts{};
+        opts.window_bits = 8; // the analyzers never touch the k*G table: keep it tiny
+        if (vk_engine_create_ex(device, &opts, &engine) != VK_OK) {
+            fprintf(stderr, "GPU engine unavailable: %s\n", vk_last_error(nullptr));
+            return 1;
+        }
+        struct Guard { vk_engine *e; ~Guard() { vk_engine_destroy(e); } } guard{engine};
+        std::vector<AnalysisResult> results;
+        for (const std::string &n : names) {
+            if (n == "milksad") results.push_back(MilksadAnalyzer(engine).analyze(key, cfg));
+            else if (n == "mt64") results.push_back(Mt64Analyzer(engine, mt64_limit).analyze(key, cfg));
+            else if (n == "lcg" || n.rfind("lcg:", 0) == 0) {
+                Transform t = TransformType::from_str(n); // same grammar as the transform (src/lcg.rs:247-277)
+                results.push_back(LcgAnalyzer(engine, t.spec().variant, t.spec().endian).analyze(key, cfg));
+            } else throw std::invalid_argument("analyzer '" + n + "' is not on the device path (built: milksad, lcg[:variant][:endian], mt64)");
+        }
+        fputs(format_results(key, results).c_str(), stdout);
+        return 0;
+    } catch (const EngineError &e) {
+        fprintf(stderr, "Error: GPU engine failure (%d): %s\n", e.code, e.what());
+        return 1;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 2;
+    }
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) return usage(nullptr);
     const std::string cmd = argv[1];
+    if (cmd == "analyze") return run_analyze(argc, argv);
     if (cmd != "generate" && cmd != "scan" && cmd != "single") return usage("unknown subcommand");
     std::vector<std::string> tnames;
     std::string targets, outpath, single_value;

@@ -178,6 +178,64 @@ private:
 // Load a BIP-39 word list file (2048 whitespace-separated words of <= 8 bytes) into the engine (multibit transform).
 void load_bip39_wordlist(vk_engine *e, const std::string &path);
 
+// ---------------------------------------------------------------- analyze/ 
+enum class AnalysisStatus { Confirmed, Possible, NotFound, Unknown }; // src/analyze/mod.rs:48-59
+struct AnalysisResult {                                               // :36-45
+    const char *analyzer;
+    AnalysisStatus status;
+    std::string details;
+    const char *symbol() const;
+    const char *status_str() const;
+};
+struct AnalysisConfig { // :61-66
+    std::optional<uint8_t> mask_bits;
+    std::optional<std::vector<std::pair<uint8_t, uint64_t>>> cascade_targets;
+};
+class Analyzer { // :91-129
+public:
+    virtual ~Analyzer() = default;
+    virtual const char *name() const = 0;
+    virtual AnalysisResult analyze(const Key &key, const AnalysisConfig &config) const = 0;
+    virtual bool supports_mask() const { return false; }
+    virtual bool is_brute_force() const { return true; }
+    virtual bool supports_gpu() const { return true; }
+};
+class MilksadAnalyzer : public Analyzer {
+public:
+    explicit MilksadAnalyzer(vk_engine *e) : engine_(e) {}
+    const char *name() const override { return "milksad"; }
+    bool supports_mask() const override { return true; }
+    AnalysisResult analyze(const Key &key, const AnalysisConfig &config) const override;
+
+private:
+    vk_engine *engine_;
+};
+class LcgAnalyzer : public Analyzer {
+public:
+    LcgAnalyzer(vk_engine *e, uint32_t variant = VK_VARIANT_ALL, uint32_t little_endian = 0) : engine_(e), variant_(variant), endian_(little_endian) {}
+    const char *name() const override { return "lcg"; }
+    bool supports_mask() const override { return true; }
+    AnalysisResult analyze(const Key &key, const AnalysisConfig &config) const override;
+
+private:
+    vk_engine *engine_;
+    uint32_t variant_, endian_;
+};
+class Mt64Analyzer : public Analyzer {
+public:
+    // the reference walks 2^64 seeds until it finds one; `limit` bounds the sweep here
+    explicit Mt64Analyzer(vk_engine *e, uint64_t limit = (1ull << 40) - 1) : engine_(e), limit_(limit) {}
+    const char *name() const override { return "mt64"; }
+    AnalysisResult analyze(const Key &key, const AnalysisConfig &config) const override;
+
+private:
+    vk_engine *engine_;
+    uint64_t limit_;
+};
+Key parse_private_key(const std::string &input);                              // src/analyze/key_parser.rs:32-48
+std::vector<std::pair<uint8_t, uint64_t>> parse_cascade(const std::string &input); // :131-166
+std::string format_results(const Key &key, const std::vector<AnalysisResult> &results); // src/analyze/output.rs:3-25
+
 // error carrying the C ABI's code + message
 struct EngineError : std::runtime_error {
     int code;
