@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # rehearsal knobs (not used by the driver): run the N-rank path on a box with fewer GPUs than ranks
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal)")
+    ap.add_argument("--share-device", type=int, default=-1, help="put every rank on this one GPU (rehearsal only)")
     # table geometry of the flagship run: 9 signed-digit windows (120 GB of the 288 GB HBM, 8 point additions per
     # key), 128 keys per lane per field inversion, 3 resident workgroups per CU.  --layout 0 --window-bits 24 is the
     # library default (11.8 GB, 10 additions).
@@ -78,11 +81,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_device >= 0:
+        local_rank = args.share_device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     elif args.gpus != 1:
         print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
         sys.exit(2)
@@ -143,7 +151,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # counters: one tiny all-reduce over RCCL (the only collective on this path)
-    (total_keys, total_matches, total_expected), t = reduce_counters(dist, dev, [keys_done, matches, expected], elapsed)
+    red_dev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")
+    (total_keys, total_matches, total_expected), t = reduce_counters(dist, red_dev, [keys_done, matches, expected], elapsed)
     if total_matches != total_expected:
         print(f"bench.py: PARITY FAILURE: {total_matches} matches, {total_expected} planted seeds in range", file=sys.stderr)
         sys.exit(3)
