@@ -103,6 +103,13 @@ def test_codecs_match_oracle(host, vko):
         d = C.create_string_buffer(32)
         host.vkh_sha256(msg, len(msg), d)
         assert d.raw == vko.sha256(msg)
+    # leading zero bytes, tiny values and every payload length the 58^5-radix encoder splits differently
+    out = C.create_string_buffer(128)
+    for n in range(1, 41):
+        for z in (0, 1, min(n, 3), n):
+            p = bytes(z) + bytes(rnd.getrandbits(8) | 1 for _ in range(n - z))
+            host.vkh_base58check_encode(p, len(p), out, 128)
+            assert out.value.decode() == vko.base58check_encode(p), (n, z)
     dec = C.create_string_buffer(64)
     assert host.vkh_base58check_decode(b"1NonExistentAddress", dec, 64) == -1
     assert host.vkh_base58check_decode(b"1JwSSubhmg6iPtRjtyqhUYYH7bZg3Lfy1U", dec, 64) == -1

@@ -6,6 +6,7 @@
 
 #include <array>
 #include <cstring>
+#include <stdexcept>
 
 namespace vuke {
 
@@ -79,29 +80,45 @@ static const char B58[] = "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstu
 
 std::string base58check_encode(const uint8_t *payload, size_t len)
 {
-    std::vector<uint8_t> buf(payload, payload + len);
+    if (len > 60) throw std::invalid_argument("base58check payload too long");
+    uint8_t buf[64];
+    memcpy(buf, payload, len);
     uint8_t d1[32], d2[32];
     sha256(payload, len, d1);
     sha256(d1, 32, d2);
-    buf.insert(buf.end(), d2, d2 + 4);
+    memcpy(buf + len, d2, 4);
+    const size_t total = len + 4;
     size_t zeros = 0;
-    while (zeros < buf.size() && buf[zeros] == 0) zeros++;
-    // repeated division of the big-endian number by 58
-    std::vector<uint8_t> num(buf.begin() + zeros, buf.end());
-    std::string out;
-    size_t start = 0;
-    while (start < num.size()) {
-        uint32_t rem = 0;
-        for (size_t i = start; i < num.size(); i++) {
-            uint32_t cur = rem * 256 + num[i];
-            num[i] = (uint8_t)(cur / 58);
-            rem = cur % 58;
-        }
-        out.push_back(B58[rem]);
-        while (start < num.size() && num[start] == 0) start++;
+    while (zeros < total && buf[zeros] == 0) zeros++;
+    // big-endian u32 limbs of the non-zero tail, divided by 58^5 per pass (five characters per division sweep)
+    uint32_t limb[16];
+    const size_t nb = total - zeros, nl = (nb + 3) / 4;
+    for (size_t i = 0; i < nl; i++) limb[i] = 0;
+    for (size_t i = 0; i < nb; i++) {
+        const size_t pos = nb - 1 - i; // byte significance
+        limb[nl - 1 - pos / 4] |= (uint32_t)buf[zeros + i] << (8 * (pos % 4));
     }
-    out.append(zeros, '1');
-    return std::string(out.rbegin(), out.rend());
+    char rev[96];
+    size_t n = 0, start = 0;
+    while (start < nl) {
+        uint64_t rem = 0;
+        for (size_t i = start; i < nl; i++) {
+            const uint64_t cur = (rem << 32) | limb[i];
+            limb[i] = (uint32_t)(cur / 656356768u); // 58^5
+            rem = cur % 656356768u;
+        }
+        while (start < nl && limb[start] == 0) start++;
+        uint32_t r = (uint32_t)rem;
+        for (int k = 0; k < 5; k++) {
+            if (start >= nl && r == 0) break; // most significant group: no leading '1's from the number itself
+            rev[n++] = B58[r % 58];
+            r /= 58;
+        }
+    }
+    for (size_t i = 0; i < zeros; i++) rev[n++] = '1';
+    std::string out(n, '1');
+    for (size_t i = 0; i < n; i++) out[i] = rev[n - 1 - i];
+    return out;
 }
 
 bool base58check_decode(const std::string &s, std::vector<uint8_t> &out)

@@ -52,8 +52,8 @@ std::vector<DerivedKey> KeyDeriver::derive(const std::vector<Key> &keys) const
     std::vector<uint8_t> in(n * 32), norm(n * 32), hc(n * 20), hu(n * 20);
     for (size_t i = 0; i < n; i++) memcpy(&in[32 * i], keys[i].data(), 32);
     check_rc(engine_, vk_derive_batch(engine_, in.data(), n, norm.data(), hc.data(), hu.data()));
-    out.reserve(n);
-    for (size_t i = 0; i < n; i++) out.push_back(from_device(&norm[32 * i], &hc[20 * i], &hu[20 * i]));
+    out.resize(n);
+    for (size_t i = 0; i < n; i++) out[i] = from_device(&norm[32 * i], &hc[20 * i], &hu[20 * i]);
     return out;
 }
 

@@ -8,8 +8,32 @@
 #include <algorithm>
 #include <cstring>
 #include <fstream>
+#include <thread>
 
 namespace vuke {
+
+// The text encodings of a key (base58check x4, bech32, decimal, binary) cost more host time than the
+// device spends deriving it, so generate mode formats a chunk on every host core (the reference does
+// the same work under rayon, src/source/range.rs:44-70) and then writes the chunk in input order.
+template <typename F>
+static void parallel_for(size_t n, F fn)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 64) nt = 64;
+    if (n < 4096 || nt == 1) {
+        fn(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const size_t a = (size_t)t * per, b = std::min(n, a + per);
+        if (a >= b) break;
+        th.emplace_back([=]() { fn(a, b); });
+    }
+    for (auto &x : th) x.join();
+}
 
 // shared by the string-capable paths: keys (with labels) -> derive on the device -> match / emit
 static void emit_keys(vk_engine *engine, const Transform &t, const std::vector<std::pair<std::string, Key>> &batch, const Matcher *matcher,
@@ -138,7 +162,7 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
         }
         check_rc(engine_, vk_targets_set(engine_, nullptr, nullptr, 0));
     } else {
-        const uint64_t chunk = 1ull << 18; // inputs per vk_generate call (host buffers: 72 B per key)
+        const uint64_t chunk = 1ull << 16; // inputs per vk_generate call (host: 72 B raw + ~1 KB of text per key)
         for (uint64_t lo = start;; lo += chunk) {
             const uint64_t hi = (end - lo < chunk - 1) ? end : lo + chunk - 1;
             for (const Transform &t : transforms) {
@@ -156,11 +180,13 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
                 vk_sweep_stats ss;
                 check_rc(engine_, vk_generate(engine_, &t.spec(), lo, hi, flags, priv.data(), hc.data(), hu.data(), valid.data(), &ss));
                 st.keys_generated += ss.keys;
-                for (size_t i = 0; i < n; i++) {
-                    if (!valid[i]) continue;
-                    DerivedKey d = KeyDeriver::from_device(&priv[32 * i], &hc[20 * i], &hu[20 * i]);
-                    output.key(t.label(lo + i / k, (uint32_t)(i % k)), t.name(), d);
-                }
+                std::vector<DerivedKey> derived(n);
+                parallel_for(n, [&](size_t a, size_t b) {
+                    for (size_t i = a; i < b; i++)
+                        if (valid[i]) derived[i] = KeyDeriver::from_device(&priv[32 * i], &hc[20 * i], &hu[20 * i]);
+                });
+                for (size_t i = 0; i < n; i++)
+                    if (valid[i]) output.key(t.label(lo + i / k, (uint32_t)(i % k)), t.name(), derived[i]);
             }
             if (hi == end) break;
         }
