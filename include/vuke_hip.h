@@ -182,10 +182,13 @@ int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t
 int vk_scan_keys(vk_engine *e, const uint8_t *keys /* n*32 */, size_t n, uint32_t flags, vk_hit *hits, size_t hit_cap,
                  vk_sweep_stats *out);
 
-/* ---- analyzer brute force (reference src/analyze/{milksad,lcg,mt64}.rs) -------------------
+/* ---- analyzer brute force (reference src/analyze/{milksad,lcg,mt64,xorshift,sha256_chain}.rs)
  * Smallest seed in [seed_lo, seed_hi] whose generated key(s) satisfy the target.  Kinds: VK_T_MILKSAD, VK_T_MT64,
- * VK_T_LCG (one variant: spec.variant 0..3, spec.endian).  The reference reports whichever matching seed a worker
- * thread finds first; this search reports the smallest, which is one of the reference's possible answers. */
+ * VK_T_LCG (one variant: spec.variant 0..3, spec.endian), VK_T_XORSHIFT (one variant, cascade only) and
+ * VK_T_SHA256_CHAIN (u32 seeds hashed as 4 big-endian bytes; spec.variant 0..3 or VK_VARIANT_ALL; exact / masked look
+ * at every key of the chain of spec.chain_depth, cascade compares chain[j] with target j).  The reference reports
+ * whichever matching seed a worker thread finds first; this search reports the smallest, which is one of the
+ * reference's possible answers; for sha256_chain the (variant, index) is the first in the reference's loop order. */
 #define VK_SEARCH_EXACT 0u   /* key == target.key                                     (analyze_exact) */
 #define VK_SEARCH_MASKED 1u  /* ((last 8 key bytes, BE) & (2^bits-1)) | 2^(bits-1) == last 8 bytes of target.key  (analyze_masked) */
 #define VK_SEARCH_CASCADE 2u /* draws j = 0..n-1 of one generator instance: masked(draw j, bits[j]) == targets[j]  (analyze_cascading) */
@@ -205,6 +208,8 @@ typedef struct vk_search_result {
     uint64_t seeds_checked; /* whole range when nothing was found */
     double kernel_seconds;
     uint8_t keys[8][32];    /* the generated key(s) of the reported seed */
+    uint32_t variant;       /* sha256_chain: variant that matched (0 iterated, 1 indexed:be, 2 indexed:le, 3 counter) */
+    uint32_t index;         /* sha256_chain exact / masked: chain index of keys[0] */
 } vk_search_result;
 int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_t seed_hi_inclusive,
               const vk_search_target *target, vk_search_result *out);

@@ -331,25 +331,101 @@ static int masked_eq(const uint8_t *k, uint32_t bits, uint64_t target)
     return ((last8_be(k) & mask) | high) == target;
 }
 
+/* nd successive 32-byte fills of one xorshift-family generator instance (src/analyze/xorshift.rs:187-206):
+ * fill_bytes continues the stream, so draw j is outputs [4j, 4j+4) (u64 variants) or [8j, 8j+8) (xorshift128). */
+void vko_xorshift_draws(uint64_t seed, uint32_t variant, uint32_t nd, uint8_t *out)
+{
+    if (seed == 0) seed = 1;
+    if (variant == 0) {
+        uint64_t x = seed;
+        for (uint32_t i = 0; i < 4 * nd; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; put_be64(out + 8 * i, x); }
+    } else if (variant == 1) {
+        uint32_t x = (uint32_t)seed, y = (uint32_t)(seed >> 32);
+        uint32_t z = (uint32_t)seed ^ 0x12345678u, w = (uint32_t)(seed >> 32) ^ 0x87654321u;
+        for (uint32_t i = 0; i < 8 * nd; i++) {
+            uint32_t t = x ^ (x << 11);
+            x = y; y = z; z = w;
+            w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+            put_be32(out + 4 * i, w);
+        }
+    } else {
+        uint64_t s0 = splitmix64(seed), s1 = splitmix64(s0);
+        for (uint32_t i = 0; i < 4 * nd; i++) {
+            uint64_t r = (variant == 2) ? s0 + s1 : rotl64(s0 * 5, 7) * 9;
+            uint64_t t = s1 ^ s0;
+            s0 = rotl64(s0, 24) ^ t ^ (t << 16);
+            s1 = rotl64(t, 37);
+            put_be64(out + 8 * i, r);
+        }
+    }
+}
+
+/* sha256_chain analyzer for one u32 seed (src/analyze/sha256_chain.rs:48-425): variants in order, chain index
+ * ascending, first match wins.  exact / masked: any key of generate_chain(seed_be4, v, depth); cascade: chain[j] vs
+ * target j with depth = n.  On a match: *variant, *index (0 for cascade) and the key(s) the reference prints. */
+static int chain_seed_match(const vko_spec *spec, uint32_t seed, uint32_t mode, const uint8_t key[32], uint32_t n, const uint8_t *bits,
+                            const uint64_t *targets, uint32_t *variant, uint32_t *index, uint8_t *keys_out)
+{
+    uint8_t be[4];
+    put_be32(be, seed);
+    uint32_t v0 = spec->variant == VKO_VARIANT_ALL ? 0 : spec->variant, v1 = spec->variant == VKO_VARIANT_ALL ? 3 : spec->variant;
+    uint32_t depth = mode == 2 ? n : spec->chain_depth;
+    for (uint32_t v = v0; v <= v1; v++) {
+        uint8_t chain[8 * 32];
+        int all = 1;
+        for (uint32_t idx = 0; idx < depth; idx++) {
+            uint8_t k[32];
+            vko_sha256_chain_key(be, 4, v, idx, k);
+            if (mode == 0 ? memcmp(k, key, 32) == 0 : mode == 1 ? masked_eq(k, bits[0], last8_be(key)) : 0) {
+                *variant = v; *index = idx;
+                if (keys_out) memcpy(keys_out, k, 32);
+                return 1;
+            }
+            if (mode == 2) {
+                if (!masked_eq(k, bits[idx], targets[idx])) { all = 0; break; }
+                memcpy(chain + 32 * idx, k, 32);
+            }
+        }
+        if (mode == 2 && all) {
+            *variant = v; *index = 0;
+            if (keys_out) memcpy(keys_out, chain, 32 * n);
+            return 1;
+        }
+    }
+    return 0;
+}
+
 /* smallest seed in [lo, hi] matching; mode 0 exact (key), 1 masked (key, bits[0]), 2 cascade (n, bits, targets).
- * kind: VKO_T_MILKSAD, VKO_T_MT64, VKO_T_LCG (spec->variant single, spec->endian).  Returns 1 and *seed when found. */
+ * kind: VKO_T_MILKSAD, VKO_T_MT64, VKO_T_LCG (spec->variant single, spec->endian), VKO_T_XORSHIFT (single variant),
+ * VKO_T_SHA256_CHAIN (variant single or all; vi[0] = matching variant, vi[1] = chain index).  Returns 1 and *seed. */
 int vko_search(const vko_spec *spec, uint64_t lo, uint64_t hi, uint32_t mode, const uint8_t key[32], uint32_t n,
-               const uint8_t *bits, const uint64_t *targets, uint64_t *seed_out, uint8_t *keys_out /* n*32 */)
+               const uint8_t *bits, const uint64_t *targets, uint64_t *seed_out, uint8_t *keys_out /* n*32 */, uint32_t vi[2])
 {
     uint32_t nd = mode == 2 ? n : 1;
+    if (nd > 8) return -1;
     for (uint64_t s = lo;; s++) {
         uint8_t d[8 * 32];
         int have = 1;
-        if (spec->kind == VKO_T_MILKSAD) { if (s > 0xFFFFFFFFULL) have = 0; else vko_milksad_draws((uint32_t)s, nd, d); }
+        if (spec->kind == VKO_T_SHA256_CHAIN) {
+            uint32_t v = 0, ix = 0;
+            if (s <= 0xFFFFFFFFULL && chain_seed_match(spec, (uint32_t)s, mode, key, n, bits, targets, &v, &ix, keys_out)) {
+                *seed_out = s;
+                if (vi) { vi[0] = v; vi[1] = ix; }
+                return 1;
+            }
+            have = 0;
+        }
+        else if (spec->kind == VKO_T_MILKSAD) { if (s > 0xFFFFFFFFULL) have = 0; else vko_milksad_draws((uint32_t)s, nd, d); }
         else if (spec->kind == VKO_T_MT64) vko_mt64_draws(s, nd, d);
         else if (spec->kind == VKO_T_LCG) have = vko_lcg_key(s, spec->variant, spec->endian, d);
+        else if (spec->kind == VKO_T_XORSHIFT) { if (spec->variant > 3) return -1; vko_xorshift_draws(s, spec->variant, nd, d); }
         else return -1;
         if (have) {
             int ok = 1;
             if (mode == 0) ok = memcmp(d, key, 32) == 0;
             else if (mode == 1) ok = masked_eq(d, bits[0], last8_be(key));
             else for (uint32_t j = 0; j < n && ok; j++) ok = masked_eq(d + 32 * j, bits[j], targets[j]);
-            if (ok) { *seed_out = s; if (keys_out) memcpy(keys_out, d, 32 * nd); return 1; }
+            if (ok) { *seed_out = s; if (keys_out) memcpy(keys_out, d, 32 * nd); if (vi) { vi[0] = spec->variant; vi[1] = 0; } return 1; }
         }
         if (s == hi) break;
     }

@@ -79,11 +79,12 @@ int vko_transform_label(const vko_spec *spec, uint64_t seed, uint32_t sub_index,
 /* Transform::name() */
 const char *vko_transform_name(const vko_spec *spec);
 
-/* analyzer brute force (src/analyze/{milksad,lcg,mt64}.rs): successive draws and the smallest matching seed */
+/* analyzer brute force (src/analyze/{milksad,lcg,mt64,xorshift,sha256_chain}.rs): successive draws and the smallest matching seed */
 void vko_milksad_draws(uint32_t seed, uint32_t ndraws, uint8_t *out);
 void vko_mt64_draws(uint64_t seed, uint32_t ndraws, uint8_t *out);
+void vko_xorshift_draws(uint64_t seed, uint32_t variant, uint32_t ndraws, uint8_t *out);
 int vko_search(const vko_spec *spec, uint64_t lo, uint64_t hi, uint32_t mode, const uint8_t key[32], uint32_t n,
-               const uint8_t *bits, const uint64_t *targets, uint64_t *seed_out, uint8_t *keys_out);
+               const uint8_t *bits, const uint64_t *targets, uint64_t *seed_out, uint8_t *keys_out, uint32_t variant_index[2]);
 
 /* Electrum v1 (src/electrum.rs, src/transform/electrum.rs); rounds = 100000 in the reference */
 void vko_electrum_stretch(const uint8_t *seed, size_t len, uint32_t rounds, uint8_t out[32]);

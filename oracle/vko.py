@@ -104,7 +104,8 @@ def lib():
         L.vko_multibit_label.argtypes = [cp, u32, cp, sz]
         L.vko_milksad_draws.argtypes = [u32, u32, cp]
         L.vko_mt64_draws.argtypes = [u64, u32, cp]
-        L.vko_search.argtypes = [C.POINTER(Spec), u64, u64, u32, cp, u32, cp, C.POINTER(u64), C.POINTER(u64), cp]
+        L.vko_search.argtypes = [C.POINTER(Spec), u64, u64, u32, cp, u32, cp, C.POINTER(u64), C.POINTER(u64), cp, C.POINTER(u32)]
+        L.vko_xorshift_draws.argtypes = [u64, u32, u32, cp]
         _ = (u8p, u64)
         _lib = L
     return _lib
@@ -218,8 +219,15 @@ def mt64_draws(seed, n):
     return [o.raw[32 * i:32 * i + 32] for i in range(n)]
 
 
-def search(sp, lo, hi, key=None, mask_bits=None, cascade=None):
-    """Analyzer brute force on the CPU: (seed, [keys]) of the smallest matching seed in [lo, hi], or None."""
+def xorshift_draws(seed, variant, n):
+    o = _out(32 * n)
+    lib().vko_xorshift_draws(seed, variant, n, o)
+    return [o.raw[32 * i:32 * i + 32] for i in range(n)]
+
+
+def search(sp, lo, hi, key=None, mask_bits=None, cascade=None, detail=False):
+    """Analyzer brute force on the CPU: (seed, [keys]) of the smallest matching seed in [lo, hi], or None.
+    detail=True appends (variant, chain_index) -- meaningful for sha256_chain."""
     if cascade is not None:
         mode, n = 2, len(cascade)
         bits = bytes(b for b, _ in cascade)
@@ -230,10 +238,12 @@ def search(sp, lo, hi, key=None, mask_bits=None, cascade=None):
         bits = bytes([mask_bits or 0])
         targets = (C.c_uint64 * 1)(0)
     seed, keys = C.c_uint64(), _out(32 * 8)
-    r = lib().vko_search(C.byref(sp), lo, hi, mode, key, n, bits, targets, C.byref(seed), keys)
+    vi = (C.c_uint32 * 2)()
+    r = lib().vko_search(C.byref(sp), lo, hi, mode, key, n, bits, targets, C.byref(seed), keys, vi)
     if r != 1:
         return None
-    return seed.value, [keys.raw[32 * i:32 * i + 32] for i in range(n)]
+    ks = [keys.raw[32 * i:32 * i + 32] for i in range(n)]
+    return (seed.value, ks, (vi[0], vi[1])) if detail else (seed.value, ks)
 
 
 class Wordlist:

@@ -408,3 +408,63 @@ def test_analyzer_search(eng, vko):
     casc = [(8, masked(d[0], 8)), (16, masked(d[1], 16)), (24, masked(d[2], 24))]
     r = eng.search(ffi.spec(ffi.T_MT64), 2**40, 2**40 + 10**6, cascade=casc)
     assert r["found"] and r["seed"] == 2**40 + 99 and r["keys"] == d
+
+
+def test_analyzer_search_xorshift_and_sha256_chain(eng, vko):
+    """SURVEY 8(f) rank 1, the remaining analyzers: xorshift cascade (src/analyze/xorshift.rs) and sha256_chain
+    exact / masked / cascade over all 2^32 four-byte seeds (src/analyze/sha256_chain.rs:686-810)."""
+    import hashlib
+    from vuke_amd import _ffi as ffi
+
+    def masked(key, bits):
+        k = int.from_bytes(key[24:], "big")
+        return (k & ((1 << bits) - 1)) | (1 << (bits - 1))
+
+    for variant in range(4):
+        base = 2**41 + variant
+        d = vko.xorshift_draws(base + 123456, variant, 8)
+        casc = [(8 + 4 * j, masked(d[j], 8 + 4 * j)) for j in range(8)]
+        for n in (1, 3, 8):
+            got = eng.search(ffi.spec(ffi.T_XORSHIFT, variant), base, base + 300000, cascade=casc[:n])
+            want = vko.search(vko.spec(vko.T_XORSHIFT, variant), base, base + 300000, cascade=casc[:n])
+            assert got["found"] and (got["seed"], got["keys"]) == (want[0], want[1]), (variant, n)
+        r = eng.search(ffi.spec(ffi.T_XORSHIFT, variant), 0, 2**30, cascade=[(64, 2**63 + 12345), (64, 2**63 + 1)])
+        assert not r["found"] and r["seeds_checked"] == 2**30 + 1
+    with pytest.raises(Exception):
+        eng.search(ffi.spec(ffi.T_XORSHIFT, 0), 0, 10, key=bytes(32))     # cascade only, like the reference
+
+    def chain(seed, variant, depth):
+        s, out = seed.to_bytes(4, "big"), []
+        for i in range(depth):
+            tail = [None, i.to_bytes(4, "big"), i.to_bytes(4, "little"), str(i).encode()][variant]
+            out.append(hashlib.sha256((out[-1] if out else s) if variant == 0 else s + tail).digest())
+        return out
+
+    # exact, full 2^32 range, every variant tried (default analyzer): reference test_find_known_seed_exact
+    key = chain(12345, 0, 5)[2]
+    r = eng.search(ffi.spec(ffi.T_SHA256_CHAIN, chain_depth=5), 0, 2**32 - 1, key=key)
+    assert (r["found"], r["seed"], r["variant"], r["index"], r["keys"]) == (True, 12345, 0, 2, [key])
+    key = chain(4_000_000_123, 3, 10)[9]
+    r = eng.search(ffi.spec(ffi.T_SHA256_CHAIN, 3, 0, 10), 0, 2**32 - 1, key=key)
+    assert (r["found"], r["seed"], r["variant"], r["index"], r["keys"]) == (True, 4_000_000_123, 3, 9, [key])
+    assert not eng.search(ffi.spec(ffi.T_SHA256_CHAIN, 3, 0, 9), 3_999_000_000, 2**32 - 1, key=key)["found"]   # depth too short
+    # masked / cascade / exact vs the oracle on bounded ranges: smallest seed, and the first (variant, index) in loop order
+    for variant in (ffi.VARIANT_ALL, 0, 1, 2, 3):
+        gs, os_ = ffi.spec(ffi.T_SHA256_CHAIN, variant, 0, 6), vko.spec(vko.T_SHA256_CHAIN, variant, 0, 6)
+        for bits, target in ((6, 0x2a), (12, 0xabc), (20, 0x9abcd)):
+            tk = target.to_bytes(32, "big")
+            want = vko.search(os_, 10**6, 10**6 + 60000, key=tk, mask_bits=bits, detail=True)
+            got = eng.search(gs, 10**6, 10**6 + 60000, key=tk, mask_bits=bits)
+            assert got["found"] == (want is not None), (variant, bits)
+            if want:
+                assert (got["seed"], got["keys"], (got["variant"], got["index"])) == want, (variant, bits)
+        v = 2 if variant == ffi.VARIANT_ALL else variant
+        ch = chain(10**6 + 4321, v, 8)
+        casc = [(5 + 2 * j, masked(ch[j], 5 + 2 * j)) for j in range(8)]
+        for n in (2, 3, 8):
+            want = vko.search(os_, 10**6, 10**6 + 60000, cascade=casc[:n], detail=True)
+            got = eng.search(gs, 10**6, 10**6 + 60000, cascade=casc[:n])
+            assert (got["seed"], got["keys"], (got["variant"], got["index"])) == want, (variant, n)
+        k = ch[5]
+        got = eng.search(gs, 10**6, 10**6 + 60000, key=k)
+        assert (got["seed"], got["variant"], got["index"], got["keys"]) == (10**6 + 4321, v, 5, [k])

@@ -39,3 +39,52 @@ def test_search_modes(vko):
     d = vko.mt64_draws(777, 3)
     casc = [(8, masked(d[0], 8)), (16, masked(d[1], 16)), (24, masked(d[2], 24))]
     assert vko.search(sp, 0, 2000, cascade=casc) == (777, d)
+
+
+def _chain(seed, variant, depth):
+    """generate_chain(seed.to_be_bytes(), variant, depth) restated with hashlib (src/sha256_chain.rs:88-145)."""
+    import hashlib
+    s = seed.to_bytes(4, "big")
+    out = []
+    for i in range(depth):
+        if variant == 0:
+            out.append(hashlib.sha256(out[-1] if out else s).digest())
+        elif variant == 1:
+            out.append(hashlib.sha256(s + i.to_bytes(4, "big")).digest())
+        elif variant == 2:
+            out.append(hashlib.sha256(s + i.to_bytes(4, "little")).digest())
+        else:
+            out.append(hashlib.sha256(s + str(i).encode()).digest())
+    return out
+
+
+def test_xorshift_cascade(vko):
+    for variant in range(4):
+        for seed in (0, 1, 77, 2**40 + 5, 2**64 - 1):
+            d = vko.xorshift_draws(seed, variant, 4)
+            assert d[0] == vko.xorshift_key(seed, variant) and len(set(d)) == 4
+        # src/analyze/xorshift.rs tests: a cascade built from a known seed finds it
+        d = vko.xorshift_draws(3000, variant, 3)
+        casc = [(8, masked(d[0], 8)), (16, masked(d[1], 16)), (24, masked(d[2], 24))]
+        assert vko.search(vko.spec(vko.T_XORSHIFT, variant), 0, 5000, cascade=casc) == (3000, d)
+    assert vko.xorshift_draws(0, 0, 2) == vko.xorshift_draws(1, 0, 2)    # seed 0 is mapped to 1
+
+
+def test_sha256_chain_search_reference_cases(vko):
+    # src/analyze/sha256_chain.rs:686-810 (the reference's #[ignore]d full-range tests, on bounded ranges here)
+    key = _chain(12345, 0, 5)[2]
+    assert vko.search(vko.spec(vko.T_SHA256_CHAIN, 0, 0, 5), 12000, 13000, key=key, detail=True) == (12345, [key], (0, 2))
+    assert vko.search(vko.spec(vko.T_SHA256_CHAIN, 0, 0, 2), 12000, 13000, key=key) is None           # depth too short
+    full = _chain(42, 0, 3)[0]
+    tkey = bytes(24) + masked(full, 10).to_bytes(8, "big")
+    seed, keys, (v, idx) = vko.search(vko.spec(vko.T_SHA256_CHAIN, 0, 0, 3), 0, 42, key=tkey, mask_bits=10, detail=True)
+    assert seed <= 42 and masked(keys[0], 10) == masked(full, 10) and keys[0] == _chain(seed, 0, 3)[idx] and v == 0
+    for known, variant in ((100, 0), (500, 1), (999, 3), (0, 0), (321, 2)):
+        ch = _chain(known, variant, 3)
+        casc = [(5, masked(ch[0], 5)), (10, masked(ch[1], 10)), (15, masked(ch[2], 15))]
+        seed, keys, (v, _) = vko.search(vko.spec(vko.T_SHA256_CHAIN, variant), 0, known, cascade=casc, detail=True)
+        assert seed <= known and v == variant and keys == _chain(seed, variant, 3)
+        assert [masked(k, b) for k, (b, _) in zip(keys, casc)] == [t for _, t in casc]
+    # all variants: the first variant in ALL_VARIANTS order that matches is the one reported
+    key = _chain(777, 2, 10)[9]
+    assert vko.search(vko.spec(vko.T_SHA256_CHAIN), 700, 800, key=key, detail=True) == (777, [key], (2, 9))

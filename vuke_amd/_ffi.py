@@ -52,7 +52,7 @@ class SearchTarget(C.Structure):
 
 class SearchResult(C.Structure):
     _fields_ = [("found", C.c_uint32), ("n_keys", C.c_uint32), ("seed", C.c_uint64), ("seeds_checked", C.c_uint64),
-                ("kernel_seconds", C.c_double), ("keys", (C.c_uint8 * 32) * 8)]
+                ("kernel_seconds", C.c_double), ("keys", (C.c_uint8 * 32) * 8), ("variant", C.c_uint32), ("index", C.c_uint32)]
 
 
 SEARCH_EXACT, SEARCH_MASKED, SEARCH_CASCADE = 0, 1, 2
@@ -232,7 +232,7 @@ class Engine:
         r = SearchResult()
         self._chk(self._L.vk_search(self._e, C.byref(spec), lo, hi, C.byref(tg), C.byref(r)))
         return dict(found=bool(r.found), seed=r.seed, seeds_checked=r.seeds_checked, kernel_seconds=r.kernel_seconds,
-                    keys=[bytes(r.keys[j]) for j in range(r.n_keys)])
+                    keys=[bytes(r.keys[j]) for j in range(r.n_keys)], variant=r.variant, index=r.index)
 
     def table_entry(self, window, digit):
         xy = C.create_string_buffer(64)

@@ -774,9 +774,19 @@ extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
     std::lock_guard<std::mutex> lk(e->mu);
     if (!t || !tg || !out) return fail(e, VK_E_INVALID_ARG, "spec / target / out is NULL");
     if (hi < lo) return fail(e, VK_E_INVALID_ARG, "seed_hi < seed_lo");
-    if (t->kind != VK_T_MILKSAD && t->kind != VK_T_MT64 && t->kind != VK_T_LCG)
-        return fail(e, VK_E_UNSUPPORTED, "vk_search is built for milksad, mt64 and lcg");
+    if (t->kind != VK_T_MILKSAD && t->kind != VK_T_MT64 && t->kind != VK_T_LCG && t->kind != VK_T_XORSHIFT && t->kind != VK_T_SHA256_CHAIN)
+        return fail(e, VK_E_UNSUPPORTED, "vk_search is built for milksad, mt64, lcg, xorshift and sha256_chain");
     if (t->kind == VK_T_LCG && (t->variant > 3 || t->endian > 1)) return fail(e, VK_E_INVALID_ARG, "lcg search takes one variant (0..3) and an endian");
+    if (t->kind == VK_T_XORSHIFT) {
+        if (t->variant > 3) return fail(e, VK_E_INVALID_ARG, "xorshift search takes one variant (0..3)");
+        if (tg->mode != VK_SEARCH_CASCADE) return fail(e, VK_E_UNSUPPORTED, "the xorshift analyzer has cascade mode only (64-bit seed space)");
+    }
+    if (t->kind == VK_T_SHA256_CHAIN) {
+        if (t->variant != VK_VARIANT_ALL && t->variant > 3) return fail(e, VK_E_INVALID_ARG, "sha256_chain variant must be 0..3 or VK_VARIANT_ALL");
+        if (tg->mode != VK_SEARCH_CASCADE && (t->chain_depth == 0 || t->chain_depth > 4096)) return fail(e, VK_E_INVALID_ARG, "chain_depth must be 1..4096");
+        if (lo > 0xFFFFFFFFull) return fail(e, VK_E_INVALID_ARG, "sha256_chain search takes u32 seeds");
+        if (hi > 0xFFFFFFFFull) hi = 0xFFFFFFFFull;
+    }
     if (tg->mode > VK_SEARCH_CASCADE) return fail(e, VK_E_INVALID_ARG, "unknown search mode");
     if (tg->mode == VK_SEARCH_MASKED && (tg->mask_bits < 1 || tg->mask_bits > 64)) return fail(e, VK_E_INVALID_ARG, "mask_bits must be 1..64");
     if (tg->mode == VK_SEARCH_CASCADE) {
@@ -818,6 +828,8 @@ extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
         HIPCHK(e, hipEventRecord(e->ev0, e->stream));
         if (t->kind == VK_T_MILKSAD) wide ? launch_search<VK_T_MILKSAD, 8>(p, grid, e->stream) : launch_search<VK_T_MILKSAD, 1>(p, grid, e->stream);
         else if (t->kind == VK_T_MT64) wide ? launch_search<VK_T_MT64, 8>(p, grid, e->stream) : launch_search<VK_T_MT64, 1>(p, grid, e->stream);
+        else if (t->kind == VK_T_XORSHIFT) wide ? launch_search<VK_T_XORSHIFT, 8>(p, grid, e->stream) : launch_search<VK_T_XORSHIFT, 1>(p, grid, e->stream);
+        else if (t->kind == VK_T_SHA256_CHAIN) launch_search<VK_T_SHA256_CHAIN, 1>(p, grid, e->stream);
         else launch_search<VK_T_LCG, 1>(p, grid, e->stream);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipEventRecord(e->ev1, e->stream));
@@ -836,17 +848,24 @@ extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
     out->seed = best;
     out->n_keys = p.ndraws;
     u32 *d_out = nullptr;
-    HIPCHK(e, hipMalloc(&d_out, 8 * 32));
-    hipError_t c = hipMemsetAsync(d_out, 0, 8 * 32, e->stream);
+    u32 h_out[66];
+    HIPCHK(e, hipMalloc(&d_out, sizeof h_out));
+    hipError_t c = hipMemsetAsync(d_out, 0, sizeof h_out, e->stream);
     if (c == hipSuccess) {
         if (t->kind == VK_T_MILKSAD) launch_emit<VK_T_MILKSAD, 8>(p.spec, best, d_out, e->stream);
         else if (t->kind == VK_T_MT64) launch_emit<VK_T_MT64, 8>(p.spec, best, d_out, e->stream);
+        else if (t->kind == VK_T_XORSHIFT) launch_emit<VK_T_XORSHIFT, 8>(p.spec, best, d_out, e->stream);
+        else if (t->kind == VK_T_SHA256_CHAIN) hipLaunchKernelGGL(vk_search_emit_chain_kernel, dim3(1), dim3(64), 0, e->stream, p, best, d_out);
         else launch_emit<VK_T_LCG, 1>(p.spec, best, d_out, e->stream);
         c = hipGetLastError();
     }
     if (c == hipSuccess) c = hipStreamSynchronize(e->stream);
-    if (c == hipSuccess) c = hipMemcpy(out->keys, d_out, 8 * 32, hipMemcpyDeviceToHost);
+    if (c == hipSuccess) c = hipMemcpy(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost);
     (void)hipFree(d_out);
+    memcpy(out->keys, h_out, 8 * 32);
+    out->variant = t->kind == VK_T_SHA256_CHAIN ? h_out[64] : (t->variant == VK_VARIANT_ALL ? 0u : t->variant);
+    out->index = t->kind == VK_T_SHA256_CHAIN ? h_out[65] : 0u;
+    if (t->kind == VK_T_SHA256_CHAIN && tg->mode != VK_SEARCH_CASCADE) out->n_keys = 1;
     if (c != hipSuccess) {
         e->err = std::string("vk_search: ") + hipGetErrorString(c);
         return VK_E_HIP;

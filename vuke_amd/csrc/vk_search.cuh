@@ -4,6 +4,8 @@
 //   milksad  exact / masked / cascade   src/analyze/milksad.rs:69-366
 //   lcg      exact / masked             src/analyze/lcg.rs:49-210 (one variant per launch)
 //   mt64     cascade                    src/analyze/mt64.rs:60-215
+//   xorshift cascade (one variant per launch)             src/analyze/xorshift.rs:30-206
+//   sha256_chain exact / masked / cascade, u32 seeds as 4 BE bytes    src/analyze/sha256_chain.rs:48-425
 // masked:  ((last 8 key bytes as BE u64) & (2^bits - 1)) | 2^(bits-1) == target
 // cascade: successive 32-byte draws of one generator instance, draw j masked with bits[j] == targets[j].
 // No EC, no hashing: a few hundred to ~1.8 k integer instructions per seed.  The reference returns
@@ -93,6 +95,47 @@ VK_DEV void mt64_draws(u32 kw[ND][8], u64 seed)
     }
 }
 
+// ND successive 32-byte draws of one xorshift-family generator (big-endian fill, src/xorshift.rs:108-118 etc.)
+template <int ND>
+VK_DEV void xorshift_draws(u32 kw[ND][8], u64 seed, u32 variant)
+{
+    if (seed == 0) seed = 1;
+    if (variant == 0) {
+        u64 x = seed;
+#pragma unroll
+        for (int i = 0; i < 4 * ND; i++) {
+            x ^= x << 13;
+            x ^= x >> 7;
+            x ^= x << 17;
+            kw[i / 4][2 * (i % 4)] = (u32)(x >> 32);
+            kw[i / 4][2 * (i % 4) + 1] = (u32)x;
+        }
+    } else if (variant == 1) {
+        u32 x = (u32)seed, y = (u32)(seed >> 32);
+        u32 z = (u32)seed ^ 0x12345678u, w = (u32)(seed >> 32) ^ 0x87654321u;
+#pragma unroll
+        for (int i = 0; i < 8 * ND; i++) {
+            u32 t = x ^ (x << 11);
+            x = y;
+            y = z;
+            z = w;
+            w = (w ^ (w >> 19)) ^ (t ^ (t >> 8));
+            kw[i / 8][i % 8] = w;
+        }
+    } else {
+        u64 s0 = splitmix64(seed), s1 = splitmix64(s0);
+#pragma unroll
+        for (int i = 0; i < 4 * ND; i++) {
+            u64 r = (variant == 2) ? s0 + s1 : rotl64(s0 * 5, 7) * 9;
+            u64 t = s1 ^ s0;
+            s0 = rotl64(s0, 24) ^ t ^ (t << 16);
+            s1 = rotl64(t, 37);
+            kw[i / 4][2 * (i % 4)] = (u32)(r >> 32);
+            kw[i / 4][2 * (i % 4) + 1] = (u32)r;
+        }
+    }
+}
+
 VK_DEV bool masked_eq(const u32 kw[8], u32 bits, u64 target)
 {
     const u64 k = ((u64)kw[6] << 32) | kw[7];
@@ -131,6 +174,81 @@ VK_DEV bool search_draws(u32 kw[ND][8], const vk_spec_dev &s, u64 seed)
         return true;
     }
     if (KIND == VK_T_LCG) return transform_lcg(kw[0], seed, s.variant, s.endian); // ND == 1
+    if (KIND == VK_T_XORSHIFT) {
+        xorshift_draws<ND>(kw, seed, s.variant);
+        return true;
+    }
+    return false;
+}
+
+// ---- sha256_chain: every key of generate_chain(seed.to_be_bytes(), variant, depth) (src/sha256_chain.rs:88-145)
+VK_DEV void chain_key(u32 kw[8], u32 seed, u32 v, u32 idx, const u32 prev[8])
+{
+    if (v == 0 && idx > 0) { // iterated: k_i = SHA256(k_{i-1})
+        u32 t[8];
+        sha256_of_digest(t, prev);
+#pragma unroll
+        for (int j = 0; j < 8; j++) kw[j] = t[j];
+        return;
+    }
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = 0;
+    w[0] = seed;
+    u32 len = 4;
+    if (v == 1 || v == 2) {
+        w[1] = (v == 1) ? idx : bswap32(idx);
+        len = 8;
+    } else if (v == 3) {
+        len = msg_put_decimal(w, 4, (u64)idx);
+    }
+    msg_finish(w, len);
+    sha256_oneblock(kw, w);
+}
+
+// reference iteration order: variants in ALL_VARIANTS order, chain index ascending; the first match wins.
+// exact / masked: any key of the chain; cascade: chain[j] against target j for every j (depth = ndraws).
+VK_DEV bool chain_search_seed(const vk_search_params &p, u32 seed, u32 &hit_variant, u32 &hit_index)
+{
+    const bool all = p.spec.variant == VK_VARIANT_ALL;
+    const u32 v0 = all ? 0u : p.spec.variant, v1 = all ? 3u : p.spec.variant;
+    const u32 depth = p.mode == VK_SEARCH_CASCADE ? p.ndraws : p.spec.chain_depth;
+    for (u32 v = v0; v <= v1; v++) {
+        u32 kw[8], prev[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) prev[j] = 0;
+        bool ok = true;
+#pragma unroll 1
+        for (u32 idx = 0; idx < depth; idx++) {
+            chain_key(kw, seed, v, idx, prev);
+#pragma unroll
+            for (int j = 0; j < 8; j++) prev[j] = kw[j];
+            if (p.mode == VK_SEARCH_EXACT) {
+                u32 d = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) d |= kw[j] ^ p.key[j];
+                if (d == 0) {
+                    hit_variant = v;
+                    hit_index = idx;
+                    return true;
+                }
+            } else if (p.mode == VK_SEARCH_MASKED) {
+                if (masked_eq(kw, p.bits[0], p.targets[0])) {
+                    hit_variant = v;
+                    hit_index = idx;
+                    return true;
+                }
+            } else if (!masked_eq(kw, p.bits[idx], p.targets[idx])) {
+                ok = false;
+                break;
+            }
+        }
+        if (p.mode == VK_SEARCH_CASCADE && ok) {
+            hit_variant = v;
+            hit_index = 0;
+            return true;
+        }
+    }
     return false;
 }
 
@@ -141,8 +259,15 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_search_kernel(const vk_search_par
     u64 best = ~0ull;
     for (u64 off = (u64)blockIdx.x * VK_BLOCK + threadIdx.x; off <= p.span; off += stride) {
         const u64 seed = p.lo + off;
-        u32 kw[ND][8];
-        if (search_draws<KIND, ND>(kw, p.spec, seed) && search_match<ND>(kw, p)) {
+        bool hit;
+        if (KIND == VK_T_SHA256_CHAIN) {
+            u32 hv, hx;
+            hit = seed <= 0xFFFFFFFFull && chain_search_seed(p, (u32)seed, hv, hx);
+        } else {
+            u32 kw[ND][8];
+            hit = search_draws<KIND, ND>(kw, p.spec, seed) && search_match<ND>(kw, p);
+        }
+        if (hit) {
             best = seed; // offsets grow within a lane: the first match is this lane's smallest
             break;
         }
@@ -162,4 +287,32 @@ __global__ void vk_search_emit_kernel(vk_spec_dev spec, u64 seed, u32 *out /* ND
     for (int j = 0; j < ND; j++)
 #pragma unroll
         for (int i = 0; i < 8; i++) out[8 * j + i] = bswap32(kw[j][i]);
+}
+
+// sha256_chain: which (variant, index) matched for `seed`, and the key(s) the reference prints:
+// exact / masked: the matching key; cascade: chain[0 .. ndraws).  out = 8 x 8 words, then variant, index.
+__global__ void vk_search_emit_chain_kernel(const vk_search_params p, u64 seed, u32 *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u32 hv = 0, hx = 0;
+    if (seed > 0xFFFFFFFFull || !chain_search_seed(p, (u32)seed, hv, hx)) return;
+    out[64] = hv;
+    out[65] = hx;
+    const u32 last = p.mode == VK_SEARCH_CASCADE ? p.ndraws - 1 : hx;
+    u32 kw[8], prev[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) prev[j] = 0;
+#pragma unroll 1
+    for (u32 idx = 0; idx <= last; idx++) {
+        chain_key(kw, (u32)seed, hv, idx, prev);
+#pragma unroll
+        for (int j = 0; j < 8; j++) prev[j] = kw[j];
+        if (p.mode == VK_SEARCH_CASCADE) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) out[8 * idx + j] = bswap32(kw[j]);
+        }
+    }
+    if (p.mode != VK_SEARCH_CASCADE)
+#pragma unroll
+        for (int j = 0; j < 8; j++) out[j] = bswap32(kw[j]);
 }

@@ -1,5 +1,6 @@
 // analyze.cpp -- host mirror of the reference's analyzer interface for the generators whose seed space the
-// GPU can sweep (src/analyze/mod.rs:36-129, milksad.rs, lcg.rs, mt64.rs, key_parser.rs:32-215, output.rs:3-25).
+// GPU can sweep (src/analyze/mod.rs:36-129, milksad.rs, lcg.rs, mt64.rs, xorshift.rs, sha256_chain.rs,
+// key_parser.rs:32-215, output.rs:3-25).
 // The search runs on the device (vk_search); this file parses keys / cascades and words the results the way the
 // reference does.  Where several seeds match (masked / cascade), the reference reports whichever a worker
 // thread finds first; here it is the smallest.
@@ -157,6 +158,68 @@ AnalysisResult Mt64Analyzer::analyze(const Key &key, const AnalysisConfig &cfg) 
         d += "\n  P" + std::to_string((*cfg.cascade_targets)[j].first) + ": target=0x" + hexu((*cfg.cascade_targets)[j].second) + ", full_key=" +
              hex_encode(r.keys[j], 32);
     return {name(), AnalysisStatus::Confirmed, d};
+}
+
+// ---------------------------------------------------------------- xorshift (src/analyze/xorshift.rs)
+AnalysisResult XorshiftAnalyzer::analyze(const Key &key, const AnalysisConfig &cfg) const
+{
+    static const char *NAMES[4] = {"xorshift64", "xorshift128", "xorshift128+", "xoroshiro128**"};
+    if (!cfg.cascade_targets)
+        return {name(), AnalysisStatus::Unknown, "64-bit seed space requires --cascade filter. Example: --cascade 5:0x15,10:0x202,20:0xd2c55"};
+    if (cfg.cascade_targets->empty()) return {name(), AnalysisStatus::Unknown, "Cascade filter is empty"};
+    std::string names;
+    for (uint32_t v = 0; v < 4; v++) {
+        if (variant_ != VK_VARIANT_ALL && variant_ != v) continue;
+        const vk_transform_spec sp{VK_T_XORSHIFT, v, 0, 0};
+        const auto t0 = std::chrono::steady_clock::now();
+        const vk_search_result r = run(engine_, sp, 0, limit_, target_of(key, cfg));
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (r.found) { // format_cascade_result, :208-232 (cascade_hits is a progress statistic the device search does not keep)
+            char buf[192];
+            snprintf(buf, sizeof buf, "variant=%s, seed=%llu (0x%016llx)\nsearched %llu seeds in %.2fs", NAMES[v], (unsigned long long)r.seed,
+                     (unsigned long long)r.seed, (unsigned long long)r.seeds_checked, secs);
+            std::string d = buf;
+            for (size_t j = 0; j < cfg.cascade_targets->size(); j++)
+                d += "\n  P" + std::to_string((*cfg.cascade_targets)[j].first) + ": target=0x" + hexu((*cfg.cascade_targets)[j].second) + ", full_key=" +
+                     hex_encode(r.keys[j], 32);
+            return {name(), AnalysisStatus::Confirmed, d};
+        }
+        names += (names.empty() ? "" : ", ") + std::string(NAMES[v]);
+    }
+    return {name(), AnalysisStatus::NotFound, "checked variants=[" + names + "], cascade=[" + cascade_desc(cfg) + "]"};
+}
+
+// ---------------------------------------------------------------- sha256_chain (src/analyze/sha256_chain.rs)
+AnalysisResult Sha256ChainAnalyzer::analyze(const Key &key, const AnalysisConfig &cfg) const
+{
+    static const char *NAMES[4] = {"iterated", "indexed:be", "indexed:le", "counter"};
+    const vk_transform_spec sp{VK_T_SHA256_CHAIN, variant_, 0, depth_};
+    const uint64_t total = 1ull << 32;
+    const vk_search_result r = run(engine_, sp, 0, total - 1, target_of(key, cfg));
+    std::string names;
+    for (uint32_t v = 0; v < 4; v++)
+        if (variant_ == VK_VARIANT_ALL || variant_ == v) names += (names.empty() ? "" : ", ") + std::string(NAMES[v]);
+    char head[96];
+    snprintf(head, sizeof head, "seed=%llu (0x%08llx), variant=%s", (unsigned long long)r.seed, (unsigned long long)r.seed, NAMES[r.variant & 3]);
+    if (cfg.cascade_targets) {
+        if (!r.found)
+            return {name(), AnalysisStatus::NotFound, "checked " + std::to_string(total) + " seeds, variants=[" + names + "], cascade=[" + cascade_desc(cfg) + "]"};
+        std::string d = head; // format_cascade_result, :427-448
+        for (size_t j = 0; j < cfg.cascade_targets->size(); j++)
+            d += "\n  P" + std::to_string((*cfg.cascade_targets)[j].first) + ": target=0x" + hexu((*cfg.cascade_targets)[j].second) + ", full_key=" +
+                 hex_encode(r.keys[j], 32);
+        return {name(), AnalysisStatus::Confirmed, d};
+    }
+    if (cfg.mask_bits) {
+        if (!r.found)
+            return {name(), AnalysisStatus::NotFound, "checked " + std::to_string(total) + " seeds with " + std::to_string(*cfg.mask_bits) + "-bit mask, variants=[" + names +
+                                                          "], chain_depth=" + std::to_string(depth_)};
+        return {name(), AnalysisStatus::Confirmed, std::string(head) + ", chain_index=" + std::to_string(r.index) + ", full_key=" + hex_encode(r.keys[0], 32) +
+                                                       ", mask_bits=" + std::to_string(*cfg.mask_bits)};
+    }
+    if (!r.found)
+        return {name(), AnalysisStatus::NotFound, "checked " + std::to_string(total) + " seeds, variants=[" + names + "], chain_depth=" + std::to_string(depth_)};
+    return {name(), AnalysisStatus::Confirmed, std::string(head) + ", chain_index=" + std::to_string(r.index)};
 }
 
 // ---------------------------------------------------------------- key_parser.rs

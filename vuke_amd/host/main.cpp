@@ -19,7 +19,7 @@ static int usage(const char *msg)
 {
     if (msg) fprintf(stderr, "error: %s\n\n", msg);
     fprintf(stderr, "Usage: vuke-hip <generate|scan|single> [OPTIONS] range --start <START> --end <END>\n"
-                    "       vuke-hip analyze <KEY> [--mask BITS] [--cascade b:t,b:t,...] [--analyzer milksad|lcg[:variant][:endian]|mt64]...\n"
+                    "       vuke-hip analyze <KEY> [--mask BITS] [--cascade b:t,b:t,...] [--analyzer milksad|lcg[:variant][:endian]|mt64|xorshift[:variant]|sha256_chain[:variant]]...\n"
                     "  --transform <T>...   sha256 | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] | sha256_chain[:variant] | electrum[:change] | multibit\n"
                     "  sources: range --start A --end B | wordlist --file F (string transforms: electrum[:change])\n"
                     "  --targets <FILE>     (scan) one address per line\n"
@@ -53,6 +53,7 @@ static int run_analyze(int argc, char **argv)
     std::optional<uint8_t> mask;
     int device = 0;
     uint64_t mt64_limit = (1ull << 40) - 1;
+    uint32_t chain_depth = 10; // DEFAULT_CHAIN_DEPTH (src/sha256_chain.rs:82)
     try {
         for (int i = 2; i < argc; i++) {
             std::string a = argv[i];
@@ -67,7 +68,8 @@ static int run_analyze(int argc, char **argv)
             } else if (a == "--cascade") cascade_s = need("--cascade");
             else if (a == "--analyzer") names.push_back(need("--analyzer"));
             else if (a == "--device") device = atoi(need("--device"));
-            else if (a == "--mt64-limit") mt64_limit = parse_u64(need("--mt64-limit"));
+            else if (a == "--mt64-limit" || a == "--seed-limit") mt64_limit = parse_u64(need("--seed-limit")); // bound for the 64-bit seed spaces
+            else if (a == "--chain-depth") chain_depth = (uint32_t)parse_u64(need("--chain-depth"));
             else if (key_s.empty() && a[0] != '-') key_s = a;
             else throw std::invalid_argument("unexpected argument '" + a + "'");
         }
@@ -92,7 +94,13 @@ static int run_analyze(int argc, char **argv)
             else if (n == "lcg" || n.rfind("lcg:", 0) == 0) {
                 Transform t = TransformType::from_str(n); // same grammar as the transform (src/lcg.rs:247-277)
                 results.push_back(LcgAnalyzer(engine, t.spec().variant, t.spec().endian).analyze(key, cfg));
-            } else throw std::invalid_argument("analyzer '" + n + "' is not on the device path (built: milksad, lcg[:variant][:endian], mt64)");
+            } else if (n == "xorshift" || n.rfind("xorshift:", 0) == 0) {
+                Transform t = TransformType::from_str(n); // XorshiftConfig::parse (src/xorshift.rs:334-357)
+                results.push_back(XorshiftAnalyzer(engine, t.spec().variant, mt64_limit).analyze(key, cfg));
+            } else if (n == "sha256_chain" || n.rfind("sha256_chain:", 0) == 0) {
+                Transform t = TransformType::from_str(n); // Sha256ChainConfig::parse (src/sha256_chain.rs:187-217)
+                results.push_back(Sha256ChainAnalyzer(engine, t.spec().variant, chain_depth).analyze(key, cfg));
+            } else throw std::invalid_argument("analyzer '" + n + "' is not on the device path (built: milksad, lcg[:variant][:endian], mt64, xorshift[:variant], sha256_chain[:variant])");
         }
         fputs(format_results(key, results).c_str(), stdout);
         return 0;

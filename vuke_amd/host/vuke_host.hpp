@@ -232,6 +232,29 @@ private:
     vk_engine *engine_;
     uint64_t limit_;
 };
+class XorshiftAnalyzer : public Analyzer { // src/analyze/xorshift.rs: cascade only, every variant walks seeds upward
+public:
+    XorshiftAnalyzer(vk_engine *e, uint32_t variant = VK_VARIANT_ALL, uint64_t limit = (1ull << 40) - 1) : engine_(e), variant_(variant), limit_(limit) {}
+    const char *name() const override { return "xorshift"; }
+    bool supports_mask() const override { return true; }
+    AnalysisResult analyze(const Key &key, const AnalysisConfig &config) const override;
+
+private:
+    vk_engine *engine_;
+    uint32_t variant_;
+    uint64_t limit_;
+};
+class Sha256ChainAnalyzer : public Analyzer { // src/analyze/sha256_chain.rs: all 2^32 seeds as 4 BE bytes
+public:
+    Sha256ChainAnalyzer(vk_engine *e, uint32_t variant = VK_VARIANT_ALL, uint32_t chain_depth = 10) : engine_(e), variant_(variant), depth_(chain_depth) {}
+    const char *name() const override { return "sha256_chain"; }
+    bool supports_mask() const override { return true; }
+    AnalysisResult analyze(const Key &key, const AnalysisConfig &config) const override;
+
+private:
+    vk_engine *engine_;
+    uint32_t variant_, depth_;
+};
 Key parse_private_key(const std::string &input);                              // src/analyze/key_parser.rs:32-48
 std::vector<std::pair<uint8_t, uint64_t>> parse_cascade(const std::string &input); // :131-166
 std::string format_results(const Key &key, const std::vector<AnalysisResult> &results); // src/analyze/output.rs:3-25
