@@ -58,6 +58,10 @@ extern "C" {
                                 variant = 0 receiving / 1 change chain, chain_depth = derivation count (reference: 20) */
 #define VK_T_MULTIBIT 7u     /* src/multibit.rs, src/transform/multibit.rs: STRING inputs only; chain_depth = derivation
                                 count (reference: 20); needs vk_bip39_wordlist_set first */
+#define VK_T_DOUBLE_SHA256 8u /* src/transform/double_sha256.rs:13-32: SHA256(SHA256(x)), x = decimal string, 8 BE bytes, 8 LE bytes */
+#define VK_T_MD5 9u           /* src/transform/md5.rs:13-21: MD5(decimal string) twice, key[0..16] = key[16..32] */
+#define VK_T_DIRECT 10u       /* src/transform/direct.rs:13-34: slot 0 = 8 BE bytes right-aligned, 1 = 8 LE bytes left-aligned,
+                                2 = the string zero padded to 32 bytes (strings longer than 32 bytes emit nothing) */
 #define VK_VARIANT_ALL 0xFFFFFFFFu
 
 typedef struct vk_transform_spec {
@@ -172,8 +176,10 @@ int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, const uint64_t 
 int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words /* 16384 bytes */);
 
 /* Transform::apply_batch for string inputs (Input::from_string; wordlist / stdin sources).  String i is
- * data[offsets[i] .. offsets[i+1]).  Supported kinds: VK_T_ELECTRUM (strings up to 64 bytes) and
- * VK_T_MULTIBIT (up to 256 bytes); longer strings return VK_E_UNSUPPORTED.  keys_out = n*slots*32, valid = n*slots, slot order = emit order. */
+ * data[offsets[i] .. offsets[i+1]).  slots = vk_slots_per_string(t): the hash transforms (sha256, double_sha256, md5,
+ * direct) emit one key per string of any length, sha256_chain variants x depth, VK_T_ELECTRUM (strings up to 64
+ * bytes) and VK_T_MULTIBIT (up to 256 bytes; longer strings return VK_E_UNSUPPORTED) chain_depth keys; the PRNG
+ * transforms need a numeric seed and return VK_E_UNSUPPORTED.  keys_out = n*slots*32, valid = n*slots, slot order = emit order. */
 int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
                          uint8_t *keys_out, uint8_t *valid);
 
@@ -214,8 +220,10 @@ typedef struct vk_search_result {
 int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_t seed_hi_inclusive,
               const vk_search_target *target, vk_search_result *out);
 
-/* Slots one input occupies under `t` (0 if the spec is invalid). */
+/* Slots one numeric input (Input::from_u64) occupies under `t` (0 if the spec is invalid). */
 uint32_t vk_slots_per_input(const vk_transform_spec *t);
+/* Slots one string input (Input::from_string: no numeric forms) occupies; 0 = the transform emits nothing for strings. */
+uint32_t vk_slots_per_string(const vk_transform_spec *t);
 
 /* Test hook: (d << (window_bits*w)) * G table entry as 64 bytes X||Y big-endian. */
 int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digit, uint8_t xy[64]);

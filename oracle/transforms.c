@@ -9,6 +9,7 @@
  */
 #include "vko.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* ---------------------------------------------------------------- MT19937 */
@@ -153,28 +154,22 @@ int vko_xorshift_key(uint64_t seed, uint32_t variant, uint8_t key[32])
  * 2 indexed:le, 3 counter.  generate_key_at_index: src/sha256_chain.rs:88-118. */
 int vko_sha256_chain_key(const uint8_t *seed, size_t seedlen, uint32_t variant, uint32_t index, uint8_t key[32])
 {
-    uint8_t buf[96];
-    if (seedlen > 64) return 0;
-    switch (variant) {
-    case 0:
+    if (variant > 3) return 0;
+    if (variant == 0) {
         vko_sha256(seed, seedlen, key);
         for (uint32_t i = 0; i < index; i++) { uint8_t t[32]; vko_sha256(key, 32, t); memcpy(key, t, 32); }
         return 1;
-    case 1:
-    case 2:
-        memcpy(buf, seed, seedlen);
-        if (variant == 1) put_be32(buf + seedlen, index);
-        else { buf[seedlen] = (uint8_t)index; buf[seedlen + 1] = (uint8_t)(index >> 8); buf[seedlen + 2] = (uint8_t)(index >> 16); buf[seedlen + 3] = (uint8_t)(index >> 24); }
-        vko_sha256(buf, seedlen + 4, key);
-        return 1;
-    case 3: {
-        memcpy(buf, seed, seedlen);
-        int n = snprintf((char *)buf + seedlen, sizeof buf - seedlen, "%u", index);
-        vko_sha256(buf, seedlen + (size_t)n, key);
-        return 1;
     }
-    default: return 0;
-    }
+    uint8_t stack[128], *buf = seedlen + 16 <= sizeof stack ? stack : malloc(seedlen + 16);
+    if (!buf) return 0;
+    size_t n = seedlen;
+    memcpy(buf, seed, seedlen);
+    if (variant == 1) { put_be32(buf + n, index); n += 4; }
+    else if (variant == 2) { for (int j = 0; j < 4; j++) buf[n + j] = (uint8_t)(index >> (8 * j)); n += 4; }
+    else n += (size_t)snprintf((char *)buf + n, 16, "%u", index);
+    vko_sha256(buf, n, key);
+    if (buf != stack) free(buf);
+    return 1;
 }
 
 /* --------------------------------------------------- generic (spec, seed, slot) */
@@ -184,12 +179,50 @@ static const char *CH_NAME[4] = {"iterated", "indexed:be", "indexed:le", "counte
 uint32_t vko_slots_per_input(const vko_spec *s)
 {
     switch (s->kind) {
-    case VKO_T_SHA256: return 3;
+    case VKO_T_SHA256:
+    case VKO_T_DOUBLE_SHA256:
+    case VKO_T_DIRECT: return 3;
     case VKO_T_MILKSAD:
+    case VKO_T_MD5:
     case VKO_T_MT64: return 1;
     case VKO_T_LCG:
     case VKO_T_XORSHIFT: return s->variant == VKO_VARIANT_ALL ? 4 : 1;
     case VKO_T_SHA256_CHAIN: return 2u * (s->variant == VKO_VARIANT_ALL ? 4u : 1u) * s->chain_depth;
+    default: return 0;
+    }
+}
+
+/* Input::from_string (src/transform/input.rs:33-41): string_val only, so every `if let Some(be)` arm is skipped
+ * and the transforms that need u64_val emit nothing. */
+uint32_t vko_slots_per_string(const vko_spec *s)
+{
+    switch (s->kind) {
+    case VKO_T_SHA256:
+    case VKO_T_DOUBLE_SHA256:
+    case VKO_T_MD5:
+    case VKO_T_DIRECT: return 1;
+    case VKO_T_SHA256_CHAIN: return (s->variant == VKO_VARIANT_ALL ? 4u : 1u) * s->chain_depth;
+    default: return 0;
+    }
+}
+
+int vko_transform_string(const vko_spec *s, const uint8_t *str, size_t len, uint32_t sub, uint8_t key[32])
+{
+    uint8_t t[32];
+    switch (s->kind) {
+    case VKO_T_SHA256: if (sub) return 0; vko_sha256(str, len, key); return 1;                       /* sha256.rs:16-18 */
+    case VKO_T_DOUBLE_SHA256: if (sub) return 0; vko_sha256(str, len, t); vko_sha256(t, 32, key); return 1; /* double_sha256.rs:15-17 */
+    case VKO_T_MD5: if (sub) return 0; vko_md5(str, len, key); memcpy(key + 16, key, 16); return 1;  /* md5.rs:15-19 */
+    case VKO_T_DIRECT:                                                                               /* direct.rs:28-32 */
+        if (sub || len > 32) return 0;
+        memset(key, 0, 32);
+        memcpy(key, str, len);
+        return 1;
+    case VKO_T_SHA256_CHAIN: { /* sha256_chain.rs:63-72; generate_chain_from_string = chain over the string's bytes */
+        uint32_t nv = s->variant == VKO_VARIANT_ALL ? 4u : 1u, d = s->chain_depth;
+        if (d == 0 || sub >= nv * d) return 0;
+        return vko_sha256_chain_key(str, len, s->variant == VKO_VARIANT_ALL ? sub / d : s->variant, sub % d, key);
+    }
     default: return 0;
     }
 }
@@ -207,6 +240,25 @@ int vko_transform_key(const vko_spec *s, uint64_t seed, uint32_t sub, uint8_t ke
         if (sub == 2) { for (int j = 0; j < 8; j++) b[j] = (uint8_t)(seed >> (8 * j)); vko_sha256(b, 8, key); return 1; }
         return 0;
     }
+    case VKO_T_DOUBLE_SHA256: { /* src/transform/double_sha256.rs:13-32: same three forms, hashed twice */
+        vko_spec one = *s;
+        uint8_t t[32];
+        one.kind = VKO_T_SHA256;
+        if (!vko_transform_key(&one, seed, sub, t)) return 0;
+        vko_sha256(t, 32, key);
+        return 1;
+    }
+    case VKO_T_MD5: /* src/transform/md5.rs:13-21 */
+        if (sub) return 0;
+        vko_md5((const uint8_t *)dec, (size_t)dl, key);
+        memcpy(key + 16, key, 16);
+        return 1;
+    case VKO_T_DIRECT: /* src/transform/direct.rs:13-34: BE right-aligned, LE left-aligned, string zero padded */
+        memset(key, 0, 32);
+        if (sub == 0) { for (int j = 0; j < 8; j++) key[24 + j] = (uint8_t)(seed >> (56 - 8 * j)); return 1; }
+        if (sub == 1) { for (int j = 0; j < 8; j++) key[j] = (uint8_t)(seed >> (8 * j)); return 1; }
+        if (sub == 2) { memcpy(key, dec, (size_t)dl); return 1; } /* a u64 has at most 20 digits */
+        return 0;
     case VKO_T_MILKSAD: return sub == 0 ? vko_milksad_key(seed, key) : 0;
     case VKO_T_MT64: return sub == 0 ? vko_mt64_key(seed, key) : 0;
     case VKO_T_LCG: {
@@ -239,6 +291,9 @@ int vko_transform_label(const vko_spec *s, uint64_t seed, uint32_t sub, char *ou
     unsigned long long sd = seed;
     switch (s->kind) {
     case VKO_T_SHA256:
+    case VKO_T_DOUBLE_SHA256:
+    case VKO_T_MD5:
+    case VKO_T_DIRECT:
     case VKO_T_MILKSAD:
     case VKO_T_MT64: return snprintf(out, cap, "%llu", sd);
     case VKO_T_LCG: /* src/transform/lcg.rs:54-66 */
@@ -264,6 +319,9 @@ const char *vko_transform_name(const vko_spec *s)
 {
     switch (s->kind) {
     case VKO_T_SHA256: return "sha256";
+    case VKO_T_DOUBLE_SHA256: return "double_sha256";
+    case VKO_T_MD5: return "md5";
+    case VKO_T_DIRECT: return "direct";
     case VKO_T_MILKSAD: return "milksad";
     case VKO_T_MT64: return "mt64";
     case VKO_T_LCG: return "lcg";

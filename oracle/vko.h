@@ -38,6 +38,7 @@ extern "C" {
 void vko_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
 void vko_ripemd160(const uint8_t *msg, size_t len, uint8_t out[20]);
 void vko_hash160(const uint8_t *msg, size_t len, uint8_t out[20]); /* RIPEMD160(SHA256(m)) */
+void vko_md5(const uint8_t *msg, size_t len, uint8_t out[16]);
 void vko_sha512(const uint8_t *msg, size_t len, uint8_t out[64]);
 void vko_hmac_sha512(const uint8_t *key, size_t klen, const uint8_t *msg, size_t mlen, uint8_t out[64]);
 void vko_pbkdf2_hmac_sha512(const uint8_t *pw, size_t pwlen, const uint8_t *salt, size_t saltlen,
@@ -52,6 +53,11 @@ enum {
     VKO_T_LCG = 3,          /* src/lcg.rs:107-128, src/transform/lcg.rs:43-72 */
     VKO_T_XORSHIFT = 4,     /* src/xorshift.rs:83-317, src/transform/xorshift.rs:33-52 */
     VKO_T_SHA256_CHAIN = 5, /* src/sha256_chain.rs:88-145, src/transform/sha256_chain.rs:60-94 */
+    VKO_T_ELECTRUM = 6,     /* vko_electrum_keys (string inputs) */
+    VKO_T_MULTIBIT = 7,     /* vko_multibit_keys (string inputs) */
+    VKO_T_DOUBLE_SHA256 = 8, /* src/transform/double_sha256.rs:13-32 */
+    VKO_T_MD5 = 9,          /* src/transform/md5.rs:13-21 */
+    VKO_T_DIRECT = 10,      /* src/transform/direct.rs:13-34 */
 };
 #define VKO_VARIANT_ALL 0xFFFFFFFFu
 
@@ -74,6 +80,9 @@ int vko_sha256_chain_key(const uint8_t *seed, size_t seedlen, uint32_t variant, 
 uint32_t vko_slots_per_input(const vko_spec *spec);
 /* Key for (seed, sub_index); returns 0 if the reference emits nothing for that slot. */
 int vko_transform_key(const vko_spec *spec, uint64_t seed, uint32_t sub_index, uint8_t key[32]);
+/* The same for Input::from_string inputs (wordlist / stdin sources: no numeric forms). */
+uint32_t vko_slots_per_string(const vko_spec *spec);
+int vko_transform_string(const vko_spec *spec, const uint8_t *str, size_t len, uint32_t sub_index, uint8_t key[32]);
 /* Label the reference attaches to (seed, sub_index) -- the `source` column. */
 int vko_transform_label(const vko_spec *spec, uint64_t seed, uint32_t sub_index, char *out, size_t cap);
 /* Transform::name() */

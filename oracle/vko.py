@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "build", "libvko.so")
 
-T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN = range(6)
+T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM, T_MULTIBIT, T_DOUBLE_SHA256, T_MD5, T_DIRECT = range(11)
 VARIANT_ALL = 0xFFFFFFFF
 F_COMPRESSED, F_UNCOMPRESSED, F_FAITHFUL = 1, 2, 0x100
 
@@ -106,6 +106,10 @@ def lib():
         L.vko_mt64_draws.argtypes = [u64, u32, cp]
         L.vko_search.argtypes = [C.POINTER(Spec), u64, u64, u32, cp, u32, cp, C.POINTER(u64), C.POINTER(u64), cp, C.POINTER(u32)]
         L.vko_xorshift_draws.argtypes = [u64, u32, u32, cp]
+        L.vko_slots_per_string.argtypes = [C.POINTER(Spec)]
+        L.vko_slots_per_string.restype = u32
+        L.vko_transform_string.argtypes = [C.POINTER(Spec), cp, sz, u32, cp]
+        L.vko_md5.argtypes = [cp, sz, cp]
         _ = (u8p, u64)
         _lib = L
     return _lib
@@ -165,6 +169,24 @@ def slots_per_input(sp):
 def transform_key(sp, seed, sub):
     o = _out(32)
     return o.raw if lib().vko_transform_key(C.byref(sp), seed, sub, o) else None
+
+
+def slots_per_string(sp):
+    return lib().vko_slots_per_string(C.byref(sp))
+
+
+def transform_string(sp, s, sub):
+    """Key for (Input::from_string(s), sub) or None where the reference emits nothing."""
+    if isinstance(s, str):
+        s = s.encode()
+    o = _out(32)
+    return o.raw if lib().vko_transform_string(C.byref(sp), s, len(s), sub, o) else None
+
+
+def md5(msg):
+    o = _out(16)
+    lib().vko_md5(msg, len(msg), o)
+    return o.raw
 
 
 def transform_label(sp, seed, sub):

@@ -104,6 +104,9 @@ def test_derive_batch_edges_and_random(eng, vko):
 
 def _specs(vko, ffi):
     out = [(ffi.spec(ffi.T_SHA256), vko.spec(vko.T_SHA256)),
+           (ffi.spec(ffi.T_DOUBLE_SHA256), vko.spec(vko.T_DOUBLE_SHA256)),
+           (ffi.spec(ffi.T_MD5), vko.spec(vko.T_MD5)),
+           (ffi.spec(ffi.T_DIRECT), vko.spec(vko.T_DIRECT)),
            (ffi.spec(ffi.T_MILKSAD), vko.spec(vko.T_MILKSAD)),
            (ffi.spec(ffi.T_MT64), vko.spec(vko.T_MT64))]
     for v in (ffi.VARIANT_ALL, 0, 1, 2, 3):
@@ -468,3 +471,35 @@ def test_analyzer_search_xorshift_and_sha256_chain(eng, vko):
         k = ch[5]
         got = eng.search(gs, 10**6, 10**6 + 60000, key=k)
         assert (got["seed"], got["variant"], got["index"], got["keys"]) == (10**6 + 4321, v, 5, [k])
+
+
+def test_hash_transforms_on_strings(eng, vko):
+    """Input::from_string inputs (wordlist / stdin sources) through sha256, double_sha256, md5, direct and
+    sha256_chain: any length, block-boundary lengths included; the PRNG transforms emit nothing for strings."""
+    import hashlib
+    from vuke_amd import _ffi as ffi
+    rnd = random.Random(77)
+    strings = [b"", b"a", b"abc", b"password", b"correct horse battery staple", b"satoshi nakamoto", "zażółć gęślą jaźń".encode()]
+    strings += [bytes(rnd.randrange(1, 256) for _ in range(n)) for n in (31, 32, 33, 54, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 129, 1000, 5000)]
+    strings += [bytes(rnd.randrange(32, 127) for _ in range(rnd.randrange(1, 200))) for _ in range(300)]
+    specs = [(ffi.spec(k), vko.spec(k)) for k in (ffi.T_SHA256, ffi.T_DOUBLE_SHA256, ffi.T_MD5, ffi.T_DIRECT)]
+    for v in (ffi.VARIANT_ALL, 0, 1, 2, 3):
+        for depth in (1, 4, 11):
+            specs.append((ffi.spec(ffi.T_SHA256_CHAIN, v, 0, depth), vko.spec(vko.T_SHA256_CHAIN, v, 0, depth)))
+    for gs, os_ in specs:
+        slots = vko.slots_per_string(os_)
+        got = eng.transform_strings(gs, strings)
+        assert len(got) == len(strings) and all(len(r) == slots for r in got)
+        for s, row in zip(strings, got):
+            assert row == [vko.transform_string(os_, s, sub) for sub in range(slots)], (gs.kind, gs.variant, gs.chain_depth, len(s))
+    # independent pins (hashlib) for the four one-key transforms, through the device path
+    g = lambda k: [r[0] for r in eng.transform_strings(ffi.spec(k), strings)]
+    assert g(ffi.T_SHA256) == [hashlib.sha256(s).digest() for s in strings]
+    assert g(ffi.T_DOUBLE_SHA256) == [hashlib.sha256(hashlib.sha256(s).digest()).digest() for s in strings]
+    assert g(ffi.T_MD5) == [hashlib.md5(s).digest() * 2 for s in strings]
+    assert g(ffi.T_DIRECT) == [s.ljust(32, b"\0") if len(s) <= 32 else None for s in strings]
+    # the classic brain wallet: SHA256("correct horse battery staple") -> c4bb...9a8a (src/derive.rs:190-197)
+    assert eng.transform_strings(ffi.spec(ffi.T_SHA256), [b"correct horse battery staple"])[0][0] == CHBS
+    for k in (ffi.T_MILKSAD, ffi.T_MT64, ffi.T_LCG, ffi.T_XORSHIFT):
+        with pytest.raises(Exception):
+            eng.transform_strings(ffi.spec(k), [b"123"])

@@ -232,3 +232,50 @@ def test_labels_lcg_xorshift(vko):
     sp = vko.spec(vko.T_XORSHIFT)
     assert [l for l, _ in vko.transform_apply(sp, 5)] == ["5:xorshift64", "5:xorshift128", "5:xorshift128+", "5:xoroshiro128**"]
     assert [l for l, _ in vko.transform_apply(vko.spec(vko.T_XORSHIFT, variant=2), 5)] == ["5"]
+
+
+def test_cheap_hash_transforms_vs_hashlib(vko):
+    """double_sha256 / md5 / direct (src/transform/{double_sha256,md5,direct}.rs): the reference has no vectors for
+    them, so the pins are hashlib and the byte layouts spelled out in the reference source."""
+    d2 = lambda b: hashlib.sha256(hashlib.sha256(b).digest()).digest()
+    rnd = random.Random(8)
+    for seed in SEEDS64 + [rnd.getrandbits(64) for _ in range(100)]:
+        dec, be, le = str(seed).encode(), struct.pack(">Q", seed), struct.pack("<Q", seed)
+        sp = vko.spec(vko.T_DOUBLE_SHA256)
+        assert [vko.transform_key(sp, seed, i) for i in range(4)] == [d2(dec), d2(be), d2(le), None]
+        sp = vko.spec(vko.T_MD5)
+        assert [vko.transform_key(sp, seed, i) for i in range(2)] == [hashlib.md5(dec).digest() * 2, None]
+        sp = vko.spec(vko.T_DIRECT)
+        assert [vko.transform_key(sp, seed, i) for i in range(4)] == [bytes(24) + be, le + bytes(24), dec.ljust(32, b"\0"), None]
+        for k in (vko.T_DOUBLE_SHA256, vko.T_MD5, vko.T_DIRECT):
+            assert vko.transform_label(vko.spec(k), seed, 0) == str(seed)
+    assert [vko.slots_per_input(vko.spec(k)) for k in (vko.T_DOUBLE_SHA256, vko.T_MD5, vko.T_DIRECT)] == [3, 1, 3]
+    assert [vko.transform_name(vko.spec(k)) for k in (vko.T_DOUBLE_SHA256, vko.T_MD5, vko.T_DIRECT)] == ["double_sha256", "md5", "direct"]
+    for n in list(range(0, 70)) + [119, 120, 121, 1000]:
+        m = bytes(rnd.getrandbits(8) for _ in range(n))
+        assert vko.md5(m) == hashlib.md5(m).digest()
+
+
+def test_string_inputs(vko):
+    """Input::from_string: only the string arm of each transform fires; the PRNG transforms emit nothing."""
+    rnd = random.Random(9)
+    strs = [b"", b"abc", b"correct horse battery staple", bytes(rnd.randrange(1, 256) for _ in range(300))] + [bytes(rnd.randrange(32, 127) for _ in range(n)) for n in (31, 32, 33, 55, 56, 64)]
+    for s in strs:
+        assert vko.transform_string(vko.spec(vko.T_SHA256), s, 0) == hashlib.sha256(s).digest()
+        assert vko.transform_string(vko.spec(vko.T_SHA256), s, 1) is None
+        assert vko.transform_string(vko.spec(vko.T_DOUBLE_SHA256), s, 0) == hashlib.sha256(hashlib.sha256(s).digest()).digest()
+        assert vko.transform_string(vko.spec(vko.T_MD5), s, 0) == hashlib.md5(s).digest() * 2
+        assert vko.transform_string(vko.spec(vko.T_DIRECT), s, 0) == (s.ljust(32, b"\0") if len(s) <= 32 else None)
+        sp = vko.spec(vko.T_SHA256_CHAIN, vko.VARIANT_ALL, 0, 3)
+        assert vko.slots_per_string(sp) == 12
+        it = [hashlib.sha256(s).digest()]
+        it += [hashlib.sha256(it[-1]).digest()]
+        it += [hashlib.sha256(it[-1]).digest()]
+        want = it + [hashlib.sha256(s + struct.pack(">I", i)).digest() for i in range(3)] + [hashlib.sha256(s + struct.pack("<I", i)).digest() for i in range(3)] \
+            + [hashlib.sha256(s + str(i).encode()).digest() for i in range(3)]
+        assert [vko.transform_string(sp, s, i) for i in range(12)] == want
+        assert vko.transform_string(sp, s, 12) is None
+    # src/derive.rs:190-197: the brain wallet key of the reference's own derive test
+    assert vko.transform_string(vko.spec(vko.T_SHA256), b"correct horse battery staple", 0).hex() == "c4bbcb1fbec99d65bf59d85c8cb62ee2db963f0fe106f483d9afa73bd4e39a8a"
+    for k in (vko.T_MILKSAD, vko.T_MT64, vko.T_LCG, vko.T_XORSHIFT):
+        assert vko.slots_per_string(vko.spec(k)) == 0 and vko.transform_string(vko.spec(k), b"123", 0) is None

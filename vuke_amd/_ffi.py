@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvuke_hip.so")
 
 VK_OK = 0
 VK_E_NO_DEVICE, VK_E_HIP, VK_E_INVALID_ARG, VK_E_UNSUPPORTED, VK_E_NOMEM = -1, -2, -3, -4, -5
-T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM, T_MULTIBIT = range(8)
+T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM, T_MULTIBIT, T_DOUBLE_SHA256, T_MD5, T_DIRECT = range(11)
 VARIANT_ALL = 0xFFFFFFFF
 F_COMPRESSED, F_UNCOMPRESSED = 1, 2
 ADDR_P2PKH_C, ADDR_P2PKH_U, ADDR_P2WPKH = 0, 1, 2
@@ -61,7 +61,7 @@ EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
     "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_transform_batch",
     "vk_transform_strings", "vk_scan_keys", "vk_bip39_wordlist_set", "vk_search",
-    "vk_slots_per_input", "vk_debug_table_entry", "vk_debug_field",
+    "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field",
 ]
 
 _lib = None
@@ -96,6 +96,8 @@ def load():
     L.vk_scan_keys.argtypes = [vp, cp, sz, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_slots_per_input.argtypes = [C.POINTER(TransformSpec)]
     L.vk_slots_per_input.restype = u32
+    L.vk_slots_per_string.argtypes = [C.POINTER(TransformSpec)]
+    L.vk_slots_per_string.restype = u32
     L.vk_debug_table_entry.argtypes = [vp, u32, u32, vp]
     L.vk_debug_field.argtypes = [vp, C.c_int, cp, cp, sz, vp]
     _lib = L
@@ -193,7 +195,7 @@ class Engine:
         """Transform::apply_batch for string inputs: per input a list of keys (None where nothing is emitted).
         raw=True returns (keys bytes, valid bytes, seconds inside the library call) without per-key unpacking."""
         n = len(strings)
-        slots = self._L.vk_slots_per_input(C.byref(spec))
+        slots = self._L.vk_slots_per_string(C.byref(spec))
         offs = (C.c_uint32 * (n + 1))()
         for i, s in enumerate(strings):
             offs[i + 1] = offs[i] + len(s)

@@ -79,8 +79,11 @@ extern "C" uint32_t vk_slots_per_input(const vk_transform_spec *t)
 {
     if (!t) return 0;
     switch (t->kind) {
-    case VK_T_SHA256: return 3;
+    case VK_T_SHA256:
+    case VK_T_DOUBLE_SHA256:
+    case VK_T_DIRECT: return 3;
     case VK_T_MILKSAD:
+    case VK_T_MD5:
     case VK_T_MT64: return 1;
     case VK_T_LCG:
     case VK_T_XORSHIFT:
@@ -100,6 +103,21 @@ extern "C" uint32_t vk_slots_per_input(const vk_transform_spec *t)
     }
 }
 
+extern "C" uint32_t vk_slots_per_string(const vk_transform_spec *t)
+{
+    if (!t) return 0;
+    switch (t->kind) {
+    case VK_T_SHA256:
+    case VK_T_DOUBLE_SHA256:
+    case VK_T_MD5:
+    case VK_T_DIRECT: return 1;
+    case VK_T_SHA256_CHAIN: return vk_slots_per_input(t) / 2; // the string form only (src/transform/sha256_chain.rs:60-72)
+    case VK_T_ELECTRUM:
+    case VK_T_MULTIBIT: return vk_slots_per_input(t);
+    default: return 0; // the PRNG transforms need Input::u64_val: nothing is emitted for a string
+    }
+}
+
 static int validate_spec(vk_engine *e, const vk_transform_spec *t, bool strings = false)
 {
     if (!t) return fail(e, VK_E_INVALID_ARG, "transform spec is NULL");
@@ -107,7 +125,7 @@ static int validate_spec(vk_engine *e, const vk_transform_spec *t, bool strings 
     const bool string_kind = t->kind == VK_T_ELECTRUM || t->kind == VK_T_MULTIBIT;
     if (!strings && string_kind)
         return fail(e, VK_E_UNSUPPORTED, "electrum / multibit take string inputs: use vk_transform_strings + vk_scan_keys");
-    if (strings && !string_kind) return fail(e, VK_E_UNSUPPORTED, "only electrum and multibit are built for string inputs");
+    if (strings && vk_slots_per_string(t) == 0) return fail(e, VK_E_UNSUPPORTED, "this transform emits nothing for string inputs (it needs a numeric seed)");
     if (strings && t->kind == VK_T_MULTIBIT && !e->d_wordlist)
         return fail(e, VK_E_INVALID_ARG, "multibit needs the BIP-39 word list: call vk_bip39_wordlist_set first");
     if (t->kind == VK_T_LCG && t->endian > 1) return fail(e, VK_E_INVALID_ARG, "lcg endian must be 0 (big) or 1 (little)");
@@ -396,6 +414,9 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     case VK_T_LCG: launch_sweep<VK_T_LCG>(p, grid, e->stream); break;
     case VK_T_XORSHIFT: launch_sweep<VK_T_XORSHIFT>(p, grid, e->stream); break;
     case VK_T_SHA256_CHAIN: launch_sweep<VK_T_SHA256_CHAIN>(p, grid, e->stream); break;
+    case VK_T_DOUBLE_SHA256: launch_sweep<VK_T_DOUBLE_SHA256>(p, grid, e->stream); break;
+    case VK_T_MD5: launch_sweep<VK_T_MD5>(p, grid, e->stream); break;
+    case VK_T_DIRECT: launch_sweep<VK_T_DIRECT>(p, grid, e->stream); break;
     case VK_T_RAWKEYS: launch_sweep<VK_T_RAWKEYS>(p, grid, e->stream); break;
     default: return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
     }
@@ -638,6 +659,9 @@ extern "C" int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, cons
         case VK_T_LCG: launch_transform<VK_T_LCG>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
         case VK_T_XORSHIFT: launch_transform<VK_T_XORSHIFT>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
         case VK_T_SHA256_CHAIN: launch_transform<VK_T_SHA256_CHAIN>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
+        case VK_T_DOUBLE_SHA256: launch_transform<VK_T_DOUBLE_SHA256>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
+        case VK_T_MD5: launch_transform<VK_T_MD5>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
+        case VK_T_DIRECT: launch_transform<VK_T_DIRECT>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
         default: cleanup(); return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
         }
         c = hipGetLastError();
@@ -683,9 +707,10 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
     if (rc) return rc;
     if (n == 0) return VK_OK;
     if (!data || !offsets || !keys_out || !valid) return fail(e, VK_E_INVALID_ARG, "data / offsets / keys_out / valid is NULL");
-    const u32 slots = vk_slots_per_input(t);
+    const u32 slots = vk_slots_per_string(t);
     if ((u64)n * slots > (1ull << 28)) return fail(e, VK_E_INVALID_ARG, "too many keys for one vk_transform_strings call (max 2^28)");
-    const u32 max_len = t->kind == VK_T_MULTIBIT ? VK_MULTIBIT_MAX_MNEMONIC : VK_ELECTRUM_MAX_SEED;
+    const bool kdf = t->kind == VK_T_ELECTRUM || t->kind == VK_T_MULTIBIT;
+    const u32 max_len = t->kind == VK_T_MULTIBIT ? VK_MULTIBIT_MAX_MNEMONIC : kdf ? VK_ELECTRUM_MAX_SEED : 0x7FFFFFFFu;
     for (size_t i = 0; i < n; i++) {
         if (offsets[i + 1] < offsets[i]) return fail(e, VK_E_INVALID_ARG, "offsets must be non-decreasing");
         if (offsets[i + 1] - offsets[i] > max_len) return fail(e, VK_E_UNSUPPORTED, "string too long for this transform on the device (electrum 64, multibit 256 bytes)");
@@ -703,7 +728,10 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
     if (c == hipSuccess) c = hipMemsetAsync(d_keys, 0, items * 32, e->stream);
     if (c == hipSuccess) c = hipMemsetAsync(d_valid, 0, items, e->stream);
     if (c == hipSuccess) {
-        if (t->kind == VK_T_MULTIBIT)
+        if (!kdf)
+            hipLaunchKernelGGL(vk_strings_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, to_dev(t), d_data, d_offs,
+                               (u64)n, slots, d_keys, d_valid);
+        else if (t->kind == VK_T_MULTIBIT)
             hipLaunchKernelGGL(vk_multibit_kernel, dim3((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_data, d_offs, (u64)n,
                                t->chain_depth, e->d_wordlist, e->table, e->d_wins, e->nwin, d_keys, d_valid);
         else

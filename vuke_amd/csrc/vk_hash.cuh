@@ -193,3 +193,117 @@ VK_DEV void hash160_pub65(u32 out[5], const fe &x, const fe &y)
     sha256_pub65(d, x, y);
     ripemd160_of_digest(out, d);
 }
+
+// ---- MD5 (RFC 1321), for the md5 transform (src/transform/md5.rs:13-21; md-5 crate) -------------------------
+__device__ __constant__ const u32 VK_MD5_K[64] = {
+    0xd76aa478u, 0xe8c7b756u, 0x242070dbu, 0xc1bdceeeu, 0xf57c0fafu, 0x4787c62au, 0xa8304613u, 0xfd469501u,
+    0x698098d8u, 0x8b44f7afu, 0xffff5bb1u, 0x895cd7beu, 0x6b901122u, 0xfd987193u, 0xa679438eu, 0x49b40821u,
+    0xf61e2562u, 0xc040b340u, 0x265e5a51u, 0xe9b6c7aau, 0xd62f105du, 0x02441453u, 0xd8a1e681u, 0xe7d3fbc8u,
+    0x21e1cde6u, 0xc33707d6u, 0xf4d50d87u, 0x455a14edu, 0xa9e3e905u, 0xfcefa3f8u, 0x676f02d9u, 0x8d2a4c8au,
+    0xfffa3942u, 0x8771f681u, 0x6d9d6122u, 0xfde5380cu, 0xa4beea44u, 0x4bdecfa9u, 0xf6bb4b60u, 0xbebfbc70u,
+    0x289b7ec6u, 0xeaa127fau, 0xd4ef3085u, 0x04881d05u, 0xd9d4d039u, 0xe6db99e5u, 0x1fa27cf8u, 0xc4ac5665u,
+    0xf4292244u, 0x432aff97u, 0xab9423a7u, 0xfc93a039u, 0x655b59c3u, 0x8f0ccc92u, 0xffeff47du, 0x85845dd1u,
+    0x6fa87e4fu, 0xfe2ce6e0u, 0xa3014314u, 0x4e0811a1u, 0xf7537e82u, 0xbd3af235u, 0x2ad7d2bbu, 0xeb86d391u};
+
+#define VK_MD5_IV {0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u}
+
+// one compression; m[16] = the block as little-endian words
+VK_DEV void md5_compress(u32 st[4], const u32 m[16])
+{
+    u32 a = st[0], b = st[1], c = st[2], d = st[3];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        u32 f;
+        int g, r;
+        if (i < 16) {
+            f = VK_BITOP3(b, c, d, 0xCA); // (b & c) | (~b & d)
+            g = i;
+            r = (i & 3) == 0 ? 7 : (i & 3) == 1 ? 12 : (i & 3) == 2 ? 17 : 22;
+        } else if (i < 32) {
+            f = VK_BITOP3(d, b, c, 0xCA); // (d & b) | (~d & c)
+            g = (5 * i + 1) & 15;
+            r = (i & 3) == 0 ? 5 : (i & 3) == 1 ? 9 : (i & 3) == 2 ? 14 : 20;
+        } else if (i < 48) {
+            f = xor3(b, c, d);
+            g = (3 * i + 5) & 15;
+            r = (i & 3) == 0 ? 4 : (i & 3) == 1 ? 11 : (i & 3) == 2 ? 16 : 23;
+        } else {
+            f = VK_BITOP3(b, c, d, 0x39); // c ^ (b | ~d)
+            g = (7 * i) & 15;
+            r = (i & 3) == 0 ? 6 : (i & 3) == 1 ? 10 : (i & 3) == 2 ? 15 : 21;
+        }
+        const u32 t = a + f + VK_MD5_K[i] + m[g];
+        a = d;
+        d = c;
+        c = b;
+        b = b + rotl32(t, r);
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d;
+}
+
+// ---- streaming forms: a byte string in global memory followed by <= 12 suffix bytes held in registers -----
+// (wordlist / stdin inputs of the hash transforms: passphrases of any length)
+struct vk_bytes {
+    const unsigned char *p;
+    u32 len;
+    u32 suf[3]; // suffix bytes, big-endian packed
+    u32 suf_len;
+};
+VK_DEV u32 bytes_at(const vk_bytes &s, u32 i)
+{
+    if (i < s.len) return s.p[i];
+    const u32 j = i - s.len;
+    const u32 w = j < 4 ? s.suf[0] : j < 8 ? s.suf[1] : s.suf[2];
+    return (w >> (24 - 8 * (j & 3))) & 0xffu;
+}
+// message byte q of the padded stream: data, then 0x80, then zeros (the length words are set by the caller)
+VK_DEV u32 padded_at(const vk_bytes &s, u32 total, u32 q) { return q < total ? bytes_at(s, q) : (q == total ? 0x80u : 0u); }
+
+VK_DEV void sha256_stream(u32 out[8], const vk_bytes &s)
+{
+    const u32 total = s.len + s.suf_len, nblk = (total + 9 + 63) / 64;
+    u32 st[8] = VK_SHA256_IV;
+#pragma unroll 1
+    for (u32 blk = 0; blk < nblk; blk++) {
+        u32 w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const u32 q = blk * 64 + 4 * (u32)i;
+            w[i] = q >= total + 1 ? 0u
+                                  : (padded_at(s, total, q) << 24) | (padded_at(s, total, q + 1) << 16) | (padded_at(s, total, q + 2) << 8) |
+                                        padded_at(s, total, q + 3);
+        }
+        if (blk == nblk - 1) {
+            w[14] = total >> 29;
+            w[15] = total << 3;
+        }
+        sha256_compress(st, w);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = st[i];
+}
+
+// MD5 digest as four little-endian state words (digest byte 4j+k = (out[j] >> 8k) & 0xff)
+VK_DEV void md5_stream(u32 out[4], const vk_bytes &s)
+{
+    const u32 total = s.len + s.suf_len, nblk = (total + 9 + 63) / 64;
+    u32 st[4] = VK_MD5_IV;
+#pragma unroll 1
+    for (u32 blk = 0; blk < nblk; blk++) {
+        u32 m[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const u32 q = blk * 64 + 4 * (u32)i;
+            m[i] = q >= total + 1 ? 0u
+                                  : padded_at(s, total, q) | (padded_at(s, total, q + 1) << 8) | (padded_at(s, total, q + 2) << 16) |
+                                        (padded_at(s, total, q + 3) << 24);
+        }
+        if (blk == nblk - 1) {
+            m[14] = total << 3;
+            m[15] = total >> 29;
+        }
+        md5_compress(st, m);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = st[i];
+}

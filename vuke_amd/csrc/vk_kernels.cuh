@@ -429,6 +429,21 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_transform_kernel(vk_spec_dev spec
     valid[idx] = ok ? 1 : 0;
 }
 
+// Transform::apply_batch for Input::from_string inputs of the hash transforms: one lane per (string, slot)
+__global__ void __launch_bounds__(VK_BLOCK) vk_strings_kernel(vk_spec_dev spec, const unsigned char *data, const u32 *offsets, u64 n, u32 slots,
+                                                              u32 *keys_out, unsigned char *valid)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    if (idx >= n * slots) return;
+    const u64 i = idx / slots;
+    const u32 sub = (u32)(idx - i * slots);
+    u32 kw[8];
+    bool ok = transform_string(kw, spec, data + offsets[i], offsets[i + 1] - offsets[i], sub);
+#pragma unroll
+    for (int j = 0; j < 8; j++) keys_out[idx * 8 + j] = ok ? bswap32(kw[j]) : 0u;
+    valid[idx] = ok ? 1 : 0;
+}
+
 // ---------------------------------------------------------------- field test hook
 __global__ void vk_field_kernel(int op, const u32 *a, const u32 *b, u64 n, u32 *out)
 {

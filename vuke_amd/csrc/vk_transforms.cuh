@@ -9,6 +9,7 @@
 //   lcg           src/lcg.rs:68-128, src/transform/lcg.rs:43-72
 //   xorshift      src/xorshift.rs:83-317, src/transform/xorshift.rs:33-52
 //   sha256_chain  src/sha256_chain.rs:88-145, src/transform/sha256_chain.rs:60-94
+//   double_sha256 src/transform/double_sha256.rs:13-32, md5 src/transform/md5.rs:13-21, direct src/transform/direct.rs:13-34
 #pragma once
 #include "vk_hash.cuh"
 
@@ -18,6 +19,11 @@
 #define VK_T_LCG 3u
 #define VK_T_XORSHIFT 4u
 #define VK_T_SHA256_CHAIN 5u
+#define VK_T_ELECTRUM 6u
+#define VK_T_MULTIBIT 7u
+#define VK_T_DOUBLE_SHA256 8u
+#define VK_T_MD5 9u
+#define VK_T_DIRECT 10u
 #define VK_T_RAWKEYS 100u /* keys come from memory (vk_derive_batch) */
 #define VK_VARIANT_ALL 0xFFFFFFFFu
 
@@ -244,6 +250,59 @@ VK_DEV bool transform_sha256(u32 kw[8], u64 seed, u32 sub)
     return true;
 }
 
+// ---- double_sha256: SHA256(SHA256(x)) of the same three forms, same order -----------------------
+VK_DEV bool transform_double_sha256(u32 kw[8], u64 seed, u32 sub)
+{
+    u32 t[8];
+    if (!transform_sha256(t, seed, sub)) return false;
+    sha256_of_digest(kw, t);
+    return true;
+}
+
+// ---- md5: MD5(decimal string) written twice ------------------------------------------------------
+VK_DEV bool transform_md5(u32 kw[8], u64 seed)
+{
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = 0;
+    const u32 len = msg_put_decimal(w, 0, seed); // <= 20 bytes, big-endian packed
+    msg_put(w, len, 0x80u);
+    u32 m[16];
+#pragma unroll
+    for (int i = 0; i < 14; i++) m[i] = bswap32(w[i]);
+    m[14] = len * 8;
+    m[15] = 0;
+    u32 st[4] = VK_MD5_IV;
+    md5_compress(st, m);
+#pragma unroll
+    for (int i = 0; i < 4; i++) kw[i] = kw[4 + i] = bswap32(st[i]);
+    return true;
+}
+
+// ---- direct: slot 0 = 8 BE bytes right-aligned, 1 = 8 LE bytes left-aligned, 2 = the decimal string, zero padded
+VK_DEV bool transform_direct(u32 kw[8], u64 seed, u32 sub)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) kw[i] = 0;
+    if (sub == 0) {
+        kw[6] = (u32)(seed >> 32);
+        kw[7] = (u32)seed;
+    } else if (sub == 1) {
+        kw[0] = bswap32((u32)seed);
+        kw[1] = bswap32((u32)(seed >> 32));
+    } else if (sub == 2) {
+        u32 w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = 0;
+        msg_put_decimal(w, 0, seed);
+#pragma unroll
+        for (int i = 0; i < 8; i++) kw[i] = w[i];
+    } else {
+        return false;
+    }
+    return true;
+}
+
 // ---- sha256_chain ---------------------------------------------------------------------------
 // slot = form*(V*D) + v*D + idx; form 0: seed bytes = decimal string, form 1: 4-byte BE (u32 only)
 VK_DEV bool transform_sha256_chain(u32 kw[8], u64 seed, u32 sub, u32 spec_variant, u32 depth)
@@ -292,8 +351,11 @@ VK_DEV bool transform_sha256_chain(u32 kw[8], u64 seed, u32 sub, u32 spec_varian
 VK_DEV u32 spec_slots(const vk_spec_dev &s)
 {
     switch (s.kind) {
-    case VK_T_SHA256: return 3;
+    case VK_T_SHA256:
+    case VK_T_DOUBLE_SHA256:
+    case VK_T_DIRECT: return 3;
     case VK_T_MILKSAD:
+    case VK_T_MD5:
     case VK_T_MT64: return 1;
     case VK_T_LCG:
     case VK_T_XORSHIFT: return s.variant == VK_VARIANT_ALL ? 4u : 1u;
@@ -311,5 +373,89 @@ VK_DEV bool transform_key(u32 kw[8], const vk_spec_dev &s, u64 seed, u32 sub)
     if (KIND == VK_T_LCG) return transform_lcg(kw, seed, s.variant == VK_VARIANT_ALL ? sub : s.variant, s.endian);
     if (KIND == VK_T_XORSHIFT) return transform_xorshift(kw, seed, s.variant == VK_VARIANT_ALL ? sub : s.variant);
     if (KIND == VK_T_SHA256_CHAIN) return transform_sha256_chain(kw, seed, sub, s.variant, s.chain_depth);
+    if (KIND == VK_T_DOUBLE_SHA256) return transform_double_sha256(kw, seed, sub);
+    if (KIND == VK_T_MD5) return transform_md5(kw, seed);
+    if (KIND == VK_T_DIRECT) return transform_direct(kw, seed, sub);
+    return false;
+}
+
+// ---- string inputs (Input::from_string: no numeric forms): one key per string for the hash transforms,
+// variants x depth for sha256_chain (src/transform/sha256_chain.rs:60-72).  Returns false where nothing is emitted.
+VK_DEV u32 string_slots(const vk_spec_dev &s)
+{
+    switch (s.kind) {
+    case VK_T_SHA256:
+    case VK_T_DOUBLE_SHA256:
+    case VK_T_MD5:
+    case VK_T_DIRECT: return 1;
+    case VK_T_SHA256_CHAIN: return (s.variant == VK_VARIANT_ALL ? 4u : 1u) * s.chain_depth;
+    default: return 0;
+    }
+}
+
+VK_DEV bool transform_string(u32 kw[8], const vk_spec_dev &s, const unsigned char *str, u32 len, u32 sub)
+{
+    vk_bytes b;
+    b.p = str;
+    b.len = len;
+    b.suf[0] = b.suf[1] = b.suf[2] = 0;
+    b.suf_len = 0;
+    if (s.kind == VK_T_SHA256) {
+        sha256_stream(kw, b);
+        return true;
+    }
+    if (s.kind == VK_T_DOUBLE_SHA256) {
+        u32 t[8];
+        sha256_stream(t, b);
+        sha256_of_digest(kw, t);
+        return true;
+    }
+    if (s.kind == VK_T_MD5) {
+        u32 st[4];
+        md5_stream(st, b);
+#pragma unroll
+        for (int i = 0; i < 4; i++) kw[i] = kw[4 + i] = bswap32(st[i]);
+        return true;
+    }
+    if (s.kind == VK_T_DIRECT) {
+        if (len > 32) return false;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            u32 w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) w |= ((u32)(4 * i + k) < len ? (u32)str[4 * i + k] : 0u) << (24 - 8 * k);
+            kw[i] = w;
+        }
+        return true;
+    }
+    if (s.kind == VK_T_SHA256_CHAIN) {
+        const u32 depth = s.chain_depth;
+        if (depth == 0) return false;
+        const u32 v = s.variant == VK_VARIANT_ALL ? sub / depth : s.variant, idx = sub % depth;
+        if (v > 3 || (s.variant != VK_VARIANT_ALL && sub >= depth)) return false;
+        if (v == 1 || v == 2) {
+            b.suf[0] = v == 1 ? idx : bswap32(idx);
+            b.suf_len = 4;
+        } else if (v == 3) {
+            u32 w[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) w[i] = 0;
+            b.suf_len = msg_put_decimal(w, 0, (u64)idx);
+            b.suf[0] = w[0];
+            b.suf[1] = w[1];
+            b.suf[2] = w[2];
+        }
+        sha256_stream(kw, b);
+        if (v == 0) {
+#pragma unroll 1
+            for (u32 i = 0; i < idx; i++) {
+                u32 t[8];
+                sha256_of_digest(t, kw);
+#pragma unroll
+                for (int j = 0; j < 8; j++) kw[j] = t[j];
+            }
+        }
+        return true;
+    }
     return false;
 }

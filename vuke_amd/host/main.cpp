@@ -18,10 +18,13 @@ using namespace vuke;
 static int usage(const char *msg)
 {
     if (msg) fprintf(stderr, "error: %s\n\n", msg);
-    fprintf(stderr, "Usage: vuke-hip <generate|scan|single> [OPTIONS] range --start <START> --end <END>\n"
+    fprintf(stderr, "Usage: vuke-hip <generate|scan> [OPTIONS] <SOURCE>\n"
+                    "       vuke-hip single <PASSPHRASE> --transform <T>\n"
                     "       vuke-hip analyze <KEY> [--mask BITS] [--cascade b:t,b:t,...] [--analyzer milksad|lcg[:variant][:endian]|mt64|xorshift[:variant]|sha256_chain[:variant]]...\n"
-                    "  --transform <T>...   sha256 | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] | sha256_chain[:variant] | electrum[:change] | multibit\n"
-                    "  sources: range --start A --end B | wordlist --file F (string transforms: electrum[:change])\n"
+                    "  --transform <T>...   sha256 | double_sha256 | md5 | direct | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] |\n"
+                    "                       sha256_chain[:variant] | electrum[:change] | multibit\n"
+                    "  sources: range --start A --end B | timestamps --start YYYY-MM-DD --end YYYY-MM-DD [--microseconds] |\n"
+                    "           wordlist --file F | stdin   (passphrase sources feed the string form of each transform)\n"
                     "  --targets <FILE>     (scan) one address per line\n"
                     "  -v, --verbose        (generate) all key formats\n"
                     "  -o, --output <FILE>  write to FILE instead of stdout\n"
@@ -43,6 +46,13 @@ static uint64_t parse_u64(const char *s)
     unsigned long long v = strtoull(s, &end, 10);
     if (errno || !end || *end || s[0] == '-' || !s[0]) throw std::invalid_argument(std::string("invalid value '") + s + "' for a u64 argument");
     return v;
+}
+
+static bool is_source_word(const char *a)
+{
+    for (const char *w : {"range", "wordlist", "stdin", "timestamps"})
+        if (strcmp(a, w) == 0) return true;
+    return false;
 }
 
 // `vuke analyze KEY [--mask N] [--cascade b:t,...] [--analyzer milksad|lcg[:variant][:endian]|mt64]...` (src/main.rs:307-360)
@@ -121,8 +131,8 @@ int main(int argc, char **argv)
     if (cmd != "generate" && cmd != "scan" && cmd != "single") return usage("unknown subcommand");
     std::vector<std::string> tnames;
     std::string targets, outpath, single_value;
-    bool verbose = false, have_range = false, have_start = false, have_end = false, have_wordlist = false;
-    std::string wordlist_file, bip39_file;
+    bool verbose = false, have_range = false, have_start = false, have_end = false, have_wordlist = false, have_timestamps = false, microseconds = false;
+    std::string wordlist_file, bip39_file, start_s, end_s;
     uint64_t start = 0, end = 0;
     int device = 0;
     unsigned window_bits = 0, layout = VK_LAYOUT_UNIFORM;
@@ -135,7 +145,7 @@ int main(int argc, char **argv)
             };
             if (a == "--transform") {
                 tnames.push_back(need("--transform"));
-                while (i + 1 < argc && argv[i + 1][0] != '-' && strcmp(argv[i + 1], "range") != 0) tnames.push_back(argv[++i]); // num_args = 1..
+                while (cmd != "single" && i + 1 < argc && argv[i + 1][0] != '-' && !is_source_word(argv[i + 1])) tnames.push_back(argv[++i]); // num_args = 1..
             } else if (a == "--targets") targets = need("--targets");
             else if (a == "-o" || a == "--output") outpath = need("--output");
             else if (a == "-v" || a == "--verbose") verbose = true;
@@ -145,10 +155,13 @@ int main(int argc, char **argv)
             else if (a == "--layout") layout = std::string(need("--layout")) == "signed9" ? VK_LAYOUT_SIGNED9 : VK_LAYOUT_UNIFORM;
             else if (a == "range") have_range = true;
             else if (a == "wordlist") have_wordlist = true;
+            else if (a == "stdin") { have_wordlist = true; wordlist_file = "-"; }
+            else if (a == "timestamps") have_timestamps = true;
+            else if (a == "--microseconds") microseconds = true;
             else if (a == "--file") wordlist_file = need("--file");
             else if (a == "--bip39-wordlist") bip39_file = need("--bip39-wordlist");
-            else if (a == "--start") { start = parse_u64(need("--start")); have_start = true; }
-            else if (a == "--end") { end = parse_u64(need("--end")); have_end = true; }
+            else if (a == "--start") { start_s = need("--start"); have_start = true; }
+            else if (a == "--end") { end_s = need("--end"); have_end = true; }
             else if (cmd == "single" && single_value.empty() && a[0] != '-') single_value = a;
             else throw std::invalid_argument("unexpected argument '" + a + "'");
         }
@@ -158,8 +171,13 @@ int main(int argc, char **argv)
         for (auto &n : tnames) transforms.push_back(TransformType::from_str(n));
         if (cmd == "scan" && targets.empty()) throw std::invalid_argument("the following required arguments were not provided: --targets <TARGETS>");
         if (cmd != "single" && have_wordlist && wordlist_file.empty()) throw std::invalid_argument("wordlist needs --file <FILE>");
-        if (cmd != "single" && !have_wordlist && (!have_range || !have_start || !have_end))
-            throw std::invalid_argument("sources on the device path: `range --start A --end B` and `wordlist --file F`");
+        if (cmd != "single" && !have_wordlist && ((!have_range && !have_timestamps) || !have_start || !have_end))
+            throw std::invalid_argument("sources on the device path: `range --start A --end B`, `timestamps --start DATE --end DATE [--microseconds]`, "
+                                        "`wordlist --file F`, `stdin`");
+        if (have_range) {
+            start = parse_u64(start_s.c_str());
+            end = parse_u64(end_s.c_str());
+        }
         if (cmd != "single" && have_range && end < start) throw std::invalid_argument("--end must be >= --start");
 
         vk_engine *engine = nullptr;
@@ -179,21 +197,25 @@ int main(int argc, char **argv)
                 break;
             }
 
-        if (cmd == "single") {
-            if (single_value.empty()) throw std::invalid_argument("single needs a numeric VALUE");
-            const uint64_t v = parse_u64(single_value.c_str());
+        if (cmd == "single") { // run_single, src/main.rs:954-992: the value is a passphrase (Input::from_string)
+            if (single_value.empty()) throw std::invalid_argument("single needs a PASSPHRASE");
             KeyDeriver deriver(engine);
             for (const Transform &t : transforms) {
                 std::vector<std::pair<std::string, Key>> out;
-                t.apply_batch(engine, std::vector<uint64_t>{v}, out);
+                t.apply_batch(engine, std::vector<std::string>{single_value}, out);
+                if (out.empty()) {
+                    fprintf(stderr, "No key generated from passphrase.\n");
+                    continue;
+                }
                 for (auto &[label, key] : out) {
                     DerivedKey d = deriver.derive(key);
-                    printf("Passphrase: \"%s\"\nTransform: %s\nSource: %s\n---\nPrivate Key (hex): %s\nPrivate Key (decimal): %s\n"
-                           "Bit Length: %u\nHamming Weight: %u\nWIF (compressed): %s\nWIF (uncompressed): %s\n---\n"
-                           "P2PKH (compressed): %s\nP2PKH (uncompressed): %s\nP2WPKH: %s\n\n",
+                    printf("Passphrase: \"%s\"\nTransform: %s\nSource: %s\n---\nPrivate Key (hex):     %s\nPrivate Key (decimal): %s\n"
+                           "Private Key (binary):  %s\nBit Length:            %u\nHamming Weight:        %u\nLeading Zeros (hex):   %u\n"
+                           "WIF (compressed):      %s\nWIF (uncompressed):    %s\n---\n"
+                           "P2PKH (compressed):   %s\nP2PKH (uncompressed): %s\nP2WPKH:               %s\n",
                            single_value.c_str(), t.name(), label.c_str(), d.private_key_hex.c_str(), d.private_key_decimal.c_str(),
-                           d.bit_length, d.hamming_weight, d.wif_compressed.c_str(), d.wif_uncompressed.c_str(),
-                           d.p2pkh_compressed.c_str(), d.p2pkh_uncompressed.c_str(), d.p2wpkh.c_str());
+                           d.private_key_binary.c_str(), d.bit_length, d.hamming_weight, d.leading_zeros, d.wif_compressed.c_str(),
+                           d.wif_uncompressed.c_str(), d.p2pkh_compressed.c_str(), d.p2pkh_uncompressed.c_str(), d.p2wpkh.c_str());
                 }
             }
             return 0;
@@ -205,6 +227,7 @@ int main(int argc, char **argv)
         else out = std::make_unique<ConsoleOutput>();
         std::unique_ptr<Source> source_ptr;
         if (have_wordlist) source_ptr = std::make_unique<HipWordlistSource>(engine, wordlist_file);
+        else if (have_timestamps) source_ptr = std::make_unique<HipTimestampSource>(engine, start_s, end_s, microseconds);
         else source_ptr = std::make_unique<HipRangeSource>(engine, start, end);
         Source &source = *source_ptr;
         ProcessStats stats;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstring>
 #include <fstream>
+#include <iostream>
 #include <thread>
 
 namespace vuke {
@@ -72,10 +73,12 @@ static void emit_keys(vk_engine *engine, const Transform &t, const std::vector<s
 
 ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output)
 {
-    std::ifstream f(path);
-    if (!f) throw std::runtime_error("cannot open wordlist: " + path);
-    for (const Transform &t : transforms)
-        if (!t.takes_strings()) throw std::invalid_argument(std::string("transform '") + t.name() + "' is not built for string inputs on the device path");
+    std::ifstream file;
+    if (path != "-") {
+        file.open(path);
+        if (!file) throw std::runtime_error("cannot open wordlist: " + path);
+    }
+    std::istream &f = path == "-" ? std::cin : file;
     ProcessStats st;
     if (matcher) {
         std::vector<uint8_t> h160, kind;
@@ -83,24 +86,77 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
         check_rc(engine_, vk_targets_set(engine_, h160.data(), kind.data(), kind.size()));
     }
     std::vector<std::string> lines;
+    size_t bytes = 0;
     auto flush = [&]() {
         for (const Transform &t : transforms) {
             std::vector<std::pair<std::string, Key>> batch;
-            t.apply_batch(engine_, lines, batch);
+            t.apply_batch(engine_, lines, batch); // nothing for transforms that need a numeric seed
             emit_keys(engine_, t, batch, matcher, output, st);
         }
         st.inputs_processed += lines.size();
         lines.clear();
+        bytes = 0;
     };
+    auto ws = [](unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; };
     std::string line;
-    while (std::getline(f, line)) { // src/source/wordlist.rs: lines are taken as they are, empty ones skipped
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (line.empty()) continue;
-        lines.push_back(line);
-        if (lines.size() == 262144) flush(); // enough lanes to fill the chip (256 CUs x 1024)
+    while (std::getline(f, line)) { // src/source/wordlist.rs:24-30, src/source/stdin.rs:45-50: trim, skip empty lines
+        size_t a = 0, b = line.size();
+        while (a < b && ws((unsigned char)line[a])) a++;
+        while (b > a && ws((unsigned char)line[b - 1])) b--;
+        if (a == b) continue;
+        lines.emplace_back(line, a, b - a);
+        bytes += b - a;
+        if (lines.size() == 262144 || bytes > (64u << 20)) flush(); // enough lanes to fill the chip (256 CUs x 1024)
     }
     if (!lines.empty()) flush();
     if (matcher) check_rc(engine_, vk_targets_set(engine_, nullptr, nullptr, 0));
+    return st;
+}
+
+// days since 1970-01-01 of a proleptic Gregorian date (chrono NaiveDate::parse_from_str "%Y-%m-%d")
+static int64_t days_from_civil(int64_t y, unsigned m, unsigned d)
+{
+    y -= m <= 2;
+    const int64_t era = (y >= 0 ? y : y - 399) / 400;
+    const unsigned yoe = (unsigned)(y - era * 400);
+    const unsigned doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+    const unsigned doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+    return era * 146097 + (int64_t)doe - 719468;
+}
+
+static uint64_t parse_date(const std::string &s, bool end_of_day)
+{
+    int y = 0;
+    unsigned m = 0, d = 0;
+    char tail = 0;
+    if (sscanf(s.c_str(), "%d-%u-%u%c", &y, &m, &d, &tail) != 3 || m < 1 || m > 12 || d < 1) throw std::invalid_argument("invalid date '" + s + "' (expected YYYY-MM-DD)");
+    static const unsigned DIM[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+    const bool leap = (y % 4 == 0 && y % 100 != 0) || y % 400 == 0;
+    if (d > DIM[m - 1] + (m == 2 && leap ? 1u : 0u)) throw std::invalid_argument("invalid date '" + s + "' (expected YYYY-MM-DD)");
+    const int64_t t = days_from_civil(y, m, d) * 86400 + (end_of_day ? 86399 : 0);
+    return (uint64_t)t; // `as u64`, src/source/timestamps.rs:28,35
+}
+
+HipTimestampSource::HipTimestampSource(vk_engine *engine, const std::string &start_date, const std::string &end_date, bool us)
+    : start(parse_date(start_date, false)), end(parse_date(end_date, true)), microseconds(us), engine_(engine)
+{
+    if (end < start) throw std::invalid_argument("timestamps: --end is before --start");
+}
+
+ProcessStats HipTimestampSource::process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output)
+{
+    // src/source/timestamps.rs:49-90: every second ts of the range, and with `microseconds` also ts*1000 + 0..999.
+    // Both sets are contiguous, so they are two range sweeps.
+    ProcessStats st = HipRangeSource(engine_, start, end).process(transforms, matcher, output);
+    const uint64_t count = end - start + 1;
+    st.inputs_processed = count; // :50-55
+    if (microseconds) {
+        if (end > (~0ull - 999) / 1000) throw std::invalid_argument("timestamps: range too large for --microseconds");
+        ProcessStats ms = HipRangeSource(engine_, start * 1000, end * 1000 + 999).process(transforms, matcher, output);
+        st.keys_generated += ms.keys_generated;
+        st.matches_found += ms.matches_found;
+        st.inputs_processed = count * 1000; // the reference reports count * 1000 although it walks 1001 values per second
+    }
     return st;
 }
 

@@ -76,7 +76,10 @@ Transform TransformType::from_str(const std::string &raw)
         sp.chain_depth = 20;
         return Transform(sp);
     }
-    for (const char *n : {"direct", "double_sha256", "md5", "armory", "bitimage"})
+    if (s == "double_sha256") { sp.kind = VK_T_DOUBLE_SHA256; return Transform(sp); }
+    if (s == "md5") { sp.kind = VK_T_MD5; return Transform(sp); }
+    if (s == "direct") { sp.kind = VK_T_DIRECT; return Transform(sp); }
+    for (const char *n : {"armory", "bitimage"})
         if (s == n) return unsupported(n);
     if (s == "lcg" || s.rfind("lcg:", 0) == 0) { // LcgConfig::parse
         auto parts = split_colon(s);
@@ -145,6 +148,9 @@ const char *Transform::name() const
 {
     switch (spec_.kind) {
     case VK_T_SHA256: return "sha256";
+    case VK_T_DOUBLE_SHA256: return "double_sha256";
+    case VK_T_MD5: return "md5";
+    case VK_T_DIRECT: return "direct";
     case VK_T_MILKSAD: return "milksad";
     case VK_T_MT64: return "mt64";
     case VK_T_LCG: return "lcg";
@@ -203,6 +209,11 @@ std::string Transform::label(const std::string &input, uint32_t sub) const
         std::string shown = w.size() <= 4 ? input : w[0] + " " + w[1] + "..." + w[w.size() - 2] + " " + w[w.size() - 1];
         return shown + "[m/0'/0/" + std::to_string(sub) + "]";
     }
+    if (spec_.kind == VK_T_SHA256_CHAIN) { // "{seed}[{variant}:{idx}]", src/transform/sha256_chain.rs:67
+        const bool all = spec_.variant == VK_VARIANT_ALL;
+        const uint32_t d = spec_.chain_depth ? spec_.chain_depth : 1;
+        return input + "[" + CH_NAMES[(all ? sub / d : spec_.variant) & 3] + ":" + std::to_string(sub % d) + "]";
+    }
     return input;
 }
 
@@ -223,14 +234,14 @@ void load_bip39_wordlist(vk_engine *e, const std::string &path)
 
 void Transform::apply_batch(vk_engine *e, const std::vector<std::string> &inputs, std::vector<std::pair<std::string, Key>> &output) const
 {
-    const uint32_t k = slots();
-    if (inputs.empty() || k == 0) return;
+    const uint32_t k = string_slots();
+    if (inputs.empty() || k == 0) return; // k == 0: a transform that needs Input::u64_val pushes nothing
     // strings the device entry point cannot take (longer than 64 bytes) can still be valid hex seeds in the
     // reference; they are reported, not silently dropped
     std::vector<uint8_t> data;
     std::vector<uint32_t> offs{0};
     for (const std::string &s : inputs) {
-        if (s.size() > (spec_.kind == VK_T_MULTIBIT ? 256u : 64u))
+        if (takes_strings() && s.size() > (spec_.kind == VK_T_MULTIBIT ? 256u : 64u))
             throw std::invalid_argument("input string too long for the device path (electrum 64, multibit 256 bytes)");
         data.insert(data.end(), s.begin(), s.end());
         offs.push_back((uint32_t)data.size());

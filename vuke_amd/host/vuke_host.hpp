@@ -96,6 +96,8 @@ public:
     uint32_t slots() const { return vk_slots_per_input(&spec_); }
     std::string label(uint64_t seed, uint32_t sub) const;  // the `source` string apply_batch pushes
     std::string label(const std::string &input, uint32_t sub) const; // same for Input::from_string inputs
+    uint32_t string_slots() const { return vk_slots_per_string(&spec_); } // keys per Input::from_string input (0: none)
+    // electrum / multibit read only Input::string_val: numeric sources hand them the decimal string
     bool takes_strings() const { return spec_.kind == VK_T_ELECTRUM || spec_.kind == VK_T_MULTIBIT; }
     // apply_batch for string inputs (wordlist / stdin sources), on the device
     void apply_batch(vk_engine *e, const std::vector<std::string> &inputs, std::vector<std::pair<std::string, Key>> &output) const;
@@ -109,8 +111,8 @@ private:
 
 struct TransformType {
     // TransformType::from_str (src/transform/mod.rs:170-215): throws std::invalid_argument with the
-    // reference's message for unknown names; transforms outside the device path (direct, md5, armory,
-    // multibit, electrum, bitimage, double_sha256) are recognised and rejected as unsupported.
+    // reference's message for unknown names; transforms outside the device path (armory, bitimage) are
+    // recognised and rejected as unsupported.
     static Transform from_str(const std::string &s);
 };
 
@@ -163,13 +165,27 @@ private:
     vk_engine *engine_;
 };
 
-// WordlistSource on the GPU (src/source/wordlist.rs): one passphrase per line, Input::from_string.
-// Built for the string-input transforms of the device path (electrum).
+// WordlistSource / StdinSource on the GPU (src/source/wordlist.rs, src/source/stdin.rs): one passphrase per line,
+// trimmed, empty lines skipped, Input::from_string.  path "-" reads stdin.  Transforms that need a numeric seed
+// emit nothing for these inputs, exactly like the reference.
 class HipWordlistSource : public Source {
 public:
     HipWordlistSource(vk_engine *engine, std::string path) : path(std::move(path)), engine_(engine) {}
     ProcessStats process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output) override;
     std::string path;
+
+private:
+    vk_engine *engine_;
+};
+
+// TimestampSource on the GPU (src/source/timestamps.rs): every second of [start_date 00:00:00, end_date 23:59:59] UTC
+// and, with `microseconds`, the thousand values ts*1000 + 0..999 behind each second -- two (or one) range sweeps.
+class HipTimestampSource : public Source {
+public:
+    HipTimestampSource(vk_engine *engine, const std::string &start_date, const std::string &end_date, bool microseconds); // throws on bad dates
+    ProcessStats process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output) override;
+    uint64_t start, end;
+    bool microseconds;
 
 private:
     vk_engine *engine_;
