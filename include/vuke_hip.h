@@ -62,6 +62,8 @@ extern "C" {
 #define VK_T_MD5 9u           /* src/transform/md5.rs:13-21: MD5(decimal string) twice, key[0..16] = key[16..32] */
 #define VK_T_DIRECT 10u       /* src/transform/direct.rs:13-34: slot 0 = 8 BE bytes right-aligned, 1 = 8 LE bytes left-aligned,
                                 2 = the string zero padded to 32 bytes (strings longer than 32 bytes emit nothing) */
+#define VK_T_ARMORY 11u       /* src/transform/armory.rs:21-101: root seed -> chaincode -> 4 chained key*G multiplications;
+                                slot 0 seed = SHA256(decimal string), slot 1 seed = 24 zero bytes || 8 BE bytes */
 #define VK_VARIANT_ALL 0xFFFFFFFFu
 
 typedef struct vk_transform_spec {
@@ -177,7 +179,7 @@ int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words /* 16384 bytes */);
 
 /* Transform::apply_batch for string inputs (Input::from_string; wordlist / stdin sources).  String i is
  * data[offsets[i] .. offsets[i+1]).  slots = vk_slots_per_string(t): the hash transforms (sha256, double_sha256, md5,
- * direct) emit one key per string of any length, sha256_chain variants x depth, VK_T_ELECTRUM (strings up to 64
+ * direct) and armory emit one key per string of any length, sha256_chain variants x depth, VK_T_ELECTRUM (strings up to 64
  * bytes) and VK_T_MULTIBIT (up to 256 bytes; longer strings return VK_E_UNSUPPORTED) chain_depth keys; the PRNG
  * transforms need a numeric seed and return VK_E_UNSUPPORTED.  keys_out = n*slots*32, valid = n*slots, slot order = emit order. */
 int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,

@@ -365,3 +365,19 @@ void vko_md5(const uint8_t *msg, size_t len, uint8_t out[16])
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) out[4 * i + j] = (uint8_t)(h[i] >> (8 * j));
 }
+
+/* ------------------------------------------------------------------ HMAC-SHA256 (RFC 2104), armory chaincode */
+void vko_hmac_sha256(const uint8_t *key, size_t klen, const uint8_t *msg, size_t mlen, uint8_t out[32])
+{
+    uint8_t k[64], buf[64 + 1024], inner[32];
+    memset(k, 0, sizeof k);
+    if (klen > 64) vko_sha256(key, klen, k);
+    else memcpy(k, key, klen);
+    if (mlen > 1024) { memset(out, 0, 32); return; } /* oracle use: short fixed messages */
+    for (int i = 0; i < 64; i++) buf[i] = k[i] ^ 0x36;
+    memcpy(buf + 64, msg, mlen);
+    vko_sha256(buf, 64 + mlen, inner);
+    for (int i = 0; i < 64; i++) buf[i] = k[i] ^ 0x5c;
+    memcpy(buf + 64, inner, 32);
+    vko_sha256(buf, 96, out);
+}

@@ -238,6 +238,24 @@ int vko_scalar_add(const uint8_t a[32], const uint8_t b[32], uint8_t out[32])
     return (r[0] | r[1] | r[2] | r[3]) != 0;
 }
 
+/* a * b mod n by double-and-add over the bits of b (SecretKey::mul_tweak); returns 0 if the product is zero */
+int vko_scalar_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32])
+{
+    uint64_t x[4], y[4], r[4] = {0, 0, 0, 0};
+    sc_from_be(x, a); sc_from_be(y, b);
+    if (ge4(x, ORDER_N)) sub4(x, x, ORDER_N);
+    for (int bit = 255; bit >= 0; bit--) {
+        uint64_t c = add4(r, r, r);
+        if (c || ge4(r, ORDER_N)) sub4(r, r, ORDER_N);
+        if ((y[bit / 64] >> (bit % 64)) & 1) {
+            c = add4(r, r, x);
+            if (c || ge4(r, ORDER_N)) sub4(r, r, ORDER_N);
+        }
+    }
+    sc_to_be(out, r);
+    return (r[0] | r[1] | r[2] | r[3]) != 0;
+}
+
 /* ------------------------------------------------------------------- k * G */
 void vko_pubkey_slow(const uint8_t key[32], uint8_t pub33[33], uint8_t pub65[65])
 {

@@ -172,6 +172,33 @@ int vko_sha256_chain_key(const uint8_t *seed, size_t seedlen, uint32_t variant, 
     return 1;
 }
 
+/* ------------------------------------------------------------------ armory */
+/* ArmoryTransform::generate_key + advance_key (src/transform/armory.rs:21-70) for the 32-byte seeds apply_batch
+ * builds (:84-101).  Returns 0 where the reference returns None: seed not a valid secret key, a tweak >= n
+ * (Scalar::from_be_bytes) or a zero tweak (mul_tweak). */
+int vko_armory_key(const uint8_t seed[32], uint8_t key[32])
+{
+    static const char MSG[] = "Derive Chaincode from Root Key";
+    uint8_t h1[32], h2[32], cc[32], k[32];
+    vko_sha256(seed, 32, h1);
+    vko_sha256(h1, 32, h2);
+    vko_hmac_sha256(h2, 32, (const uint8_t *)MSG, sizeof MSG - 1, cc);
+    if (!vko_scalar_valid(seed)) return 0; /* seed.len() == 32: SecretKey::from_slice(seed) */
+    memcpy(k, seed, 32);
+    for (int step = 0; step < 4; step++) {
+        uint8_t p33[33], p65[65], d1[32], d2[32], s[32], nk[32];
+        vko_pubkey(k, p33, p65);
+        vko_sha256(p65, 65, d1);
+        vko_sha256(d1, 32, d2);
+        for (int i = 0; i < 32; i++) s[i] = d2[i] ^ cc[i];
+        if (!vko_scalar_valid(s)) return 0;
+        if (!vko_scalar_mul(k, s, nk)) return 0;
+        memcpy(k, nk, 32);
+    }
+    memcpy(key, k, 32);
+    return 1;
+}
+
 /* --------------------------------------------------- generic (spec, seed, slot) */
 static const char *XS_NAME[4] = {"xorshift64", "xorshift128", "xorshift128+", "xoroshiro128**"};
 static const char *CH_NAME[4] = {"iterated", "indexed:be", "indexed:le", "counter"};
@@ -185,6 +212,7 @@ uint32_t vko_slots_per_input(const vko_spec *s)
     case VKO_T_MILKSAD:
     case VKO_T_MD5:
     case VKO_T_MT64: return 1;
+    case VKO_T_ARMORY: return 2;
     case VKO_T_LCG:
     case VKO_T_XORSHIFT: return s->variant == VKO_VARIANT_ALL ? 4 : 1;
     case VKO_T_SHA256_CHAIN: return 2u * (s->variant == VKO_VARIANT_ALL ? 4u : 1u) * s->chain_depth;
@@ -200,7 +228,8 @@ uint32_t vko_slots_per_string(const vko_spec *s)
     case VKO_T_SHA256:
     case VKO_T_DOUBLE_SHA256:
     case VKO_T_MD5:
-    case VKO_T_DIRECT: return 1;
+    case VKO_T_DIRECT:
+    case VKO_T_ARMORY: return 1;
     case VKO_T_SHA256_CHAIN: return (s->variant == VKO_VARIANT_ALL ? 4u : 1u) * s->chain_depth;
     default: return 0;
     }
@@ -218,6 +247,7 @@ int vko_transform_string(const vko_spec *s, const uint8_t *str, size_t len, uint
         memset(key, 0, 32);
         memcpy(key, str, len);
         return 1;
+    case VKO_T_ARMORY: if (sub) return 0; vko_sha256(str, len, t); return vko_armory_key(t, key);        /* armory.rs:86-89 */
     case VKO_T_SHA256_CHAIN: { /* sha256_chain.rs:63-72; generate_chain_from_string = chain over the string's bytes */
         uint32_t nv = s->variant == VKO_VARIANT_ALL ? 4u : 1u, d = s->chain_depth;
         if (d == 0 || sub >= nv * d) return 0;
@@ -259,6 +289,13 @@ int vko_transform_key(const vko_spec *s, uint64_t seed, uint32_t sub, uint8_t ke
         if (sub == 1) { for (int j = 0; j < 8; j++) key[j] = (uint8_t)(seed >> (8 * j)); return 1; }
         if (sub == 2) { memcpy(key, dec, (size_t)dl); return 1; } /* a u64 has at most 20 digits */
         return 0;
+    case VKO_T_ARMORY: { /* src/transform/armory.rs:84-101: SHA256(string) as the seed, then 24 zero bytes || BE8 */
+        uint8_t sd[32];
+        if (sub == 0) vko_sha256((const uint8_t *)dec, (size_t)dl, sd);
+        else if (sub == 1) { memset(sd, 0, 24); for (int j = 0; j < 8; j++) sd[24 + j] = (uint8_t)(seed >> (56 - 8 * j)); }
+        else return 0;
+        return vko_armory_key(sd, key);
+    }
     case VKO_T_MILKSAD: return sub == 0 ? vko_milksad_key(seed, key) : 0;
     case VKO_T_MT64: return sub == 0 ? vko_mt64_key(seed, key) : 0;
     case VKO_T_LCG: {
@@ -294,6 +331,7 @@ int vko_transform_label(const vko_spec *s, uint64_t seed, uint32_t sub, char *ou
     case VKO_T_DOUBLE_SHA256:
     case VKO_T_MD5:
     case VKO_T_DIRECT:
+    case VKO_T_ARMORY:
     case VKO_T_MILKSAD:
     case VKO_T_MT64: return snprintf(out, cap, "%llu", sd);
     case VKO_T_LCG: /* src/transform/lcg.rs:54-66 */
@@ -322,6 +360,7 @@ const char *vko_transform_name(const vko_spec *s)
     case VKO_T_DOUBLE_SHA256: return "double_sha256";
     case VKO_T_MD5: return "md5";
     case VKO_T_DIRECT: return "direct";
+    case VKO_T_ARMORY: return "armory";
     case VKO_T_MILKSAD: return "milksad";
     case VKO_T_MT64: return "mt64";
     case VKO_T_LCG: return "lcg";

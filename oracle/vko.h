@@ -39,6 +39,7 @@ void vko_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
 void vko_ripemd160(const uint8_t *msg, size_t len, uint8_t out[20]);
 void vko_hash160(const uint8_t *msg, size_t len, uint8_t out[20]); /* RIPEMD160(SHA256(m)) */
 void vko_md5(const uint8_t *msg, size_t len, uint8_t out[16]);
+void vko_hmac_sha256(const uint8_t *key, size_t klen, const uint8_t *msg, size_t mlen, uint8_t out[32]);
 void vko_sha512(const uint8_t *msg, size_t len, uint8_t out[64]);
 void vko_hmac_sha512(const uint8_t *key, size_t klen, const uint8_t *msg, size_t mlen, uint8_t out[64]);
 void vko_pbkdf2_hmac_sha512(const uint8_t *pw, size_t pwlen, const uint8_t *salt, size_t saltlen,
@@ -58,6 +59,7 @@ enum {
     VKO_T_DOUBLE_SHA256 = 8, /* src/transform/double_sha256.rs:13-32 */
     VKO_T_MD5 = 9,          /* src/transform/md5.rs:13-21 */
     VKO_T_DIRECT = 10,      /* src/transform/direct.rs:13-34 */
+    VKO_T_ARMORY = 11,      /* src/transform/armory.rs:21-101 */
 };
 #define VKO_VARIANT_ALL 0xFFFFFFFFu
 
@@ -75,6 +77,7 @@ int vko_lcg_key(uint64_t seed, uint32_t variant, uint32_t little_endian, uint8_t
 int vko_xorshift_key(uint64_t seed, uint32_t variant, uint8_t key[32]);
 int vko_sha256_chain_key(const uint8_t *seed, size_t seedlen, uint32_t variant, uint32_t index,
                          uint8_t key[32]);
+int vko_armory_key(const uint8_t seed[32], uint8_t key[32]); /* ArmoryTransform::generate_key for a 32-byte seed */
 
 /* Number of (sub_index) slots one input can produce under `spec` (fixed per spec). */
 uint32_t vko_slots_per_input(const vko_spec *spec);
@@ -116,6 +119,7 @@ void vko_pubkey_slow(const uint8_t key[32], uint8_t pub33[33], uint8_t pub65[65]
 void vko_pubkey(const uint8_t key[32], uint8_t pub33[33], uint8_t pub65[65]);
 /* master + tweak mod n (BIP32 / Electrum child keys); returns 0 if result is 0. */
 int vko_scalar_add(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+int vko_scalar_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]); /* a * b mod n; 0 if the product is zero */
 /* 1 if 1 <= k < n */
 int vko_scalar_valid(const uint8_t k[32]);
 

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "build", "libvko.so")
 
-T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM, T_MULTIBIT, T_DOUBLE_SHA256, T_MD5, T_DIRECT = range(11)
+T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM, T_MULTIBIT, T_DOUBLE_SHA256, T_MD5, T_DIRECT, T_ARMORY = range(12)
 VARIANT_ALL = 0xFFFFFFFF
 F_COMPRESSED, F_UNCOMPRESSED, F_FAITHFUL = 1, 2, 0x100
 
@@ -110,6 +110,9 @@ def lib():
         L.vko_slots_per_string.restype = u32
         L.vko_transform_string.argtypes = [C.POINTER(Spec), cp, sz, u32, cp]
         L.vko_md5.argtypes = [cp, sz, cp]
+        L.vko_hmac_sha256.argtypes = [cp, sz, cp, sz, cp]
+        L.vko_scalar_mul.argtypes = [cp, cp, cp]
+        L.vko_armory_key.argtypes = [cp, cp]
         _ = (u8p, u64)
         _lib = L
     return _lib
@@ -181,6 +184,22 @@ def transform_string(sp, s, sub):
         s = s.encode()
     o = _out(32)
     return o.raw if lib().vko_transform_string(C.byref(sp), s, len(s), sub, o) else None
+
+
+def hmac_sha256(key, msg):
+    o = _out(32)
+    lib().vko_hmac_sha256(key, len(key), msg, len(msg), o)
+    return o.raw
+
+
+def scalar_mul(a, b):
+    o = _out(32)
+    return o.raw if lib().vko_scalar_mul(a, b, o) else None
+
+
+def armory_key(seed32):
+    o = _out(32)
+    return o.raw if lib().vko_armory_key(seed32, o) else None
 
 
 def md5(msg):

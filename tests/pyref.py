@@ -62,3 +62,24 @@ def b58check(payload: bytes) -> str:
         n, r = divmod(n, 58)
         s = B58[r] + s
     return "1" * (len(full) - len(full.lstrip(b"\0"))) + s
+
+
+def armory_key(seed: bytes):
+    """Armory root-key chain in python ints + hashlib/hmac: chaincode = HMAC-SHA256(SHA256d(seed), "Derive Chaincode from
+    Root Key"), then four times key <- key * (SHA256d(04||X||Y) xor chaincode) mod n.  None where a secret key / scalar
+    would be rejected (zero or >= n)."""
+    import hmac
+    assert len(seed) == 32
+    h2 = hashlib.sha256(hashlib.sha256(seed).digest()).digest()
+    cc = hmac.new(h2, b"Derive Chaincode from Root Key", hashlib.sha256).digest()
+    k = int.from_bytes(seed, "big")
+    if not 0 < k < N:
+        return None
+    for _ in range(4):
+        pub = pubkeys(k)[1]
+        d = hashlib.sha256(hashlib.sha256(pub).digest()).digest()
+        s = int.from_bytes(bytes(a ^ b for a, b in zip(d, cc)), "big")
+        if not 0 < s < N:
+            return None
+        k = k * s % N
+    return k.to_bytes(32, "big")

@@ -107,6 +107,7 @@ def _specs(vko, ffi):
            (ffi.spec(ffi.T_DOUBLE_SHA256), vko.spec(vko.T_DOUBLE_SHA256)),
            (ffi.spec(ffi.T_MD5), vko.spec(vko.T_MD5)),
            (ffi.spec(ffi.T_DIRECT), vko.spec(vko.T_DIRECT)),
+           (ffi.spec(ffi.T_ARMORY), vko.spec(vko.T_ARMORY)),
            (ffi.spec(ffi.T_MILKSAD), vko.spec(vko.T_MILKSAD)),
            (ffi.spec(ffi.T_MT64), vko.spec(vko.T_MT64))]
     for v in (ffi.VARIANT_ALL, 0, 1, 2, 3):
@@ -482,7 +483,7 @@ def test_hash_transforms_on_strings(eng, vko):
     strings = [b"", b"a", b"abc", b"password", b"correct horse battery staple", b"satoshi nakamoto", "zażółć gęślą jaźń".encode()]
     strings += [bytes(rnd.randrange(1, 256) for _ in range(n)) for n in (31, 32, 33, 54, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 129, 1000, 5000)]
     strings += [bytes(rnd.randrange(32, 127) for _ in range(rnd.randrange(1, 200))) for _ in range(300)]
-    specs = [(ffi.spec(k), vko.spec(k)) for k in (ffi.T_SHA256, ffi.T_DOUBLE_SHA256, ffi.T_MD5, ffi.T_DIRECT)]
+    specs = [(ffi.spec(k), vko.spec(k)) for k in (ffi.T_SHA256, ffi.T_DOUBLE_SHA256, ffi.T_MD5, ffi.T_DIRECT, ffi.T_ARMORY)]
     for v in (ffi.VARIANT_ALL, 0, 1, 2, 3):
         for depth in (1, 4, 11):
             specs.append((ffi.spec(ffi.T_SHA256_CHAIN, v, 0, depth), vko.spec(vko.T_SHA256_CHAIN, v, 0, depth)))
@@ -503,3 +504,32 @@ def test_hash_transforms_on_strings(eng, vko):
     for k in (ffi.T_MILKSAD, ffi.T_MT64, ffi.T_LCG, ffi.T_XORSHIFT):
         with pytest.raises(Exception):
             eng.transform_strings(ffi.spec(k), [b"123"])
+
+
+def test_armory_chain(eng, vko):
+    """armory (src/transform/armory.rs): device vs the oracle and vs the python-int restatement, numeric and string inputs,
+    and through the fused sweep (planted targets)."""
+    import hashlib
+    from vuke_amd import _ffi as ffi
+    gs, os_ = ffi.spec(ffi.T_ARMORY), vko.spec(vko.T_ARMORY)
+    seeds = [0, 1, 2, 12345, 2**32 - 1, 2**32, 2**63, 2**64 - 1, (N - 1) % 2**64, N % 2**64]
+    got = eng.transform_batch(gs, seeds)
+    for v, row in zip(seeds, got):
+        want = [pyref.armory_key(hashlib.sha256(str(v).encode()).digest()), pyref.armory_key(bytes(24) + v.to_bytes(8, "big")) if v else None]
+        assert row == want, v
+    assert eng.transform_strings(gs, [b"armory", b""])[0] == [pyref.armory_key(hashlib.sha256(b"armory").digest())]
+    # sweep: counters, digest and planted hits against the oracle
+    lo, hi = 1000, 1400
+    planted = [(1003, 0, 0), (1111, 1, 1), (1400, 0, 2), (1000, 1, 0)]
+    addrs, h160s, kinds = [], [], []
+    for seed, sub, kind in planted:
+        d = vko.derive(vko.transform_key(os_, seed, sub))
+        addrs.append([d.p2pkh_compressed, d.p2pkh_uncompressed, d.p2wpkh][kind].decode())
+        h160s.append(bytes(d.h160_u if kind == 1 else d.h160_c))
+        kinds.append(1 if kind == 2 else 0)
+    eng.targets_set(h160s, kinds)
+    st, hits = eng.sweep(gs, lo, hi, flags=3)
+    ost, ohits = vko.sweep(os_, lo, hi, flags=3, matcher=vko.Matcher(addrs), nthreads=8)
+    eng.targets_set([], [])
+    assert (st["inputs"], st["keys"], st["matches"], st["digest"]) == (ost["inputs"], ost["keys"], 4, ost["digest"])
+    assert hits == ohits and sorted((h["seed"], h["sub_index"], h["addr_kind"]) for h in hits) == sorted(planted)

@@ -64,8 +64,8 @@ def test_transform_grammar_reference_cases(host):
     assert parse(host, "sha256_chain:foo")[1].startswith("Invalid SHA256 chain variant: 'foo'")
     assert parse(host, "sha256_chain:iterated:le")[1].startswith("Invalid SHA256 chain format")
     assert parse(host, "nothing")[1].startswith("Unknown transform: nothing. Valid: direct, sha256,")
-    assert [parse(host, n)[0][0] for n in ("double_sha256", "md5", "direct")] == [8, 9, 10]
-    assert parse(host, "armory")[0] is None and "outside the device hot path" in parse(host, "armory")[1]
+    assert [parse(host, n)[0][0] for n in ("double_sha256", "md5", "direct", "armory")] == [8, 9, 10, 11]
+    assert parse(host, "bitimage")[0] is None and "outside the device hot path" in parse(host, "bitimage")[1]
     assert parse(host, "electrum") == ((6, 0, 0, 20), "electrum")                 # src/transform/mod.rs:180-181
     assert parse(host, "electrum:change") == ((6, 1, 0, 20), "electrum:change")
     assert parse(host, "multibit") == ((7, 0, 0, 20), "multibit")                 # src/transform/mod.rs:178

@@ -279,3 +279,31 @@ def test_string_inputs(vko):
     assert vko.transform_string(vko.spec(vko.T_SHA256), b"correct horse battery staple", 0).hex() == "c4bbcb1fbec99d65bf59d85c8cb62ee2db963f0fe106f483d9afa73bd4e39a8a"
     for k in (vko.T_MILKSAD, vko.T_MT64, vko.T_LCG, vko.T_XORSHIFT):
         assert vko.slots_per_string(vko.spec(k)) == 0 and vko.transform_string(vko.spec(k), b"123", 0) is None
+
+
+def test_armory_vs_python_reference(vko):
+    """armory (src/transform/armory.rs): no vectors in the reference, so the oracle is pinned to a python-int / hashlib /
+    hmac restatement (tests/pyref.py) and its parts to hmac + python ints."""
+    import hmac
+    from tests import pyref
+    rnd = random.Random(10)
+    for _ in range(50):
+        k, m = bytes(rnd.getrandbits(8) for _ in range(rnd.choice([1, 32, 64, 65, 100]))), bytes(rnd.getrandbits(8) for _ in range(rnd.randrange(0, 200)))
+        assert vko.hmac_sha256(k, m) == hmac.new(k, m, hashlib.sha256).digest()
+    edge = [1, 2, pyref.N - 1, pyref.N - 2, 2**255, 2**128 + 1, (1 << 256) - 1 - pyref.N]
+    for _ in range(200):
+        a, b = rnd.choice(edge + [rnd.getrandbits(256) % pyref.N]), rnd.choice(edge + [rnd.getrandbits(256) % pyref.N])
+        a, b = a % pyref.N, b % pyref.N
+        want = a * b % pyref.N
+        assert vko.scalar_mul(a.to_bytes(32, "big"), b.to_bytes(32, "big")) == (want.to_bytes(32, "big") if want else None)
+    seeds = [bytes(31) + b"\x01", hashlib.sha256(b"armory").digest(), (pyref.N - 1).to_bytes(32, "big")] + [bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(12)]
+    for sd in seeds:
+        assert vko.armory_key(sd) == pyref.armory_key(sd)
+    assert vko.armory_key(bytes(32)) is None and vko.armory_key(pyref.N.to_bytes(32, "big")) is None and vko.armory_key(b"\xff" * 32) is None
+    # apply_batch (:84-101): slot 0 = SHA256(decimal string) as the seed, slot 1 = 24 zero bytes || 8 BE bytes; value 0 has no slot 1
+    sp = vko.spec(vko.T_ARMORY)
+    for v in (0, 1, 7, 2**32, 2**64 - 1):
+        want = [pyref.armory_key(hashlib.sha256(str(v).encode()).digest()), pyref.armory_key(bytes(24) + struct.pack(">Q", v)) if v else None, None]
+        assert [vko.transform_key(sp, v, i) for i in range(3)] == want
+    assert vko.transform_string(sp, b"hello", 0) == pyref.armory_key(hashlib.sha256(b"hello").digest()) and vko.transform_string(sp, b"hello", 1) is None
+    assert vko.slots_per_input(sp) == 2 and vko.slots_per_string(sp) == 1 and vko.transform_name(sp) == "armory" and vko.transform_label(sp, 5, 1) == "5"

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvuke_hip.so")
 
 VK_OK = 0
 VK_E_NO_DEVICE, VK_E_HIP, VK_E_INVALID_ARG, VK_E_UNSUPPORTED, VK_E_NOMEM = -1, -2, -3, -4, -5
-T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM, T_MULTIBIT, T_DOUBLE_SHA256, T_MD5, T_DIRECT = range(11)
+T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM, T_MULTIBIT, T_DOUBLE_SHA256, T_MD5, T_DIRECT, T_ARMORY = range(12)
 VARIANT_ALL = 0xFFFFFFFF
 F_COMPRESSED, F_UNCOMPRESSED = 1, 2
 ADDR_P2PKH_C, ADDR_P2PKH_U, ADDR_P2WPKH = 0, 1, 2

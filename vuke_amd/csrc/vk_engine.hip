@@ -85,6 +85,7 @@ extern "C" uint32_t vk_slots_per_input(const vk_transform_spec *t)
     case VK_T_MILKSAD:
     case VK_T_MD5:
     case VK_T_MT64: return 1;
+    case VK_T_ARMORY: return 2;
     case VK_T_LCG:
     case VK_T_XORSHIFT:
         if (t->variant != VK_VARIANT_ALL && t->variant > 3) return 0;
@@ -110,7 +111,8 @@ extern "C" uint32_t vk_slots_per_string(const vk_transform_spec *t)
     case VK_T_SHA256:
     case VK_T_DOUBLE_SHA256:
     case VK_T_MD5:
-    case VK_T_DIRECT: return 1;
+    case VK_T_DIRECT:
+    case VK_T_ARMORY: return 1;
     case VK_T_SHA256_CHAIN: return vk_slots_per_input(t) / 2; // the string form only (src/transform/sha256_chain.rs:60-72)
     case VK_T_ELECTRUM:
     case VK_T_MULTIBIT: return vk_slots_per_input(t);
@@ -417,6 +419,7 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     case VK_T_DOUBLE_SHA256: launch_sweep<VK_T_DOUBLE_SHA256>(p, grid, e->stream); break;
     case VK_T_MD5: launch_sweep<VK_T_MD5>(p, grid, e->stream); break;
     case VK_T_DIRECT: launch_sweep<VK_T_DIRECT>(p, grid, e->stream); break;
+    case VK_T_ARMORY: launch_sweep<VK_T_ARMORY>(p, grid, e->stream); break;
     case VK_T_RAWKEYS: launch_sweep<VK_T_RAWKEYS>(p, grid, e->stream); break;
     default: return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
     }
@@ -618,11 +621,12 @@ extern "C" int vk_derive_batch(vk_engine *e, const uint8_t *keys, size_t n, uint
 }
 
 template <u32 KIND>
-static void launch_transform(const vk_spec_dev &s, const u64 *seeds, u64 n, u32 slots, u32 *keys, unsigned char *valid, hipStream_t st)
+static void launch_transform(const vk_spec_dev &s, const u64 *seeds, u64 n, u32 slots, u32 *keys, unsigned char *valid, hipStream_t st,
+                             const vk_ec_ctx &ec = vk_ec_ctx{nullptr, nullptr, 0})
 {
     const u64 items = n * slots;
     hipLaunchKernelGGL(vk_transform_kernel<KIND>, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, st, s, seeds, n,
-                       slots, keys, valid);
+                       slots, keys, valid, ec);
 }
 
 extern "C" int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, const uint64_t *seeds, size_t n, uint8_t *keys_out,
@@ -662,6 +666,7 @@ extern "C" int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, cons
         case VK_T_DOUBLE_SHA256: launch_transform<VK_T_DOUBLE_SHA256>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
         case VK_T_MD5: launch_transform<VK_T_MD5>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
         case VK_T_DIRECT: launch_transform<VK_T_DIRECT>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream); break;
+        case VK_T_ARMORY: launch_transform<VK_T_ARMORY>(spec, d_seeds, n, slots, d_keys, d_valid, e->stream, vk_ec_ctx{e->table, e->d_wins, e->nwin}); break;
         default: cleanup(); return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
         }
         c = hipGetLastError();
@@ -730,7 +735,7 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
     if (c == hipSuccess) {
         if (!kdf)
             hipLaunchKernelGGL(vk_strings_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, to_dev(t), d_data, d_offs,
-                               (u64)n, slots, d_keys, d_valid);
+                               (u64)n, slots, d_keys, d_valid, vk_ec_ctx{e->table, e->d_wins, e->nwin});
         else if (t->kind == VK_T_MULTIBIT)
             hipLaunchKernelGGL(vk_multibit_kernel, dim3((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_data, d_offs, (u64)n,
                                t->chain_depth, e->d_wordlist, e->table, e->d_wins, e->nwin, d_keys, d_valid);

@@ -18,6 +18,7 @@
 #pragma once
 #include "vk_ec.cuh"
 #include "vk_transforms.cuh"
+#include "vk_armory.cuh"
 
 #define VK_F_COMPRESSED 1u
 #define VK_F_UNCOMPRESSED 2u
@@ -120,6 +121,10 @@ VK_DEV bool item_key(u32 kw[8], const vk_sweep_params &p, u64 off, u32 sub)
         kw[0] = bswap32(a.x); kw[1] = bswap32(a.y); kw[2] = bswap32(a.z); kw[3] = bswap32(a.w);
         kw[4] = bswap32(b.x); kw[5] = bswap32(b.y); kw[6] = bswap32(b.z); kw[7] = bswap32(b.w);
         return true;
+    }
+    if (KIND == VK_T_ARMORY) {
+        const vk_ec_ctx ec = {p.table, p.wins, p.nwin};
+        return transform_armory(kw, p.lo + off, sub, ec);
     }
     return transform_key<KIND>(kw, p.spec, p.lo + off, sub);
 }
@@ -416,14 +421,14 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_table_combine_kernel(uint4 *win, 
 // ---------------------------------------------------------------- Transform::apply_batch
 template <u32 KIND>
 __global__ void __launch_bounds__(VK_BLOCK) vk_transform_kernel(vk_spec_dev spec, const u64 *seeds, u64 n, u32 slots,
-                                                                u32 *keys_out, unsigned char *valid)
+                                                                u32 *keys_out, unsigned char *valid, vk_ec_ctx ec)
 {
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
     if (idx >= n * slots) return;
     const u64 i = idx / slots;
     const u32 sub = (u32)(idx - i * slots);
     u32 kw[8];
-    bool ok = transform_key<KIND>(kw, spec, seeds[i], sub);
+    bool ok = KIND == VK_T_ARMORY ? transform_armory(kw, seeds[i], sub, ec) : transform_key<KIND>(kw, spec, seeds[i], sub);
 #pragma unroll
     for (int j = 0; j < 8; j++) keys_out[idx * 8 + j] = ok ? bswap32(kw[j]) : 0u;
     valid[idx] = ok ? 1 : 0;
@@ -431,14 +436,16 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_transform_kernel(vk_spec_dev spec
 
 // Transform::apply_batch for Input::from_string inputs of the hash transforms: one lane per (string, slot)
 __global__ void __launch_bounds__(VK_BLOCK) vk_strings_kernel(vk_spec_dev spec, const unsigned char *data, const u32 *offsets, u64 n, u32 slots,
-                                                              u32 *keys_out, unsigned char *valid)
+                                                              u32 *keys_out, unsigned char *valid, vk_ec_ctx ec)
 {
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
     if (idx >= n * slots) return;
     const u64 i = idx / slots;
     const u32 sub = (u32)(idx - i * slots);
     u32 kw[8];
-    bool ok = transform_string(kw, spec, data + offsets[i], offsets[i + 1] - offsets[i], sub);
+    const unsigned char *str = data + offsets[i];
+    const u32 len = offsets[i + 1] - offsets[i];
+    bool ok = spec.kind == VK_T_ARMORY ? transform_armory_string(kw, str, len, sub, ec) : transform_string(kw, spec, str, len, sub);
 #pragma unroll
     for (int j = 0; j < 8; j++) keys_out[idx * 8 + j] = ok ? bswap32(kw[j]) : 0u;
     valid[idx] = ok ? 1 : 0;

@@ -357,6 +357,7 @@ VK_DEV u32 spec_slots(const vk_spec_dev &s)
     case VK_T_MILKSAD:
     case VK_T_MD5:
     case VK_T_MT64: return 1;
+    case 11u /* VK_T_ARMORY */: return 2;
     case VK_T_LCG:
     case VK_T_XORSHIFT: return s.variant == VK_VARIANT_ALL ? 4u : 1u;
     case VK_T_SHA256_CHAIN: return 2u * (s.variant == VK_VARIANT_ALL ? 4u : 1u) * s.chain_depth;
@@ -387,7 +388,8 @@ VK_DEV u32 string_slots(const vk_spec_dev &s)
     case VK_T_SHA256:
     case VK_T_DOUBLE_SHA256:
     case VK_T_MD5:
-    case VK_T_DIRECT: return 1;
+    case VK_T_DIRECT:
+    case 11u /* VK_T_ARMORY */: return 1;
     case VK_T_SHA256_CHAIN: return (s.variant == VK_VARIANT_ALL ? 4u : 1u) * s.chain_depth;
     default: return 0;
     }

@@ -21,7 +21,7 @@ static int usage(const char *msg)
     fprintf(stderr, "Usage: vuke-hip <generate|scan> [OPTIONS] <SOURCE>\n"
                     "       vuke-hip single <PASSPHRASE> --transform <T>\n"
                     "       vuke-hip analyze <KEY> [--mask BITS] [--cascade b:t,b:t,...] [--analyzer milksad|lcg[:variant][:endian]|mt64|xorshift[:variant]|sha256_chain[:variant]]...\n"
-                    "  --transform <T>...   sha256 | double_sha256 | md5 | direct | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] |\n"
+                    "  --transform <T>...   sha256 | double_sha256 | md5 | direct | armory | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] |\n"
                     "                       sha256_chain[:variant] | electrum[:change] | multibit\n"
                     "  sources: range --start A --end B | timestamps --start YYYY-MM-DD --end YYYY-MM-DD [--microseconds] |\n"
                     "           wordlist --file F | stdin   (passphrase sources feed the string form of each transform)\n"

@@ -79,8 +79,8 @@ Transform TransformType::from_str(const std::string &raw)
     if (s == "double_sha256") { sp.kind = VK_T_DOUBLE_SHA256; return Transform(sp); }
     if (s == "md5") { sp.kind = VK_T_MD5; return Transform(sp); }
     if (s == "direct") { sp.kind = VK_T_DIRECT; return Transform(sp); }
-    for (const char *n : {"armory", "bitimage"})
-        if (s == n) return unsupported(n);
+    if (s == "armory") { sp.kind = VK_T_ARMORY; return Transform(sp); }
+    if (s == "bitimage") return unsupported("bitimage");
     if (s == "lcg" || s.rfind("lcg:", 0) == 0) { // LcgConfig::parse
         auto parts = split_colon(s);
         sp.kind = VK_T_LCG;
@@ -151,6 +151,7 @@ const char *Transform::name() const
     case VK_T_DOUBLE_SHA256: return "double_sha256";
     case VK_T_MD5: return "md5";
     case VK_T_DIRECT: return "direct";
+    case VK_T_ARMORY: return "armory";
     case VK_T_MILKSAD: return "milksad";
     case VK_T_MT64: return "mt64";
     case VK_T_LCG: return "lcg";

@@ -111,7 +111,7 @@ private:
 
 struct TransformType {
     // TransformType::from_str (src/transform/mod.rs:170-215): throws std::invalid_argument with the
-    // reference's message for unknown names; transforms outside the device path (armory, bitimage) are
+    // reference's message for unknown names; the one transform outside the device path (bitimage) is
     // recognised and rejected as unsupported.
     static Transform from_str(const std::string &s);
 };
