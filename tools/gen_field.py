@@ -21,8 +21,10 @@ def col_products_sqr(k):
     return [(i, k - i) for i in range(max(0, k - 7), min(k, 7) + 1) if i < k - i]
 
 
-def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same):
-    """one asm statement: even column ke and odd column ke+1."""
+def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, zero_o=False):
+    """one asm statement: even column ke and odd column ke+1.  A column whose start value is zero takes the literal 0
+    as the addend of its first multiply (no register to clear); the first carry of a column *sets* its counter
+    (0 + 0 + carry), so the counters need no clearing either."""
     ko = ke + 1
     # operand table
     ops_out = []   # (constraint, expr)
@@ -35,13 +37,13 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same):
 
     have_e, have_o = bool(prods_e), bool(prods_o)
     if have_e:
-        out("+v", f"acc[{ke}]")
+        out("=&v" if zero_e else "+v", f"acc[{ke}]")
         if len(prods_e) > 1:
-            out("+v", f"cy[{ke}]")
+            out("=&v", f"cy[{ke}]")
     if have_o:
-        out("+v", f"acc[{ko}]")
+        out("=&v" if zero_o else "+v", f"acc[{ko}]")
         if len(prods_o) > 1:
-            out("+v", f"cy[{ko}]")
+            out("=&v", f"cy[{ko}]")
             out("=&s", "sc")
     used = []
     for (i, j) in prods_e + prods_o:
@@ -61,17 +63,19 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same):
     for step in range(max(ne, no)):
         if step < ne:
             i, j = prods_e[step]
-            body.append(f"v_mad_u64_u32 {r(f'acc[{ke}]')}, vcc, {r((a_name, i))}, {r((a_name if same else b_name, j))}, {r(f'acc[{ke}]')}")
+            add = "0" if (zero_e and step == 0) else r(f'acc[{ke}]')
+            body.append(f"v_mad_u64_u32 {r(f'acc[{ke}]')}, vcc, {r((a_name, i))}, {r((a_name if same else b_name, j))}, {add}")
         if step < no:
             i, j = prods_o[step]
             sd = r("sc") if no > 1 else "vcc"
-            if no > 1 or step >= ne or True:
-                pass
-            body.append(f"v_mad_u64_u32 {r(f'acc[{ko}]')}, {sd}, {r((a_name, i))}, {r((a_name if same else b_name, j))}, {r(f'acc[{ko}]')}")
+            add = "0" if (zero_o and step == 0) else r(f'acc[{ko}]')
+            body.append(f"v_mad_u64_u32 {r(f'acc[{ko}]')}, {sd}, {r((a_name, i))}, {r((a_name if same else b_name, j))}, {add}")
         if step < ne and step > 0:
-            body.append(f"v_addc_co_u32 {r(f'cy[{ke}]')}, vcc, 0, {r(f'cy[{ke}]')}, vcc")
+            prev = "0" if step == 1 else r(f'cy[{ke}]')
+            body.append(f"v_addc_co_u32 {r(f'cy[{ke}]')}, vcc, 0, {prev}, vcc")
         if step < no and step > 0:
-            body.append(f"v_addc_co_u32 {r(f'cy[{ko}]')}, {r('sc')}, 0, {r(f'cy[{ko}]')}, {r('sc')}")
+            prev = "0" if step == 1 else r(f'cy[{ko}]')
+            body.append(f"v_addc_co_u32 {r(f'cy[{ko}]')}, {r('sc')}, 0, {prev}, {r('sc')}")
     # vcc hazard: if the odd column has a single product it would write vcc between the even
     # column's multiply and its carry add -> route it through a dead SGPR pair instead
     if no == 1 and ne > 1:
@@ -92,15 +96,18 @@ def gen_cols(name, prods_fn, same):
     L.append(f"// acc[k] = pair (limb k, limb k+1) of column k; returns limb 15 of the odd number\n")
     L.append(f"VK_DEV u32 {name}(u64 acc[15], {sig})\n{{\n")
     L.append("    u32 cy[15];\n    vk_carry sc;\n    (void)sc;\n")
-    L.append("#pragma unroll\n    for (int k = 0; k < 15; k++) cy[k] = 0;\n")
+    has_cy = [len(prods_fn(k)) > 1 for k in range(15)]   # columns with one product cannot overflow
     for ke in range(0, 15, 2):
         pe, po = prods_fn(ke), (prods_fn(ke + 1) if ke + 1 < 15 else [])
+        zero = {}
         for k in (ke, ke + 1):
             if k < 15:
-                L.append(f"    acc[{k}] = {'(u64)cy[%d]' % (k - 2) if k >= 2 else '0ull'};\n")
+                zero[k] = not (k >= 2 and has_cy[k - 2])
+                if not (zero[k] and prods_fn(k)):
+                    L.append(f"    acc[{k}] = {'0ull' if zero[k] else '(u64)cy[%d]' % (k - 2)};\n")
         if pe or po:
-            emit_pair(L, ke, pe, po, "a", "b", same)
-    L.append("    return cy[13];\n}\n\n")
+            emit_pair(L, ke, pe, po, "a", "b", same, zero_e=zero.get(ke, False), zero_o=zero.get(ke + 1, False))
+    L.append(f"    return {'cy[13]' if has_cy[13] else '0u'};\n}}\n\n")
     return "".join(L)
 
 

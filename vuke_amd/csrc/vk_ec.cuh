@@ -40,6 +40,28 @@ VK_DEV void jac_madd(jac &r, const jac &p, const fe &qx, const fe &qy)
     r.x = t;
 }
 
+// r = p + q for two affine points with different x: the general formula with z1 = 1.   4M + 2S
+// (the second window of every k*G: the accumulator is still the first table entry)
+VK_DEV void jac_aadd(jac &r, const fe &px, const fe &py, const fe &qx, const fe &qy)
+{
+    fe h, rr, h2, h3, v, t;
+    fe_sub(h, qx, px);
+    fe_sub(rr, qy, py);
+    fe_sqr(h2, h);
+    fe_mul(h3, h2, h);
+    fe_mul(v, px, h2);
+    fe_sqr(t, rr);
+    fe_sub(t, t, h3);
+    fe_sub(t, t, v);
+    fe_sub(t, t, v); // x3
+    fe_mul(h3, h3, py);
+    fe_sub(v, v, t);
+    fe_mul(v, v, rr);
+    fe_sub(r.y, v, h3);
+    r.x = t;
+    r.z = h;
+}
+
 // r = 2p (a = 0), p.y != 0.   2M + 5S  (used only by the table builder)
 VK_DEV void jac_double(jac &r, const jac &p)
 {
@@ -133,7 +155,7 @@ VK_DEV void fe_cond_negate(fe &y, bool neg)
 // the addend is t*G with |t| >= 2^off_i, so s != +-t, and |s + t| < n.
 VK_DEV void ecmult_table(jac &acc, const u32 k[8], const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin)
 {
-    bool inf = true;
+    bool inf = true, zone = false; // zone: the accumulator is a table entry (z = 1)
     fe_set_zero(acc.x);
     fe_set_zero(acc.y);
     fe_set_one(acc.z);
@@ -158,6 +180,10 @@ VK_DEV void ecmult_table(jac &acc, const u32 k[8], const uint4 *__restrict__ tab
                 acc.x = cx;
                 acc.y = cy;
                 inf = false;
+                zone = true;
+            } else if (zone) {
+                jac_aadd(acc, acc.x, acc.y, cx, cy);
+                zone = false;
             } else {
                 jac_madd(acc, acc, cx, cy);
             }
