@@ -71,8 +71,8 @@ def main():
     # library default (11.8 GB, 10 additions).
     ap.add_argument("--layout", type=int, default=1)
     ap.add_argument("--window-bits", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--blocks-per-cu", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--blocks-per-cu", type=int, default=2)
     args = ap.parse_args()
 
     import torch

@@ -33,7 +33,7 @@ struct vk_engine {
     u64 *d_wordlist = nullptr;     // BIP-39 list, 2048 x 8 bytes (vk_bip39_wordlist_set)
     vk_win_desc *d_wins = nullptr; // device copy of wins (kernels that take the layout by pointer)
     double table_build_seconds = 0.0;
-    u32 batch = 32;
+    u32 batch = 128;
     u32 blocks_per_cu = 0;
     uint4 *table = nullptr;
     uint4 *tgt = nullptr;
@@ -228,6 +228,10 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     }
     HIPCHK(e, hipMalloc(&e->d_wins, sizeof e->wins));
     HIPCHK(e, hipMemcpy(e->d_wins, e->wins, sizeof e->wins, hipMemcpyHostToDevice));
+    // batch-inversion workspace for the full grid, once (a multi-GB hipMalloc inside a sweep call costs seconds);
+    // run_range only grows it for specs whose slots per input exceed the batch
+    e->work_bytes = (size_t)e->cu_count * e->blocks_per_cu * VK_BLOCK * e->batch * 8 * sizeof(uint4);
+    HIPCHK(e, hipMalloc(&e->work, e->work_bytes));
     // the k*G table: affine points (64 B each), built on the device window by window in two phases
     HIPCHK(e, hipMalloc(&e->table, e->table_entries * 64));
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
@@ -359,11 +363,19 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
                      const launch_io &io, vk_sweep_stats *st)
 {
     HIPCHK(e, hipSetDevice(e->device));
+    // Tile = VK_BLOCK lanes x R inputs per lane (R * slots keys share one field inversion).  R is the largest batch
+    // that fits e->batch, then shrunk so that every workgroup of the grid gets the same number of full tiles
+    // (a 2^28-input block over 768 workgroups would otherwise end with a third of them idle for one tile).
+    const u64 max_grid = (u64)e->cu_count * e->blocks_per_cu;
     u32 R = std::max(1u, e->batch / slots);
+    {
+        const u64 per_lane = span / (max_grid * VK_BLOCK) + 1; // inputs per lane if the grid shared them evenly
+        const u64 rounds = (per_lane + R - 1) / R;             // tiles per workgroup
+        R = (u32)std::max<u64>(1, (per_lane + rounds - 1) / rounds);
+    }
     const u32 B = R * slots;
     const u64 tile_inputs = (u64)VK_BLOCK * R;
     const u64 ntiles = span / tile_inputs + 1;
-    const u64 max_grid = (u64)e->cu_count * e->blocks_per_cu;
     const u32 grid = (u32)std::min<u64>(ntiles, max_grid);
     const size_t need = (size_t)grid * VK_BLOCK * B * 8 * sizeof(uint4);
     if (need > e->work_bytes) {

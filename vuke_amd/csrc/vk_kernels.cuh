@@ -53,7 +53,7 @@ struct vk_sweep_params {
     const uint4 *table;
     const uint4 *tgt;  // slots of 2 x uint4: {h0,h1,h2,h3}, {h4, kindbits, 0, 0}
     vk_hit_dev *hits;
-    u64 *stats;        // [0] keys [1] matches [2] hit cursor [3..6] digest
+    u64 *stats;        // [0] keys [1] matches [2] hit cursor [3..6] digest [7] tile counter
     uint4 *work;       // batch-inversion workspace
     const u32 *in_keys;   // VK_T_RAWKEYS: n x 8 words (raw bytes)
     u32 *out_priv;     // generate mode: n_items x 8 words (raw bytes)
@@ -133,15 +133,23 @@ template <u32 KIND>
 __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(const vk_sweep_params p)
 {
     const u32 tid = threadIdx.x;
-    const u64 gtid = (u64)blockIdx.x * VK_BLOCK + tid;
-    const u64 nth = (u64)gridDim.x * VK_BLOCK;
     const u32 B = p.R * p.slots;
     u64 n_keys = 0, n_match = 0;
     u64 dg[4] = {0, 0, 0, 0};
-    uint4 *wk = p.work + gtid; // item b, quad q lives at wk[(b*8 + q) * nth]
+    // workspace of this workgroup: item b, quad q, lane t at wk[(b*8 + q) * VK_BLOCK] -- one contiguous
+    // B * 32 KB region per workgroup (a few TLB entries), every access a fully coalesced 16 B per lane
+    const u64 nth = VK_BLOCK;
+    uint4 *wk = p.work + (u64)blockIdx.x * ((u64)B * 8 * VK_BLOCK) + tid;
+    __shared__ u64 s_tile;
 
 #pragma unroll 1
-    for (u64 tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    for (;;) {
+        // tiles are handed out by an atomic counter: workgroups that run ahead (clock, XCD, table locality) take more
+        if (tid == 0) s_tile = atomicAdd((unsigned long long *)(p.stats + 7), 1ull);
+        __syncthreads();
+        const u64 tile = s_tile;
+        __syncthreads();
+        if (tile >= p.ntiles) break;
         const u64 tile_off = tile * ((u64)VK_BLOCK * p.R);
         // ---------------------------------------------------------------- pass 1
         fe c;
