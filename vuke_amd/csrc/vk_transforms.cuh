@@ -69,7 +69,16 @@ VK_DEV void msg_finish(u32 w[16], u32 len)
 }
 
 // ---- MT19937 (Milksad) ----------------------------------------------------------------
-VK_DEV u32 mt_init_step(u32 prev, u32 i) { return 1812433253u * (prev ^ (prev >> 30)) + i; }
+// one init_genrand step: 1812433253 * (prev ^ (prev >> 30)) + i as a single v_mad_u64_u32 (multiplier in a VGPR,
+// the index as a 64-bit scalar operand); the low half of the result is the new state word
+VK_DEV u32 mt_init_step(u32 prev, u32 i)
+{
+    const u32 x = prev ^ (prev >> 30);
+    u64 r;
+    const u32 mult = 1812433253u;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(x), "v"(mult), "s"((u64)i) : "vcc");
+    return (u32)r;
+}
 
 // Only state words 0..8 and 397..404 of init_genrand(seed) feed the first 8 outputs.
 VK_DEV bool transform_milksad(u32 kw[8], u64 seed)
