@@ -533,3 +533,40 @@ def test_armory_chain(eng, vko):
     eng.targets_set([], [])
     assert (st["inputs"], st["keys"], st["matches"], st["digest"]) == (ost["inputs"], ost["keys"], 4, ost["digest"])
     assert hits == ohits and sorted((h["seed"], h["sub_index"], h["addr_kind"]) for h in hits) == sorted(planted)
+
+
+def test_engine_is_safe_to_share_between_threads(vko):
+    """SURVEY 8(b) threading: one engine is internally serialised (Send + Sync-compatible); two engines on the same
+    GPU run concurrently.  ctypes drops the GIL during the calls, so these are real concurrent entries."""
+    import threading
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+    shared = vuke_amd.Engine(0, window_bits=16)
+    other = vuke_amd.Engine(0, window_bits=12)
+    want = {}
+    for name, kind, lo in (("a", ffi.T_MILKSAD, 1000), ("b", ffi.T_SHA256, 77000), ("c", ffi.T_LCG, 2**31 - 3000), ("d", ffi.T_XORSHIFT, 5)):
+        ost, _ = vko.sweep(vko.spec(kind), lo, lo + 4999, flags=3, nthreads=4)
+        want[name] = (kind, lo, ost["keys"], ost["digest"])
+    errors = []
+
+    def worker(eng, name, reps):
+        kind, lo, keys, digest = want[name]
+        try:
+            for _ in range(reps):
+                st, _ = eng.sweep(ffi.spec(kind), lo, lo + 4999, flags=3)
+                if (st["keys"], st["digest"]) != (keys, digest):
+                    errors.append((name, st))
+                rows = eng.transform_batch(ffi.spec(kind), [lo, lo + 1])
+                if rows[0][0] != vko.transform_key(vko.spec(kind), lo, 0):
+                    errors.append((name, "transform"))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((name, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(shared, n, 6)) for n in ("a", "b", "c")] + [threading.Thread(target=worker, args=(other, "d", 6))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    shared.close()
+    other.close()
+    assert errors == []
