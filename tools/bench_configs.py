@@ -8,7 +8,7 @@ import vuke_amd
 from vuke_amd import _ffi as ffi
 
 layout = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-e = vuke_amd.Engine(0, layout=layout, batch=128, blocks_per_cu=3)
+e = vuke_amd.Engine(0, layout=layout, batch=256, blocks_per_cu=2)
 info = e.info()
 
 # ---- config 3: 1 000 000 targets = 999 000 decoys + 1 000 planted (seed 7919*j, sub j%3, kind cycling)
