@@ -11,10 +11,11 @@ typedef uint64_t u64;
 #define CHAINS 8
 #define UNROLL 8
 
-enum { ADD, XOR, MULLO, MULHI, MAD64, ALIGNBIT, ADD3, BFI, MAD24, MULHI24, FMA64, ADDC, LSHLADD, XAD, CNDMASK, PERM, NOPS };
+enum { ADD, XOR, MULLO, MULHI, MAD64, ALIGNBIT, ADD3, BFI, MAD24, MULHI24, FMA64, ADDC, LSHLADD, XAD, CNDMASK, PERM, CNDMASK_S, ADDC_S, MOV, MOV64, BITOP3, CMP, NOPS };
 static const char *NAMES[NOPS] = {"v_add_u32", "v_xor_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_alignbit_b32",
                                   "v_add3_u32", "v_bfi_b32", "v_mad_u32_u24", "v_mul_hi_u32_u24", "v_fma_f64", "v_addc_co_u32",
-                                  "v_lshl_add_u32", "v_xad_u32", "v_cndmask_b32", "v_perm_b32"};
+                                  "v_lshl_add_u32", "v_xad_u32", "v_cndmask_b32", "v_perm_b32", "v_cndmask_b32 (sgpr mask)", "v_addc_co_u32 (sgpr carry)",
+                                  "v_mov_b32", "v_mov_b64", "v_bitop3_b32", "v_cmp_lt_u32"};
 
 template <int OP>
 __global__ void __launch_bounds__(256) k(u64 *out, u32 seed, int iters)
@@ -30,6 +31,8 @@ __global__ void __launch_bounds__(256) k(u64 *out, u32 seed, int iters)
         c[j] = ((u64)a[j] << 32) | b[j];
         d[j] = 1.0 + 1e-9 * (double)(a[j] & 0xffff);
     }
+    u64 smask = 0x5555555555555555ull ^ seed;
+    asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a[0]), "v"(b[0]) : "vcc");
     u64 c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -52,6 +55,12 @@ __global__ void __launch_bounds__(256) k(u64 *out, u32 seed, int iters)
                 if (OP == XAD) asm volatile("v_xad_u32 %0, %0, %1, %1" : "+v"(a[j]) : "v"(b[j]));
                 if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[j]) : "v"(b[j]) : "vcc");
                 if (OP == PERM) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == CNDMASK_S) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a[j]) : "v"(b[j]), "s"(smask));
+                if (OP == ADDC_S) asm volatile("v_addc_co_u32 %0, %1, %0, %2, %1" : "+v"(a[j]), "+s"(smask) : "v"(b[j]));
+                if (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(a[j]) : "v"(b[j]));
+                if (OP == MOV64) asm volatile("v_mov_b64 %0, %1" : "=v"(c[j]) : "v"(c[(j + 1) % CHAINS]));
+                if (OP == BITOP3) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a[j]) : "v"(b[j]));
+                if (OP == CMP) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a[j]), "v"(b[j]) : "vcc");
             }
         }
     }
@@ -124,5 +133,11 @@ int main()
     sweep_occ<MAD24>(cus, out);
     sweep_occ<MULHI24>(cus, out);
     sweep_occ<FMA64>(cus, out);
+    sweep_occ<CNDMASK_S>(cus, out);
+    sweep_occ<ADDC_S>(cus, out);
+    sweep_occ<MOV>(cus, out);
+    sweep_occ<MOV64>(cus, out);
+    sweep_occ<BITOP3>(cus, out);
+    sweep_occ<CMP>(cus, out);
     return 0;
 }

@@ -8,6 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvuke_hip.so")
+LIB_PATH = os.environ.get("VUKE_HIP_LIB", LIB_PATH)  # A/B runs of two builds of the same library (tools/), nothing else
 
 VK_OK = 0
 VK_E_NO_DEVICE, VK_E_HIP, VK_E_INVALID_ARG, VK_E_UNSUPPORTED, VK_E_NOMEM = -1, -2, -3, -4, -5

@@ -114,16 +114,22 @@ struct vk_win_desc {
 
 VK_DEV u32 scalar_digit(const u32 k[8], u32 bitpos, u32 W)
 {
-    // W <= 31 bits starting at bitpos (may straddle two limbs)
-    u32 limb = bitpos >> 5, sh = bitpos & 31;
-    u32 lo = 0, hi = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        lo = (limb == (u32)i) ? k[i] : lo;
-        hi = (limb + 1 == (u32)i) ? k[i] : hi;
+    // W <= 31 bits starting at bitpos (may straddle two limbs).  The window geometry is the same for every lane, so the
+    // limb pair is picked by a scalar branch (two register copies) instead of a chain of sixteen per-lane selects.
+    const u32 limb = __builtin_amdgcn_readfirstlane(bitpos >> 5), sh = __builtin_amdgcn_readfirstlane(bitpos & 31);
+    u32 lo, hi;
+    switch (limb) {
+    case 0: lo = k[0]; hi = k[1]; break;
+    case 1: lo = k[1]; hi = k[2]; break;
+    case 2: lo = k[2]; hi = k[3]; break;
+    case 3: lo = k[3]; hi = k[4]; break;
+    case 4: lo = k[4]; hi = k[5]; break;
+    case 5: lo = k[5]; hi = k[6]; break;
+    case 6: lo = k[6]; hi = k[7]; break;
+    case 7: lo = k[7]; hi = 0; break;
+    default: lo = 0; hi = 0; break;
     }
-    u64 both = ((u64)hi << 32) | lo;
-    return (u32)(both >> sh) & ((1u << W) - 1u);
+    return __builtin_amdgcn_alignbit(hi, lo, sh) & ((1u << W) - 1u);
 }
 
 // digit of window wd (magnitude), updating the running carry; neg = take the point's negative
