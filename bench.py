@@ -172,8 +172,9 @@ def main():
                 extra = {k: pj[k] for k in ("valu_insts_per_key", "cycles_per_valu_inst_per_simd", "effective_clock_ghz",
                                             "hbm_gbps_raw", "source") if k in pj}
                 extra["note"] = ("frac > 1: the shipped algorithm (9 signed windows in a 120 GB HBM table = 8 point additions per key, v_mad_u64_u32 field arithmetic) executes "
-                                 "valu_insts_per_key wave-instructions per key, not the canonical 218359 ops; the issue-limit "
-                                 "check is cycles_per_valu_inst_per_simd vs the ~4.2 cycles a wide integer op holds a SIMD")
+                                 "valu_insts_per_key wave-instructions per key, not the canonical 218359 ops; executed_frac = "
+                                 "instructions actually issued (rocprofv3 SQ_INSTS_VALU x this run's key rate) / the same 39.3 Tops/s peak; "
+                                 "the issue-limit check is cycles_per_valu_inst_per_simd vs the ~4.2 cycles a wide integer op holds a SIMD")
             except Exception:
                 pass
         out = {
@@ -215,6 +216,9 @@ def main():
                 "kernel_ms_per_launch": 1e3 * per_launch_s,
                 "keys_per_launch": per_launch_keys,
                 **extra,
+                **({"executed_tops": extra["valu_insts_per_key"] * per_launch_keys / per_launch_s / 1e12,
+                    "executed_frac": extra["valu_insts_per_key"] * per_launch_keys / per_launch_s / PEAK_INT32}
+                   if "valu_insts_per_key" in extra else {}),
             },
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
