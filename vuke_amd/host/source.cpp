@@ -6,6 +6,7 @@
 #include "vuke_host.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -71,44 +72,166 @@ static void emit_keys(vk_engine *engine, const Transform &t, const std::vector<s
     }
 }
 
+// One pass over a passphrase file (or stdin): lines are split and trimmed straight into the (data, offsets) form the
+// C ABI takes -- no std::string per line; labels are only built for the keys that are printed.
+namespace {
+struct LineBatch {
+    std::vector<uint8_t> data;
+    std::vector<uint32_t> offs{0};
+    size_t n() const { return offs.size() - 1; }
+    std::string str(size_t i) const { return std::string(data.begin() + offs[i], data.begin() + offs[i + 1]); }
+    uint32_t max_len() const
+    {
+        uint32_t m = 0;
+        for (size_t i = 0; i + 1 < offs.size(); i++) m = std::max(m, offs[i + 1] - offs[i]);
+        return m;
+    }
+    void clear()
+    {
+        data.clear();
+        offs.assign(1, 0);
+    }
+};
+
+class LineReader { // src/source/wordlist.rs:24-30, src/source/stdin.rs:45-50: trim, skip empty lines
+public:
+    explicit LineReader(FILE *fp) : fp_(fp), buf_(8u << 20) {}
+    // appends lines to `b` until it holds max_lines or max_bytes; false at end of input
+    bool fill(LineBatch &b, size_t max_lines, size_t max_bytes)
+    {
+        while (b.n() < max_lines && b.data.size() < max_bytes) {
+            if (pos_ == len_) {
+                len_ = fread(buf_.data(), 1, buf_.size(), fp_);
+                pos_ = 0;
+                if (len_ == 0) {
+                    if (!line_.empty()) push(b);
+                    return false;
+                }
+            }
+            const char *p = buf_.data() + pos_, *e = buf_.data() + len_;
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+            if (!nl) {
+                line_.append(p, e);
+                pos_ = len_;
+                continue;
+            }
+            if (line_.empty()) {
+                push(b, p, nl);
+            } else {
+                line_.append(p, nl);
+                push(b);
+            }
+            pos_ = (size_t)(nl - buf_.data()) + 1;
+        }
+        return true;
+    }
+
+private:
+    static bool ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; }
+    void push(LineBatch &b, const char *a, const char *e)
+    {
+        while (a < e && ws((unsigned char)*a)) a++;
+        while (e > a && ws((unsigned char)e[-1])) e--;
+        if (a == e) return;
+        b.data.insert(b.data.end(), a, e);
+        b.offs.push_back((uint32_t)b.data.size());
+    }
+    void push(LineBatch &b)
+    {
+        push(b, line_.data(), line_.data() + line_.size());
+        line_.clear();
+    }
+    FILE *fp_;
+    std::vector<char> buf_;
+    size_t pos_ = 0, len_ = 0;
+    std::string line_; // a line that straddles two reads
+};
+} // namespace
+
 ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output)
 {
-    std::ifstream file;
-    if (path != "-") {
-        file.open(path);
-        if (!file) throw std::runtime_error("cannot open wordlist: " + path);
-    }
-    std::istream &f = path == "-" ? std::cin : file;
+    FILE *fp = path == "-" ? stdin : fopen(path.c_str(), "rb");
+    if (!fp) throw std::runtime_error("cannot open wordlist: " + path);
+    struct Closer { FILE *f; bool own; ~Closer() { if (own) fclose(f); } } closer{fp, path != "-"};
     ProcessStats st;
     if (matcher) {
         std::vector<uint8_t> h160, kind;
         matcher->device_targets(h160, kind);
         check_rc(engine_, vk_targets_set(engine_, h160.data(), kind.data(), kind.size()));
     }
-    std::vector<std::string> lines;
-    size_t bytes = 0;
-    auto flush = [&]() {
+    const uint32_t flags = VK_F_COMPRESSED | VK_F_UNCOMPRESSED;
+    LineReader reader(fp);
+    LineBatch b;
+    std::vector<uint8_t> keys, valid, flat;
+    std::vector<uint32_t> slot_of;
+    KeyDeriver deriver(engine_);
+    bool more = true;
+    while (more) {
+        b.clear();
+        more = reader.fill(b, 1u << 20, 256u << 20); // a million passphrases per device call
+        const size_t n = b.n();
+        if (n == 0) continue;
+        st.inputs_processed += n;
         for (const Transform &t : transforms) {
-            std::vector<std::pair<std::string, Key>> batch;
-            t.apply_batch(engine_, lines, batch); // nothing for transforms that need a numeric seed
-            emit_keys(engine_, t, batch, matcher, output, st);
+            const uint32_t k = t.string_slots();
+            if (k == 0) continue; // a transform that needs Input::u64_val pushes nothing for a passphrase
+            if (t.takes_strings() && b.max_len() > (t.spec().kind == VK_T_MULTIBIT ? 256u : 64u))
+                throw std::invalid_argument("input string too long for the device path (electrum 64, multibit 256 bytes)");
+            keys.resize(n * k * 32);
+            valid.resize(n * k);
+            check_rc(engine_, vk_transform_strings(engine_, &t.spec(), b.data.data(), b.offs.data(), n, keys.data(), valid.data()));
+            // keys the transform emitted, in emit order, with the slot each came from
+            flat.clear();
+            slot_of.clear();
+            for (size_t s = 0; s < n * k; s++)
+                if (valid[s]) {
+                    flat.insert(flat.end(), keys.begin() + 32 * s, keys.begin() + 32 * s + 32);
+                    slot_of.push_back((uint32_t)s);
+                }
+            const size_t m = slot_of.size();
+            st.keys_generated += m;
+            if (m == 0) continue;
+            auto label_of = [&](size_t j) { return t.label(b.str(slot_of[j] / k), slot_of[j] % k); };
+            if (matcher) {
+                std::vector<vk_hit> hits(4096);
+                vk_sweep_stats ss;
+                for (;;) {
+                    check_rc(engine_, vk_scan_keys(engine_, flat.data(), m, flags, hits.data(), hits.size(), &ss));
+                    if (!ss.hits_dropped) break;
+                    hits.resize(hits.size() + (size_t)ss.hits_dropped + 1024);
+                }
+                hits.resize((size_t)ss.matches);
+                std::sort(hits.begin(), hits.end(), [](const vk_hit &x, const vk_hit &y) { return x.seed < y.seed; });
+                st.matches_found += ss.matches;
+                std::vector<Key> hk(hits.size());
+                for (size_t i = 0; i < hits.size(); i++) memcpy(hk[i].data(), &flat[32 * (size_t)hits[i].seed], 32);
+                std::vector<DerivedKey> derived = deriver.derive(hk);
+                for (size_t i = 0; i < hits.size(); i++) {
+                    MatchInfo mi;
+                    mi.address_type = hits[i].addr_kind == VK_ADDR_P2PKH_C   ? AddressType::P2pkhCompressed
+                                      : hits[i].addr_kind == VK_ADDR_P2PKH_U ? AddressType::P2pkhUncompressed
+                                                                             : AddressType::P2wpkh;
+                    mi.address = *derived[i].addresses()[hits[i].addr_kind];
+                    output.hit(label_of((size_t)hits[i].seed), t.name(), derived[i], mi);
+                }
+            } else {
+                std::vector<uint8_t> norm(m * 32), hc(m * 20), hu(m * 20);
+                check_rc(engine_, vk_derive_batch(engine_, flat.data(), m, norm.data(), hc.data(), hu.data()));
+                for (size_t lo = 0; lo < m; lo += 1u << 18) { // bounded text buffers: ~1 KB per key
+                    const size_t cnt = std::min<size_t>(1u << 18, m - lo);
+                    std::vector<DerivedKey> derived(cnt);
+                    std::vector<std::string> labels(cnt);
+                    parallel_for(cnt, [&](size_t a0, size_t a1) {
+                        for (size_t i = a0; i < a1; i++) {
+                            derived[i] = KeyDeriver::from_device(&norm[32 * (lo + i)], &hc[20 * (lo + i)], &hu[20 * (lo + i)]);
+                            labels[i] = label_of(lo + i);
+                        }
+                    });
+                    for (size_t i = 0; i < cnt; i++) output.key(labels[i], t.name(), derived[i]);
+                }
+            }
         }
-        st.inputs_processed += lines.size();
-        lines.clear();
-        bytes = 0;
-    };
-    auto ws = [](unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; };
-    std::string line;
-    while (std::getline(f, line)) { // src/source/wordlist.rs:24-30, src/source/stdin.rs:45-50: trim, skip empty lines
-        size_t a = 0, b = line.size();
-        while (a < b && ws((unsigned char)line[a])) a++;
-        while (b > a && ws((unsigned char)line[b - 1])) b--;
-        if (a == b) continue;
-        lines.emplace_back(line, a, b - a);
-        bytes += b - a;
-        if (lines.size() == 262144 || bytes > (64u << 20)) flush(); // enough lanes to fill the chip (256 CUs x 1024)
     }
-    if (!lines.empty()) flush();
     if (matcher) check_rc(engine_, vk_targets_set(engine_, nullptr, nullptr, 0));
     return st;
 }
