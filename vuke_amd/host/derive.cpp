@@ -44,6 +44,20 @@ DerivedKey KeyDeriver::from_device(const uint8_t k[32], const uint8_t hc[20], co
     return d;
 }
 
+DerivedKey KeyDeriver::from_device_compact(const uint8_t k[32], const uint8_t hc[20], const uint8_t hu[20])
+{
+    DerivedKey d;
+    memcpy(d.raw.data(), k, 32);
+    memcpy(d.h160_c, hc, 20);
+    memcpy(d.h160_u, hu, 20);
+    d.private_key_hex = hex_encode(k, 32);
+    uint8_t buf[21];
+    buf[0] = 0x00;
+    memcpy(buf + 1, hc, 20);
+    d.p2pkh_compressed = base58check_encode(buf, 21);
+    return d;
+}
+
 std::vector<DerivedKey> KeyDeriver::derive(const std::vector<Key> &keys) const
 {
     std::vector<DerivedKey> out;

@@ -160,6 +160,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
         check_rc(engine_, vk_targets_set(engine_, h160.data(), kind.data(), kind.size()));
     }
     const uint32_t flags = VK_F_COMPRESSED | VK_F_UNCOMPRESSED;
+    const bool full = output.needs_full_record();
     LineReader reader(fp);
     LineBatch b;
     std::vector<uint8_t> keys, valid, flat;
@@ -223,7 +224,8 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                     std::vector<std::string> labels(cnt);
                     parallel_for(cnt, [&](size_t a0, size_t a1) {
                         for (size_t i = a0; i < a1; i++) {
-                            derived[i] = KeyDeriver::from_device(&norm[32 * (lo + i)], &hc[20 * (lo + i)], &hu[20 * (lo + i)]);
+                            derived[i] = full ? KeyDeriver::from_device(&norm[32 * (lo + i)], &hc[20 * (lo + i)], &hu[20 * (lo + i)])
+                                              : KeyDeriver::from_device_compact(&norm[32 * (lo + i)], &hc[20 * (lo + i)], &hu[20 * (lo + i)]);
                             labels[i] = label_of(lo + i);
                         }
                     });
@@ -288,6 +290,7 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
     ProcessStats st;
     st.inputs_processed = end - start + 1; // src/source/range.rs:32
     const uint32_t flags = VK_F_COMPRESSED | VK_F_UNCOMPRESSED;
+    const bool full = output.needs_full_record();
     if (matcher) {
         std::vector<uint8_t> h160, kind;
         matcher->device_targets(h160, kind);
@@ -362,7 +365,9 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
                 std::vector<DerivedKey> derived(n);
                 parallel_for(n, [&](size_t a, size_t b) {
                     for (size_t i = a; i < b; i++)
-                        if (valid[i]) derived[i] = KeyDeriver::from_device(&priv[32 * i], &hc[20 * i], &hu[20 * i]);
+                        if (valid[i])
+                            derived[i] = full ? KeyDeriver::from_device(&priv[32 * i], &hc[20 * i], &hu[20 * i])
+                                              : KeyDeriver::from_device_compact(&priv[32 * i], &hc[20 * i], &hu[20 * i]);
                 });
                 for (size_t i = 0; i < n; i++)
                     if (valid[i]) output.key(t.label(lo + i / k, (uint32_t)(i % k)), t.name(), derived[i]);

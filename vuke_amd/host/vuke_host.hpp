@@ -58,6 +58,8 @@ public:
     DerivedKey derive(const Key &key) const { return derive(std::vector<Key>{key})[0]; }
     // assemble from values the device already produced
     static DerivedKey from_device(const uint8_t normalised[32], const uint8_t h160_c[20], const uint8_t h160_u[20]);
+    // the two fields the compact CSV line prints (private_key_hex, p2pkh_compressed); every other text field stays empty
+    static DerivedKey from_device_compact(const uint8_t normalised[32], const uint8_t h160_c[20], const uint8_t h160_u[20]);
 
 private:
     vk_engine *engine_;
@@ -123,6 +125,9 @@ public:
     virtual void key(const std::string &source, const std::string &transform, const DerivedKey &d) = 0;
     virtual void hit(const std::string &source, const std::string &transform, const DerivedKey &d, const MatchInfo &m) = 0;
     virtual void flush() = 0;
+    // false: key() reads only private_key_hex and p2pkh_compressed (the reference builds all fourteen fields for every
+    // key regardless; at three million keys that is most of generate's wall time)
+    virtual bool needs_full_record() const { return true; }
 };
 
 class ConsoleOutput : public Output { // src/output/console.rs
@@ -134,6 +139,7 @@ public:
     void key(const std::string &source, const std::string &transform, const DerivedKey &d) override;
     void hit(const std::string &source, const std::string &transform, const DerivedKey &d, const MatchInfo &m) override;
     void flush() override;
+    bool needs_full_record() const override { return verbose_; }
 
 private:
     ConsoleOutput(FILE *fp, bool own, bool verbose) : fp_(fp), own_(own), verbose_(verbose) {}
