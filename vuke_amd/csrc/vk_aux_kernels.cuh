@@ -1,0 +1,194 @@
+// vk_aux_kernels.cuh -- the small kernels around the sweep: k*G table builder, Transform::apply_batch for numeric and
+// passphrase inputs, field test hook.  Compiled once (vk_engine.hip); the sweep kernel instantiations live in
+// vk_sweep_tu.hip so the heavy translation units build in parallel.
+#pragma once
+#include "vk_kernels.cuh"
+
+// ---------------------------------------------------------------- table builder
+// entry (w, d) = (d << (W*w)) * G, affine canonical; d = 0 and unrepresentable entries = 0.
+//
+// Two phases so that even a 2^26-entry-per-window table (43 GB) builds in a fraction of a second:
+//   seed     the 2^h "low" multiples d = j and the 2^(W-h) "high" multiples d = i << h of every
+//            window, each by a generic double-and-add (a few 10^4 scalar multiplications);
+//   combine  every other entry is T[i << h] + T[j]: one affine + affine addition, eight of them
+//            per lane sharing one field inversion (Montgomery's trick).
+VK_DEV bool table_scalar(u32 s[8], u32 d, u32 shift, bool allow_2p256 = false)
+{
+    const u32 dbits = 32 - __builtin_clz(d | 1u);
+    if (d == 0) return false;
+    if (shift + dbits > 256) {
+        // the one scalar beyond 256 bits that can occur: 2^256 (final carry of a signed layout) = 2^256 mod n
+        if (allow_2p256 && shift + dbits == 257 && (d & (d - 1)) == 0) {
+            const u32 r[8] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 1u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = r[i];
+            return true;
+        }
+        return false;
+    }
+    const u32 limb = shift >> 5, sh = shift & 31;
+    const u64 wide = (u64)d << sh;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 v = 0;
+        v = (limb == (u32)i) ? (u32)wide : v;
+        v = (limb + 1 == (u32)i) ? (u32)(wide >> 32) : v;
+        s[i] = v;
+    }
+    return true;
+}
+
+VK_DEV void table_store(uint4 *dst, const fe &x, const fe &y)
+{
+    dst[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    dst[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    dst[2] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]);
+    dst[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+}
+
+// seed phase for one window (`win` -> its entry 0, scalar shift `off`, `tb` index bits): the 2^h low
+// digits, the 2^(tb-h) high digits i << h, and (with_max) the single entry 2^tb.
+__global__ void __launch_bounds__(VK_BLOCK) vk_table_seed_kernel(uint4 *win, u32 off, u32 tb, u32 h, u32 with_max)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    const u32 nlo = 1u << h, nhi = 1u << (tb - h);
+    if (idx >= (u64)nlo + nhi + with_max) return;
+    u32 d;
+    if (idx < nlo) d = (u32)idx;
+    else if (idx < (u64)nlo + nhi) d = (u32)(idx - nlo) << h;
+    else d = 1u << tb;
+    if (idx == nlo) return; // high digit 0 is entry 0 again
+    uint4 *dst = win + (u64)d * 4;
+    u32 s[8];
+    if (!table_scalar(s, d, off, with_max && d == (1u << tb))) {
+        dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    jac P;
+    ecmult_generic(P, s);
+    fe zi, x, y;
+    fe_inv(zi, P.z);
+    jac_to_affine(x, y, P, zi);
+    table_store(dst, x, y);
+}
+
+#define VK_TBL_K 8
+// combine phase for one window: one lane = one high digit i >= 1 and VK_TBL_K consecutive low digits
+__global__ void __launch_bounds__(VK_BLOCK) vk_table_combine_kernel(uint4 *win, u32 off, u32 tb, u32 h)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    const u32 nlo = 1u << h, nhi = 1u << (tb - h), runs = nlo / VK_TBL_K;
+    if (idx >= (u64)nhi * runs) return;
+    const u32 run = (u32)(idx % runs), i = (u32)(idx / runs);
+    if (i == 0) return; // those are the seeded low multiples themselves
+    const u32 hi_d = i << h;
+    // digits whose scalar does not fit 256 bits are never looked up: leave them zero
+    u32 tmp[8];
+    const bool hi_ok = table_scalar(tmp, hi_d, off);
+    fe xi, yi;
+    table_load(xi, yi, win + (u64)hi_d * 4);
+    fe c[VK_TBL_K]; // running products of the x differences
+    fe one;
+    fe_set_one(one);
+#pragma unroll
+    for (int k = 0; k < VK_TBL_K; k++) {
+        const u32 j = run * VK_TBL_K + k;
+        fe xj, yj, dx;
+        table_load(xj, yj, win + (u64)j * 4);
+        fe_sub(dx, xj, xi);
+        if (j == 0 || !hi_ok) dx = one;
+        if (k == 0) c[0] = dx;
+        else fe_mul(c[k], c[k - 1], dx);
+    }
+    fe inv;
+    fe_inv(inv, c[VK_TBL_K - 1]);
+#pragma unroll
+    for (int k = VK_TBL_K - 1; k >= 0; k--) {
+        const u32 j = run * VK_TBL_K + k;
+        fe xj, yj, dx, dinv;
+        table_load(xj, yj, win + (u64)j * 4);
+        fe_sub(dx, xj, xi);
+        if (j == 0 || !hi_ok) dx = one;
+        if (k > 0) {
+            fe_mul(dinv, inv, c[k - 1]);
+            fe_mul(inv, inv, dx);
+        } else {
+            dinv = inv;
+        }
+        uint4 *dst = win + ((u64)hi_d + j) * 4;
+        if (j == 0) continue; // the seeded high multiple itself
+        if (!hi_ok) {
+            dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(0, 0, 0, 0);
+            continue;
+        }
+        // (xi, yi) + (xj, yj), distinct x guaranteed (distinct scalars below n, never negatives of each other)
+        fe lam, x3, y3, t;
+        fe_sub(t, yj, yi);
+        fe_mul(lam, t, dinv);
+        fe_sqr(x3, lam);
+        fe_sub(x3, x3, xi);
+        fe_sub(x3, x3, xj);
+        fe_sub(t, xi, x3);
+        fe_mul(y3, lam, t);
+        fe_sub(y3, y3, yi);
+        fe_canon(x3);
+        fe_canon(y3);
+        table_store(dst, x3, y3);
+    }
+}
+
+// ---------------------------------------------------------------- Transform::apply_batch
+template <u32 KIND>
+__global__ void __launch_bounds__(VK_BLOCK) vk_transform_kernel(vk_spec_dev spec, const u64 *seeds, u64 n, u32 slots,
+                                                                u32 *keys_out, unsigned char *valid, vk_ec_ctx ec)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    if (idx >= n * slots) return;
+    const u64 i = idx / slots;
+    const u32 sub = (u32)(idx - i * slots);
+    u32 kw[8];
+    bool ok = KIND == VK_T_ARMORY ? transform_armory(kw, seeds[i], sub, ec) : transform_key<KIND>(kw, spec, seeds[i], sub);
+#pragma unroll
+    for (int j = 0; j < 8; j++) keys_out[idx * 8 + j] = ok ? bswap32(kw[j]) : 0u;
+    valid[idx] = ok ? 1 : 0;
+}
+
+// Transform::apply_batch for Input::from_string inputs of the hash transforms: one lane per (string, slot)
+__global__ void __launch_bounds__(VK_BLOCK) vk_strings_kernel(vk_spec_dev spec, const unsigned char *data, const u32 *offsets, u64 n, u32 slots,
+                                                              u32 *keys_out, unsigned char *valid, vk_ec_ctx ec)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    if (idx >= n * slots) return;
+    const u64 i = idx / slots;
+    const u32 sub = (u32)(idx - i * slots);
+    u32 kw[8];
+    const unsigned char *str = data + offsets[i];
+    const u32 len = offsets[i + 1] - offsets[i];
+    bool ok = spec.kind == VK_T_ARMORY ? transform_armory_string(kw, str, len, sub, ec) : transform_string(kw, spec, str, len, sub);
+#pragma unroll
+    for (int j = 0; j < 8; j++) keys_out[idx * 8 + j] = ok ? bswap32(kw[j]) : 0u;
+    valid[idx] = ok ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- field test hook
+__global__ void vk_field_kernel(int op, const u32 *a, const u32 *b, u64 n, u32 *out)
+{
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    fe x, y, r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { // operands arrive as big-endian bytes
+        x.v[i] = bswap32(a[idx * 8 + 7 - i]);
+        y.v[i] = b ? bswap32(b[idx * 8 + 7 - i]) : 0u;
+    }
+    switch (op) {
+    case 0: fe_mul(r, x, y); break;
+    case 1: fe_sqr(r, x); break;
+    case 2: fe_inv(r, x); break;
+    case 3: fe_add(r, x, y); break;
+    default: fe_sub(r, x, y); break;
+    }
+    fe_canon(r);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[idx * 8 + 7 - i] = bswap32(r.v[i]);
+}

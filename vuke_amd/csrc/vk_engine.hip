@@ -3,7 +3,8 @@
 // point returns VK_E_NO_DEVICE (the oracle under oracle/ is test infrastructure and is never
 // linked into this library).
 #include "../../include/vuke_hip.h"
-#include "vk_kernels.cuh"
+#include "vk_aux_kernels.cuh"
+#include "vk_sweep_launch.h"
 #include "vk_electrum.cuh"
 #include "vk_multibit.cuh"
 #include "vk_search.cuh"
@@ -223,7 +224,7 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     HIPCHK(e, hipMalloc(&e->d_stats, 8 * sizeof(u64)));
     if (e->blocks_per_cu == 0) {
         int occ = 0;
-        HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vk_sweep_kernel<VK_T_MILKSAD>, VK_BLOCK, 0));
+        HIPCHK(e, vk_sweep_occupancy(&occ));
         e->blocks_per_cu = (u32)std::max(1, std::min(occ, 4));
     }
     HIPCHK(e, hipMalloc(&e->d_wins, sizeof e->wins));
@@ -352,11 +353,6 @@ struct launch_io {
     unsigned char *out_valid = nullptr;
 };
 
-template <u32 KIND>
-static void launch_sweep(const vk_sweep_params &p, u32 grid, hipStream_t s)
-{
-    hipLaunchKernelGGL(vk_sweep_kernel<KIND>, dim3(grid), dim3(VK_BLOCK), 0, s, p);
-}
 
 // run [lo, lo+span] (span+1 inputs) under `spec`; accumulates into *st
 static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots, u64 lo, u64 span, u32 flags,
@@ -421,20 +417,9 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     p.out_valid = io.out_valid;
 
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    switch (kind) {
-    case VK_T_SHA256: launch_sweep<VK_T_SHA256>(p, grid, e->stream); break;
-    case VK_T_MILKSAD: launch_sweep<VK_T_MILKSAD>(p, grid, e->stream); break;
-    case VK_T_MT64: launch_sweep<VK_T_MT64>(p, grid, e->stream); break;
-    case VK_T_LCG: launch_sweep<VK_T_LCG>(p, grid, e->stream); break;
-    case VK_T_XORSHIFT: launch_sweep<VK_T_XORSHIFT>(p, grid, e->stream); break;
-    case VK_T_SHA256_CHAIN: launch_sweep<VK_T_SHA256_CHAIN>(p, grid, e->stream); break;
-    case VK_T_DOUBLE_SHA256: launch_sweep<VK_T_DOUBLE_SHA256>(p, grid, e->stream); break;
-    case VK_T_MD5: launch_sweep<VK_T_MD5>(p, grid, e->stream); break;
-    case VK_T_DIRECT: launch_sweep<VK_T_DIRECT>(p, grid, e->stream); break;
-    case VK_T_ARMORY: launch_sweep<VK_T_ARMORY>(p, grid, e->stream); break;
-    case VK_T_RAWKEYS: launch_sweep<VK_T_RAWKEYS>(p, grid, e->stream); break;
-    default: return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
-    }
+    if (!(vk_launch_sweep_g0(kind, p, grid, e->stream) || vk_launch_sweep_g1(kind, p, grid, e->stream) ||
+          vk_launch_sweep_g2(kind, p, grid, e->stream) || vk_launch_sweep_g3(kind, p, grid, e->stream)))
+        return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     u64 hs[8];

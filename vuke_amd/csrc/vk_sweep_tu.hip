@@ -1,0 +1,59 @@
+// vk_sweep_tu.hip -- instantiations of vk_sweep_kernel<KIND>, compiled once per group (-DVK_SWEEP_GROUP=0..3) so the four
+// heavy translation units build side by side (build.sh).
+#include "../../include/vuke_hip.h"
+#include "vk_sweep_launch.h"
+
+#ifndef VK_SWEEP_GROUP
+#error "compile with -DVK_SWEEP_GROUP=0..3"
+#endif
+
+template <u32 KIND>
+static void launch(const vk_sweep_params &p, u32 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(vk_sweep_kernel<KIND>, dim3(grid), dim3(VK_BLOCK), 0, s, p);
+}
+
+#if VK_SWEEP_GROUP == 0
+bool vk_launch_sweep_g0(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s)
+{
+    switch (kind) {
+    case VK_T_MILKSAD: launch<VK_T_MILKSAD>(p, grid, s); return true;
+    case VK_T_MT64: launch<VK_T_MT64>(p, grid, s); return true;
+    case VK_T_RAWKEYS: launch<VK_T_RAWKEYS>(p, grid, s); return true;
+    default: return false;
+    }
+}
+hipError_t vk_sweep_occupancy(int *blocks_per_cu)
+{
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, vk_sweep_kernel<VK_T_MILKSAD>, VK_BLOCK, 0);
+}
+#elif VK_SWEEP_GROUP == 1
+bool vk_launch_sweep_g1(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s)
+{
+    switch (kind) {
+    case VK_T_SHA256: launch<VK_T_SHA256>(p, grid, s); return true;
+    case VK_T_DOUBLE_SHA256: launch<VK_T_DOUBLE_SHA256>(p, grid, s); return true;
+    case VK_T_MD5: launch<VK_T_MD5>(p, grid, s); return true;
+    case VK_T_DIRECT: launch<VK_T_DIRECT>(p, grid, s); return true;
+    default: return false;
+    }
+}
+#elif VK_SWEEP_GROUP == 2
+bool vk_launch_sweep_g2(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s)
+{
+    switch (kind) {
+    case VK_T_LCG: launch<VK_T_LCG>(p, grid, s); return true;
+    case VK_T_XORSHIFT: launch<VK_T_XORSHIFT>(p, grid, s); return true;
+    case VK_T_SHA256_CHAIN: launch<VK_T_SHA256_CHAIN>(p, grid, s); return true;
+    default: return false;
+    }
+}
+#else
+bool vk_launch_sweep_g3(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s)
+{
+    switch (kind) {
+    case VK_T_ARMORY: launch<VK_T_ARMORY>(p, grid, s); return true;
+    default: return false;
+    }
+}
+#endif
