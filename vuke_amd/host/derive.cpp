@@ -2,14 +2,33 @@
 // Matcher (src/matcher.rs:45-108).
 #include "vuke_host.hpp"
 
+#include <cctype>
+#include <cstdio>
+
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
 
 namespace vuke {
 
-DerivedKey KeyDeriver::from_device(const uint8_t k[32], const uint8_t hc[20], const uint8_t hu[20])
+Network parse_network(const std::string &raw)
+{ // src/network.rs:6-17
+    std::string s = raw;
+    for (char &c : s) c = (char)tolower((unsigned char)c);
+    if (s == "bitcoin" || s == "mainnet" || s == "main") return Network::Bitcoin;
+    if (s == "testnet" || s == "test") return Network::Testnet;
+    if (s == "signet") return Network::Signet;
+    if (s == "regtest" || s == "reg") return Network::Regtest;
+    fprintf(stderr, "Unknown network: %s. Defaulting to Bitcoin.\n", raw.c_str());
+    return Network::Bitcoin;
+}
+
+DerivedKey KeyDeriver::from_device(const uint8_t k[32], const uint8_t hc[20], const uint8_t hu[20], Network net)
 {
+    // version bytes and bech32 prefix of the network (rust-bitcoin: PrivateKey::to_wif, Address::p2pkh / p2wpkh)
+    const bool main = net == Network::Bitcoin;
+    const uint8_t wif_ver = main ? 0x80 : 0xEF, p2pkh_ver = main ? 0x00 : 0x6F;
+    const char *hrp = main ? "bc" : net == Network::Regtest ? "bcrt" : "tb";
     DerivedKey d;
     memcpy(d.raw.data(), k, 32);
     memcpy(d.h160_c, hc, 20);
@@ -30,17 +49,17 @@ DerivedKey KeyDeriver::from_device(const uint8_t k[32], const uint8_t hc[20], co
     while (l0 < 64 && d.private_key_hex[l0] == '0') l0++;
     d.leading_zeros = (uint8_t)l0;
     uint8_t buf[40];
-    buf[0] = 0x80;                                           // :102-105,159-160 (mainnet WIF)
+    buf[0] = wif_ver;                                        // :102-105,159-160
     memcpy(buf + 1, k, 32);
     buf[33] = 0x01;
     d.wif_compressed = base58check_encode(buf, 34);
     d.wif_uncompressed = base58check_encode(buf, 33);
-    buf[0] = 0x00;                                           // :112-113 (mainnet P2PKH)
+    buf[0] = p2pkh_ver;                                      // :112-113
     memcpy(buf + 1, hc, 20);
     d.p2pkh_compressed = base58check_encode(buf, 21);
     memcpy(buf + 1, hu, 20);
     d.p2pkh_uncompressed = base58check_encode(buf, 21);
-    d.p2wpkh = segwit_encode("bc", 0, hc, 20);               // :116-118
+    d.p2wpkh = segwit_encode(hrp, 0, hc, 20);                // :116-118
     return d;
 }
 
@@ -67,7 +86,7 @@ std::vector<DerivedKey> KeyDeriver::derive(const std::vector<Key> &keys) const
     for (size_t i = 0; i < n; i++) memcpy(&in[32 * i], keys[i].data(), 32);
     check_rc(engine_, vk_derive_batch(engine_, in.data(), n, norm.data(), hc.data(), hu.data()));
     out.resize(n);
-    for (size_t i = 0; i < n; i++) out[i] = from_device(&norm[32 * i], &hc[20 * i], &hu[20 * i]);
+    for (size_t i = 0; i < n; i++) out[i] = from_device(&norm[32 * i], &hc[20 * i], &hu[20 * i], net_);
     return out;
 }
 

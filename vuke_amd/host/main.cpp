@@ -28,7 +28,8 @@ static int usage(const char *msg)
                     "  --targets <FILE>     (scan) one address per line\n"
                     "  -v, --verbose        (generate) all key formats\n"
                     "  -o, --output <FILE>  write to FILE instead of stdout\n"
-                    "  --network <N>        accepted and ignored, like the reference (src/main.rs:464,499)\n"
+                    "  --network <N>        bitcoin | testnet | signet | regtest: used by `single`; parsed and ignored by generate / scan\n"
+                    "                       exactly like the reference (src/main.rs:464,499)\n"
                     "  --bip39-wordlist <F> 2048-word BIP-39 list (required by --transform multibit)\n"
                     "  --device <N>         GPU index (default 0)\n"
                     "  --window-bits <W>    k*G table window width (default 24)\n"
@@ -132,7 +133,7 @@ int main(int argc, char **argv)
     std::vector<std::string> tnames;
     std::string targets, outpath, single_value;
     bool verbose = false, have_range = false, have_start = false, have_end = false, have_wordlist = false, have_timestamps = false, microseconds = false;
-    std::string wordlist_file, bip39_file, start_s, end_s;
+    std::string wordlist_file, bip39_file, start_s, end_s, network = "bitcoin";
     uint64_t start = 0, end = 0;
     int device = 0;
     unsigned window_bits = 0, layout = VK_LAYOUT_UNIFORM;
@@ -149,7 +150,7 @@ int main(int argc, char **argv)
             } else if (a == "--targets") targets = need("--targets");
             else if (a == "-o" || a == "--output") outpath = need("--output");
             else if (a == "-v" || a == "--verbose") verbose = true;
-            else if (a == "--network") (void)need("--network");
+            else if (a == "--network") network = need("--network");
             else if (a == "--device") device = atoi(need("--device"));
             else if (a == "--window-bits") window_bits = (unsigned)atoi(need("--window-bits"));
             else if (a == "--layout") layout = std::string(need("--layout")) == "signed9" ? VK_LAYOUT_SIGNED9 : VK_LAYOUT_UNIFORM;
@@ -165,6 +166,7 @@ int main(int argc, char **argv)
             else if (cmd == "single" && single_value.empty() && a[0] != '-') single_value = a;
             else throw std::invalid_argument("unexpected argument '" + a + "'");
         }
+        if (cmd != "single") (void)parse_network(network); // src/main.rs:464: parsed (an unknown name warns), then unused
         if (cmd == "generate" && tnames.empty()) tnames.push_back("sha256"); // default_value, src/main.rs:107
         if (tnames.empty()) throw std::invalid_argument("the following required arguments were not provided: --transform <TRANSFORM>...");
         std::vector<Transform> transforms;
@@ -199,7 +201,7 @@ int main(int argc, char **argv)
 
         if (cmd == "single") { // run_single, src/main.rs:954-992: the value is a passphrase (Input::from_string)
             if (single_value.empty()) throw std::invalid_argument("single needs a PASSPHRASE");
-            KeyDeriver deriver(engine);
+            KeyDeriver deriver(engine, parse_network(network)); // KeyDeriver::with_network, src/main.rs:957-958
             for (const Transform &t : transforms) {
                 std::vector<std::pair<std::string, Key>> out;
                 t.apply_batch(engine, std::vector<std::string>{single_value}, out);

@@ -50,19 +50,23 @@ struct DerivedKey { // src/derive.rs:12-41
 
 // KeyDeriver: the k*G + hash160 half runs on the device (vk_derive_batch / vk_generate / hits);
 // this class assembles the reference's record from the device outputs (mainnet, src/derive.rs:62-67).
+enum class Network { Bitcoin, Testnet, Signet, Regtest }; // bitcoin::Network as src/network.rs:6-17 maps it
+Network parse_network(const std::string &s);                 // unknown names warn on stderr and mean Bitcoin
+
 class KeyDeriver {
 public:
-    explicit KeyDeriver(vk_engine *engine) : engine_(engine) {}
+    explicit KeyDeriver(vk_engine *engine, Network net = Network::Bitcoin) : engine_(engine), net_(net) {} // KeyDeriver::with_network
     // derive(&[u8;32]) for arbitrary keys: normalisation + hash160s on the GPU, text on the host
     std::vector<DerivedKey> derive(const std::vector<Key> &keys) const;
     DerivedKey derive(const Key &key) const { return derive(std::vector<Key>{key})[0]; }
     // assemble from values the device already produced
-    static DerivedKey from_device(const uint8_t normalised[32], const uint8_t h160_c[20], const uint8_t h160_u[20]);
+    static DerivedKey from_device(const uint8_t normalised[32], const uint8_t h160_c[20], const uint8_t h160_u[20], Network net = Network::Bitcoin);
     // the two fields the compact CSV line prints (private_key_hex, p2pkh_compressed); every other text field stays empty
     static DerivedKey from_device_compact(const uint8_t normalised[32], const uint8_t h160_c[20], const uint8_t h160_u[20]);
 
 private:
     vk_engine *engine_;
+    Network net_;
 };
 
 // ---------------------------------------------------------------- matcher.rs
