@@ -12,6 +12,7 @@
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
+#include <thread>
 
 using namespace vuke;
 
@@ -32,6 +33,7 @@ static int usage(const char *msg)
                     "                       exactly like the reference (src/main.rs:464,499)\n"
                     "  --bip39-wordlist <F> 2048-word BIP-39 list (required by --transform multibit)\n"
                     "  --device <N>         GPU index (default 0)\n"
+                    "  --devices <LIST|all> several GPUs: a range source is cut into one contiguous block per GPU\n"
                     "  --window-bits <W>    k*G table window width (default 24)\n"
                     "  --layout <L>         uniform (default) | signed9 (120 GB table, 8 additions per key)\n");
     return 2;
@@ -133,7 +135,7 @@ int main(int argc, char **argv)
     std::vector<std::string> tnames;
     std::string targets, outpath, single_value;
     bool verbose = false, have_range = false, have_start = false, have_end = false, have_wordlist = false, have_timestamps = false, microseconds = false;
-    std::string wordlist_file, bip39_file, start_s, end_s, network = "bitcoin";
+    std::string wordlist_file, bip39_file, start_s, end_s, network = "bitcoin", devices_s;
     uint64_t start = 0, end = 0;
     int device = 0;
     unsigned window_bits = 0, layout = VK_LAYOUT_UNIFORM;
@@ -152,6 +154,7 @@ int main(int argc, char **argv)
             else if (a == "-v" || a == "--verbose") verbose = true;
             else if (a == "--network") network = need("--network");
             else if (a == "--device") device = atoi(need("--device"));
+            else if (a == "--devices") devices_s = need("--devices");
             else if (a == "--window-bits") window_bits = (unsigned)atoi(need("--window-bits"));
             else if (a == "--layout") layout = std::string(need("--layout")) == "signed9" ? VK_LAYOUT_SIGNED9 : VK_LAYOUT_UNIFORM;
             else if (a == "range") have_range = true;
@@ -182,16 +185,44 @@ int main(int argc, char **argv)
         }
         if (cmd != "single" && have_range && end < start) throw std::invalid_argument("--end must be >= --start");
 
-        vk_engine *engine = nullptr;
+        // --devices 0,1,... | all: one engine per listed GPU (range sources split the range between them)
+        std::vector<int> devs;
+        if (devices_s == "all") {
+            for (int i = 0; i < vk_device_count(); i++) devs.push_back(i);
+        } else if (!devices_s.empty()) {
+            size_t pos = 0;
+            while (pos <= devices_s.size()) {
+                size_t q = devices_s.find(',', pos);
+                const std::string part = devices_s.substr(pos, q == std::string::npos ? std::string::npos : q - pos);
+                if (part.empty() || part.find_first_not_of("0123456789") != std::string::npos) throw std::invalid_argument("--devices takes a comma separated list of GPU indices, or 'all'");
+                devs.push_back(atoi(part.c_str()));
+                if (q == std::string::npos) break;
+                pos = q + 1;
+            }
+        }
+        if (devs.empty()) devs.push_back(device);
         vk_engine_opts opts{};
         opts.window_bits = window_bits;
         opts.layout = layout;
-        int rc = vk_engine_create_ex(device, &opts, &engine);
-        if (rc != VK_OK) {
-            fprintf(stderr, "GPU engine unavailable: %s\n", vk_last_error(nullptr));
-            return 1;
+        std::vector<vk_engine *> engines(devs.size(), nullptr);
+        struct Guard { std::vector<vk_engine *> &v; ~Guard() { for (vk_engine *e : v) vk_engine_destroy(e); } } guard{engines};
+        {
+            std::vector<int> rcs(devs.size(), VK_OK);
+            std::vector<std::string> msgs(devs.size());
+            std::vector<std::thread> th; // the k*G tables are built side by side
+            for (size_t i = 0; i < devs.size(); i++)
+                th.emplace_back([&, i]() {
+                    rcs[i] = vk_engine_create_ex(devs[i], &opts, &engines[i]);
+                    if (rcs[i] != VK_OK) msgs[i] = vk_last_error(nullptr); // the creation error is thread local
+                });
+            for (auto &t : th) t.join();
+            for (size_t i = 0; i < devs.size(); i++)
+                if (rcs[i] != VK_OK) {
+                    fprintf(stderr, "GPU engine unavailable (device %d): %s\n", devs[i], msgs[i].c_str());
+                    return 1;
+                }
         }
-        struct Guard { vk_engine *e; ~Guard() { vk_engine_destroy(e); } } guard{engine};
+        vk_engine *engine = engines[0];
         for (const Transform &t : transforms)
             if (t.spec().kind == VK_T_MULTIBIT) {
                 if (bip39_file.empty()) throw std::invalid_argument("multibit needs --bip39-wordlist <FILE> (the 2048-word BIP-39 English list)");
@@ -230,6 +261,7 @@ int main(int argc, char **argv)
         std::unique_ptr<Source> source_ptr;
         if (have_wordlist) source_ptr = std::make_unique<HipWordlistSource>(engine, wordlist_file);
         else if (have_timestamps) source_ptr = std::make_unique<HipTimestampSource>(engine, start_s, end_s, microseconds);
+        else if (engines.size() > 1) source_ptr = std::make_unique<HipMultiRangeSource>(engines, start, end);
         else source_ptr = std::make_unique<HipRangeSource>(engine, start, end);
         Source &source = *source_ptr;
         ProcessStats stats;

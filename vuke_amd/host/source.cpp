@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <iostream>
 #include <thread>
@@ -235,6 +236,40 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
         }
     }
     if (matcher) check_rc(engine_, vk_targets_set(engine_, nullptr, nullptr, 0));
+    return st;
+}
+
+ProcessStats HipMultiRangeSource::process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output)
+{
+    const size_t g = engines_.size();
+    if (g == 0) throw std::invalid_argument("no engines");
+    // block i = [start + i*per, ...): ceil(N / G) inputs each, the last one shorter (N = 2^64 cannot occur: end - start <= 2^64 - 1)
+    const uint64_t span = end - start; // inputs - 1
+    const uint64_t per = span / g + 1;
+    std::vector<ProcessStats> part(g);
+    std::vector<std::exception_ptr> err(g);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < g; i++) {
+        const uint64_t off = per * i;
+        if (off > span) break; // fewer inputs than engines
+        const uint64_t lo = start + off, hi = (span - off < per - 1) ? end : lo + per - 1;
+        th.emplace_back([&, i, lo, hi]() {
+            try {
+                part[i] = HipRangeSource(engines_[i], lo, hi).process(transforms, matcher, output);
+            } catch (...) {
+                err[i] = std::current_exception();
+            }
+        });
+    }
+    for (auto &t : th) t.join();
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
+    ProcessStats st;
+    for (auto &p : part) {
+        st.inputs_processed += p.inputs_processed;
+        st.keys_generated += p.keys_generated;
+        st.matches_found += p.matches_found;
+    }
     return st;
 }
 

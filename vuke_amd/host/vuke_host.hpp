@@ -175,6 +175,18 @@ private:
     vk_engine *engine_;
 };
 
+// RangeSource over several GPUs: [start, end] cut into one contiguous block per engine, one host thread per
+// engine, no exchange between them; counters summed.  The same partition bench.py uses across processes.
+class HipMultiRangeSource : public Source {
+public:
+    HipMultiRangeSource(std::vector<vk_engine *> engines, uint64_t start, uint64_t end) : start(start), end(end), engines_(std::move(engines)) {}
+    ProcessStats process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output) override;
+    uint64_t start, end;
+
+private:
+    std::vector<vk_engine *> engines_;
+};
+
 // WordlistSource / StdinSource on the GPU (src/source/wordlist.rs, src/source/stdin.rs): one passphrase per line,
 // trimmed, empty lines skipped, Input::from_string.  path "-" reads stdin.  Transforms that need a numeric seed
 // emit nothing for these inputs, exactly like the reference.
