@@ -1,16 +1,16 @@
 // vk_kernels.cuh -- the fused sweep kernel: seed -> key -> k*G -> hash160 -> probe, on gfx950.
 //
-// Shape of one workgroup tile (256 lanes, B = R * slots items per lane):
+// Shape of one workgroup tile (256 lanes, B = R * slots items per lane; tiles come from an atomic counter):
 //   pass 1  for each item: transform -> normalise -> ecmult_table -> Jacobian (X, Y, Z);
-//           running product c_b = Z_0..Z_b; (X, Y, Z, c_b) parked in an HBM workspace laid out
-//           [item][quad][thread] so every access is a 16-byte-per-lane coalesced line.
+//           running product c_b = Z_0..Z_b; (X, Y, Z, c_b) parked in the workgroup's own slice of an HBM
+//           workspace laid out [item][quad][lane] so every access is a 16-byte-per-lane coalesced line.
 //   invert  one field inversion of c_{B-1} per lane (Montgomery's trick: 3 multiplies per key
 //           instead of a 255-squaring inversion per key).
 //   pass 2  walk the items backwards: zinv_b = inv * c_{b-1}; inv *= Z_b; affine (x, y);
 //           SHA-256 + RIPEMD-160 of the SEC1 encoding(s); digest fold; open-address probe of
 //           the target table; hit record / generate-mode record.
-// No LDS, no cross-lane traffic in the loop, no MFMA: the path is integer-VALU bound; the
-// only memory streams are the table gathers (64 B per window, L2 / Infinity-Cache resident),
+// LDS holds only the tile index, no cross-lane traffic in the loop, no MFMA: the path is integer-VALU bound; the
+// only memory streams are the table gathers (64 B per window, random over the whole HBM table),
 // the workspace (256 B per key) and one 32-byte probe line per hash160.
 //
 // Replaces the closure body of RangeSource::process (reference src/source/range.rs:42-70):
