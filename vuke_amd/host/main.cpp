@@ -94,7 +94,8 @@ static int run_analyze(int argc, char **argv)
         if (!cascade_s.empty()) cfg.cascade_targets = parse_cascade(cascade_s);
         vk_engine *engine = nullptr;
         vk_engine_opts opts{};
-        opts.window_bits = 8; // the analyzers never touch the k*G table: keep it tiny
+        opts.window_bits = 8; // the analyzers never touch the k*G table or the inversion workspace: keep both tiny
+        opts.batch = 1;
         if (vk_engine_create_ex(device, &opts, &engine) != VK_OK) {
             fprintf(stderr, "GPU engine unavailable: %s\n", vk_last_error(nullptr));
             return 1;
