@@ -71,3 +71,95 @@ def test_lcg_all_variants_key_counts_across_ceilings(eng):
     assert st["inputs"] == 2 * h and st["keys"] == h + (h - 1) + 2 * h + 2 * h
     st, _ = eng.sweep(spec, 2**32 - h, 2**32 + h - 1, flags=1)
     assert st["keys"] == 2 * h
+
+
+def test_config3_sha256_scan_against_a_million_targets(eng):
+    """BASELINE config 3 at full size: seeds 0..99 999 999 x 3 keys, 1 000 000 targets = 999 000 decoys +
+    1 000 planted (seed 7919*j, slot j%3, kind cycling p2pkh_c / p2pkh_u / p2wpkh): exactly the planted keys are hit."""
+    import hashlib
+    import struct
+    from vuke_amd import _ffi as ffi
+    spec = ffi.spec(ffi.T_SHA256)
+    planted = [(7919 * j, j % 3, j % 3) for j in range(1000)]
+    rows = eng.transform_batch(spec, [s for s, _, _ in planted])
+    keys = [rows[i][sub] for i, (_, sub, _) in enumerate(planted)]
+    _, hc, hu = eng.derive_batch(keys)
+    h160s = [u if kind == 1 else c for (_, _, kind), c, u in zip(planted, hc, hu)]
+    kinds = [ffi.TARGET_P2WPKH if kind == 2 else ffi.TARGET_P2PKH for _, _, kind in planted]
+    for j in range(999_000):
+        h160s.append(hashlib.sha256(b"decoy" + struct.pack("<Q", j)).digest()[:20])
+        kinds.append(j & 1)
+    eng.targets_set(h160s, kinds)
+    st, hits = eng.sweep(spec, 0, 99_999_999, flags=3, hit_cap=4096)
+    eng.targets_set([], [])
+    assert (st["inputs"], st["keys"], st["matches"], st["hits_dropped"]) == (10**8, 3 * 10**8, 1000, 0)
+    assert sorted((h["seed"], h["sub_index"], h["addr_kind"]) for h in hits) == sorted(planted)
+    assert {(h["seed"], h["sub_index"]): h["privkey"] for h in hits} == {(s, sub): k for (s, sub, _), k in zip(planted, keys)}
+
+
+def test_config4_all_lcg_variants_over_2p31_seeds(eng):
+    """BASELINE config 4 at full size on one GPU: every LCG variant x seeds 0..2^31-1 in eight contiguous 2^28 blocks
+    (the 8-GPU split), 256 planted keys per variant; counters, hits and the digest of the whole agree with the blocks."""
+    from vuke_amd import _ffi as ffi
+    spec = ffi.spec(ffi.T_LCG)
+    planted = sorted({((0x9E3779B1 * j + 777 * v) & 0x7FFFFFFF, v) for v in range(4) for j in range(256)} - {(2**31 - 1, 1)})
+    rows = eng.transform_batch(spec, [s for s, _ in planted])
+    keys = [rows[i][v] for i, (_, v) in enumerate(planted)]
+    assert all(k is not None for k in keys)
+    _, hc, _ = eng.derive_batch(keys)
+    eng.targets_set(hc, [ffi.TARGET_P2PKH] * len(hc))
+    parts, hits = [], []
+    for b in range(8):
+        st, h = eng.sweep(spec, b << 28, ((b + 1) << 28) - 1, flags=ffi.F_COMPRESSED, hit_cap=4096)
+        parts.append(st)
+        hits += h
+    eng.targets_set([], [])
+    assert sum(p["inputs"] for p in parts) == 2**31
+    assert sum(p["keys"] for p in parts) == 4 * 2**31 - 1          # minstd skips seed 2^31 - 1 (src/transform/lcg.rs: seed <= m - 1)
+    assert sum(p["matches"] for p in parts) == len(planted)
+    assert sorted((h["seed"], h["sub_index"]) for h in hits) == planted
+    whole, _ = eng.sweep(spec, 0, 2**31 - 1, flags=ffi.F_COMPRESSED)
+    assert whole["keys"] == 4 * 2**31 - 1 and whole["digest"] == fold(p["digest"] for p in parts)
+
+
+def test_config5_key_chains_at_size(eng, vko):
+    """BASELINE config 5 at its stated size for MultiBit (100 000 synthetic 12-word mnemonics, 20 indices) and a
+    4 096-seed Electrum slice of it (the stretch is 2 x 10^5 compressions per seed on the CPU side of the check):
+    planted = index-7 key of every 1000th / 512th input; the oracle recomputes exactly those inputs."""
+    import random
+    from tests.test_oracle_multibit import synthetic_wordlist
+    from vuke_amd import _ffi as ffi
+    words = synthetic_wordlist()
+    eng.bip39_wordlist_set(words)
+    rnd = random.Random(5489)
+    mn = [" ".join(words[rnd.getrandbits(11)] for _ in range(12)) for _ in range(100_000)]
+    spec = ffi.spec(ffi.T_MULTIBIT, 0, 0, 20)
+    keys, valid, _ = eng.transform_strings(spec, [m.encode() for m in mn], raw=True)
+    assert sum(valid) == 20 * len(mn)
+    wl = vko.Wordlist(words)
+    chosen = list(range(0, len(mn), 1000))
+    want = {i: vko.multibit_keys(wl, mn[i])[2] for i in chosen}
+    for i in chosen:
+        assert [keys[32 * (20 * i + j):32 * (20 * i + j) + 32] for j in range(20)] == [k for _, k in want[i]], i
+    planted = [want[i][7][1] for i in chosen]
+    _, hc, _ = eng.derive_batch(planted)
+    eng.targets_set(hc, [ffi.TARGET_P2PKH] * len(hc))
+    st, hits = eng.scan_keys([keys[o:o + 32] for o in range(0, len(keys), 32)], flags=3, hit_cap=1024)
+    assert (st["inputs"], st["matches"]) == (20 * len(mn), len(chosen))
+    assert [h["index"] for h in hits] == [20 * i + 7 for i in chosen]
+    # Electrum: uncompressed P2PKH is the address form of interest (src/electrum.rs:216-285)
+    seeds = [("%032x" % rnd.getrandbits(128)).encode() for _ in range(4096)]
+    spec = ffi.spec(ffi.T_ELECTRUM, 0, 0, 20)
+    keys, valid, _ = eng.transform_strings(spec, seeds, raw=True)
+    assert sum(valid) == 20 * len(seeds)
+    chosen = list(range(0, len(seeds), 512))
+    want = {i: vko.electrum_keys(seeds[i], for_change=False)[1] for i in chosen}
+    for i in chosen:
+        assert [keys[32 * (20 * i + j):32 * (20 * i + j) + 32] for j in range(20)] == [k for _, k in want[i]], i
+    planted = [want[i][7][1] for i in chosen]
+    _, _, hu = eng.derive_batch(planted)
+    eng.targets_set(hu, [ffi.TARGET_P2PKH] * len(hu))
+    st, hits = eng.scan_keys([keys[o:o + 32] for o in range(0, len(keys), 32)], flags=3, hit_cap=64)
+    eng.targets_set([], [])
+    assert st["matches"] == len(chosen) and [h["index"] for h in hits] == [20 * i + 7 for i in chosen]
+    assert all(h["addr_kind"] == 1 for h in hits)
