@@ -48,6 +48,8 @@ def main():
         "xorshift": (vko.T_XORSHIFT, vko.VARIANT_ALL, 0, 10), "xorshift:128": (vko.T_XORSHIFT, 1, 0, 10),
         "sha256_chain": (vko.T_SHA256_CHAIN, vko.VARIANT_ALL, 0, 10), "sha256_chain:counter": (vko.T_SHA256_CHAIN, 3, 0, 10),
         "sha256_chain:indexed:le": (vko.T_SHA256_CHAIN, 2, 0, 10),
+        "double_sha256": (vko.T_DOUBLE_SHA256, vko.VARIANT_ALL, 0, 10), "md5": (vko.T_MD5, vko.VARIANT_ALL, 0, 10),
+        "direct": (vko.T_DIRECT, vko.VARIANT_ALL, 0, 10), "armory": (vko.T_ARMORY, vko.VARIANT_ALL, 0, 10),
     }
     tv = {}
     for name, (kind, var, en, depth) in specs.items():
@@ -55,6 +57,24 @@ def main():
         tv[name] = {"spec": [kind, var, en, depth], "name": vko.transform_name(sp),
                     "vectors": {str(s): [[l, k.hex()] for l, k in vko.transform_apply(sp, s)] for s in SEEDS}}
     json.dump(tv, open(os.path.join(HERE, "transforms.json"), "w"), indent=0)
+
+    # passphrase inputs (Input::from_string): per transform, the keys each string emits (null = nothing emitted)
+    srnd = random.Random(424242)
+    strings = [b"", b"a", b"password", b"correct horse battery staple", "za\u017c\u00f3\u0142\u0107".encode(), b"x" * 32, b"y" * 33, b"z" * 55, b"w" * 56, b"v" * 64, b"u" * 119, b"t" * 120]
+    strings += [bytes(srnd.randrange(1, 256) for _ in range(srnd.randrange(1, 300))) for _ in range(20)]
+    sspecs = {"sha256": (vko.T_SHA256, vko.VARIANT_ALL, 0, 10), "double_sha256": (vko.T_DOUBLE_SHA256, vko.VARIANT_ALL, 0, 10),
+              "md5": (vko.T_MD5, vko.VARIANT_ALL, 0, 10), "direct": (vko.T_DIRECT, vko.VARIANT_ALL, 0, 10),
+              "armory": (vko.T_ARMORY, vko.VARIANT_ALL, 0, 10), "sha256_chain": (vko.T_SHA256_CHAIN, vko.VARIANT_ALL, 0, 3),
+              "sha256_chain:indexed:be": (vko.T_SHA256_CHAIN, 1, 0, 5)}
+    sv = {"strings": [x.hex() for x in strings], "transforms": {}}
+    for name, (kind, var, en, depth) in sspecs.items():
+        sp = vko.spec(kind, var, en, depth)
+        rows = []
+        for x in strings:
+            ks = [vko.transform_string(sp, x, sub) for sub in range(vko.slots_per_string(sp))]
+            rows.append([k.hex() if k is not None else None for k in ks])
+        sv["transforms"][name] = {"spec": [kind, var, en, depth], "keys": rows}
+    json.dump(sv, open(os.path.join(HERE, "strings.json"), "w"), indent=0)
 
     # config 1 in miniature: `generate --transform sha256 range --start 0 --end 1000`, compact lines, sorted
     sp = vko.spec(vko.T_SHA256)
