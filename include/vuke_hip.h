@@ -196,7 +196,9 @@ int vk_scan_keys(vk_engine *e, const uint8_t *keys /* n*32 */, size_t n, uint32_
  * VK_T_SHA256_CHAIN (u32 seeds hashed as 4 big-endian bytes; spec.variant 0..3 or VK_VARIANT_ALL; exact / masked look
  * at every key of the chain of spec.chain_depth, cascade compares chain[j] with target j).  The reference reports
  * whichever matching seed a worker thread finds first; this search reports the smallest, which is one of the
- * reference's possible answers; for sha256_chain the (variant, index) is the first in the reference's loop order. */
+ * reference's possible answers; for sha256_chain the (variant, index) is the first in the reference's loop order.
+ * VK_T_SHA256 / DOUBLE_SHA256 / MD5 / DIRECT (exact, masked): any key the transform emits for the seed, result.index =
+ * its slot -- the transform-only sweep the reference's `vuke bench` harness times (src/benchmark.rs:11-67). */
 #define VK_SEARCH_EXACT 0u   /* key == target.key                                     (analyze_exact) */
 #define VK_SEARCH_MASKED 1u  /* ((last 8 key bytes, BE) & (2^bits-1)) | 2^(bits-1) == last 8 bytes of target.key  (analyze_masked) */
 #define VK_SEARCH_CASCADE 2u /* draws j = 0..n-1 of one generator instance: masked(draw j, bits[j]) == targets[j]  (analyze_cascading) */

@@ -570,3 +570,25 @@ def test_engine_is_safe_to_share_between_threads(vko):
     shared.close()
     other.close()
     assert errors == []
+
+
+def test_search_over_hash_transforms(eng, vko):
+    """vk_search for sha256 / double_sha256 / md5 / direct: exact and masked against every slot of a seed (the
+    transform-only sweep behind `vuke-hip bench`)."""
+    from vuke_amd import _ffi as ffi
+    for kind in (ffi.T_SHA256, ffi.T_DOUBLE_SHA256, ffi.T_MD5, ffi.T_DIRECT):
+        gs, os_ = ffi.spec(kind), vko.spec(kind)
+        slots = vko.slots_per_input(os_)
+        for seed, sub in ((3_000_000_123, slots - 1), (17, 0)):
+            key = vko.transform_key(os_, seed, sub)
+            r = eng.search(gs, 0, 2**32 - 1, key=key)
+            assert (r["found"], r["seed"], r["index"], r["keys"]) == (True, seed, sub, [key]), (kind, seed)
+        r = eng.search(gs, 0, 2**26, key=bytes([0x55]) * 32)
+        assert not r["found"] and r["seeds_checked"] == 2**26 + 1
+        # masked: smallest seed any of whose keys ends in the 12-bit pattern; checked against the oracle's transform
+        r = eng.search(gs, 10**6, 10**6 + 50000, key=(0xabc).to_bytes(32, "big"), mask_bits=12)
+        want = next(((s, i) for s in range(10**6, 10**6 + 50001) for i in range(slots)
+                     if (int.from_bytes(vko.transform_key(os_, s, i)[24:], "big") & 0xfff) | 0x800 == 0xabc), None)
+        assert (r["found"], (r["seed"], r["index"]) if r["found"] else None) == (want is not None, want), kind
+    with pytest.raises(Exception):
+        eng.search(ffi.spec(ffi.T_SHA256), 0, 10, cascade=[(8, 0x80), (8, 0x81)])

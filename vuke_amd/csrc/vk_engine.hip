@@ -804,8 +804,10 @@ extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
     std::lock_guard<std::mutex> lk(e->mu);
     if (!t || !tg || !out) return fail(e, VK_E_INVALID_ARG, "spec / target / out is NULL");
     if (hi < lo) return fail(e, VK_E_INVALID_ARG, "seed_hi < seed_lo");
-    if (t->kind != VK_T_MILKSAD && t->kind != VK_T_MT64 && t->kind != VK_T_LCG && t->kind != VK_T_XORSHIFT && t->kind != VK_T_SHA256_CHAIN)
-        return fail(e, VK_E_UNSUPPORTED, "vk_search is built for milksad, mt64, lcg, xorshift and sha256_chain");
+    const bool slot_kind = t->kind == VK_T_SHA256 || t->kind == VK_T_DOUBLE_SHA256 || t->kind == VK_T_MD5 || t->kind == VK_T_DIRECT;
+    if (t->kind != VK_T_MILKSAD && t->kind != VK_T_MT64 && t->kind != VK_T_LCG && t->kind != VK_T_XORSHIFT && t->kind != VK_T_SHA256_CHAIN && !slot_kind)
+        return fail(e, VK_E_UNSUPPORTED, "vk_search is built for milksad, mt64, lcg, xorshift, sha256_chain and the hash transforms");
+    if (slot_kind && tg->mode == VK_SEARCH_CASCADE) return fail(e, VK_E_UNSUPPORTED, "the hash transforms are not generators: no cascade mode");
     if (t->kind == VK_T_LCG && (t->variant > 3 || t->endian > 1)) return fail(e, VK_E_INVALID_ARG, "lcg search takes one variant (0..3) and an endian");
     if (t->kind == VK_T_XORSHIFT) {
         if (t->variant > 3) return fail(e, VK_E_INVALID_ARG, "xorshift search takes one variant (0..3)");
@@ -860,6 +862,10 @@ extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
         else if (t->kind == VK_T_MT64) wide ? launch_search<VK_T_MT64, 8>(p, grid, e->stream) : launch_search<VK_T_MT64, 1>(p, grid, e->stream);
         else if (t->kind == VK_T_XORSHIFT) wide ? launch_search<VK_T_XORSHIFT, 8>(p, grid, e->stream) : launch_search<VK_T_XORSHIFT, 1>(p, grid, e->stream);
         else if (t->kind == VK_T_SHA256_CHAIN) launch_search<VK_T_SHA256_CHAIN, 1>(p, grid, e->stream);
+        else if (t->kind == VK_T_SHA256) hipLaunchKernelGGL(vk_search_slots_kernel<VK_T_SHA256>, dim3(grid), dim3(VK_BLOCK), 0, e->stream, p);
+        else if (t->kind == VK_T_DOUBLE_SHA256) hipLaunchKernelGGL(vk_search_slots_kernel<VK_T_DOUBLE_SHA256>, dim3(grid), dim3(VK_BLOCK), 0, e->stream, p);
+        else if (t->kind == VK_T_MD5) hipLaunchKernelGGL(vk_search_slots_kernel<VK_T_MD5>, dim3(grid), dim3(VK_BLOCK), 0, e->stream, p);
+        else if (t->kind == VK_T_DIRECT) hipLaunchKernelGGL(vk_search_slots_kernel<VK_T_DIRECT>, dim3(grid), dim3(VK_BLOCK), 0, e->stream, p);
         else launch_search<VK_T_LCG, 1>(p, grid, e->stream);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipEventRecord(e->ev1, e->stream));
@@ -886,6 +892,10 @@ extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
         else if (t->kind == VK_T_MT64) launch_emit<VK_T_MT64, 8>(p.spec, best, d_out, e->stream);
         else if (t->kind == VK_T_XORSHIFT) launch_emit<VK_T_XORSHIFT, 8>(p.spec, best, d_out, e->stream);
         else if (t->kind == VK_T_SHA256_CHAIN) hipLaunchKernelGGL(vk_search_emit_chain_kernel, dim3(1), dim3(64), 0, e->stream, p, best, d_out);
+        else if (t->kind == VK_T_SHA256) hipLaunchKernelGGL(vk_search_emit_slots_kernel<VK_T_SHA256>, dim3(1), dim3(64), 0, e->stream, p, best, d_out);
+        else if (t->kind == VK_T_DOUBLE_SHA256) hipLaunchKernelGGL(vk_search_emit_slots_kernel<VK_T_DOUBLE_SHA256>, dim3(1), dim3(64), 0, e->stream, p, best, d_out);
+        else if (t->kind == VK_T_MD5) hipLaunchKernelGGL(vk_search_emit_slots_kernel<VK_T_MD5>, dim3(1), dim3(64), 0, e->stream, p, best, d_out);
+        else if (t->kind == VK_T_DIRECT) hipLaunchKernelGGL(vk_search_emit_slots_kernel<VK_T_DIRECT>, dim3(1), dim3(64), 0, e->stream, p, best, d_out);
         else launch_emit<VK_T_LCG, 1>(p.spec, best, d_out, e->stream);
         c = hipGetLastError();
     }
@@ -894,7 +904,8 @@ extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
     (void)hipFree(d_out);
     memcpy(out->keys, h_out, 8 * 32);
     out->variant = t->kind == VK_T_SHA256_CHAIN ? h_out[64] : (t->variant == VK_VARIANT_ALL ? 0u : t->variant);
-    out->index = t->kind == VK_T_SHA256_CHAIN ? h_out[65] : 0u;
+    out->index = (t->kind == VK_T_SHA256_CHAIN || slot_kind) ? h_out[65] : 0u;
+    if (slot_kind) out->n_keys = 1;
     if (t->kind == VK_T_SHA256_CHAIN && tg->mode != VK_SEARCH_CASCADE) out->n_keys = 1;
     if (c != hipSuccess) {
         e->err = std::string("vk_search: ") + hipGetErrorString(c);

@@ -276,6 +276,54 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_search_kernel(const vk_search_par
     if (best != ~0ull) atomicMin((unsigned long long *)p.best, (unsigned long long)best);
 }
 
+// Any other numeric transform (sha256, double_sha256, md5, direct): exact / masked against every key the transform
+// emits for a seed (slot order = emit order).  Not a reference analyzer: it is the transform-only sweep that the
+// reference's `vuke bench` harness times (src/benchmark.rs:11-67), and an exact-key lookup for those transforms.
+template <u32 KIND>
+VK_DEV bool slots_search_seed(const vk_search_params &p, u64 seed, u32 &hit_sub, u32 kw_out[8])
+{
+    const u32 slots = spec_slots(p.spec);
+#pragma unroll 1
+    for (u32 sub = 0; sub < slots; sub++) {
+        u32 kw[1][8];
+        if (transform_key<KIND>(kw[0], p.spec, seed, sub) && search_match<1>(kw, p)) {
+            hit_sub = sub;
+#pragma unroll
+            for (int j = 0; j < 8; j++) kw_out[j] = kw[0][j];
+            return true;
+        }
+    }
+    return false;
+}
+
+template <u32 KIND>
+__global__ void __launch_bounds__(VK_BLOCK) vk_search_slots_kernel(const vk_search_params p)
+{
+    const u64 stride = (u64)gridDim.x * VK_BLOCK;
+    u64 best = ~0ull;
+    for (u64 off = (u64)blockIdx.x * VK_BLOCK + threadIdx.x; off <= p.span; off += stride) {
+        u32 sub, kw[8];
+        if (slots_search_seed<KIND>(p, p.lo + off, sub, kw)) {
+            best = p.lo + off;
+            break;
+        }
+        if (off + stride < off) break;
+    }
+    if (best != ~0ull) atomicMin((unsigned long long *)p.best, (unsigned long long)best);
+}
+
+template <u32 KIND>
+__global__ void vk_search_emit_slots_kernel(const vk_search_params p, u64 seed, u32 *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u32 sub = 0, kw[8];
+    if (!slots_search_seed<KIND>(p, seed, sub, kw)) return;
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[j] = bswap32(kw[j]);
+    out[64] = 0;
+    out[65] = sub;
+}
+
 // the ND draws of one seed, as raw key bytes (for the result record)
 template <u32 KIND, int ND>
 __global__ void vk_search_emit_kernel(vk_spec_dev spec, u64 seed, u32 *out /* ND x 8 words */)

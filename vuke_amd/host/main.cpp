@@ -8,6 +8,7 @@
 // Extras: --device N, --window-bits W.
 #include "vuke_host.hpp"
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -21,6 +22,7 @@ static int usage(const char *msg)
     if (msg) fprintf(stderr, "error: %s\n\n", msg);
     fprintf(stderr, "Usage: vuke-hip <generate|scan> [OPTIONS] <SOURCE>\n"
                     "       vuke-hip single <PASSPHRASE> --transform <T>\n"
+                    "       vuke-hip bench [--transform <T>] [--json]      transform-only inputs/s (the reference's `vuke bench`)\n"
                     "       vuke-hip analyze <KEY> [--mask BITS] [--cascade b:t,b:t,...] [--analyzer milksad|lcg[:variant][:endian]|mt64|xorshift[:variant]|sha256_chain[:variant]]...\n"
                     "  --transform <T>...   sha256 | double_sha256 | md5 | direct | armory | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] |\n"
                     "                       sha256_chain[:variant] | electrum[:change] | multibit\n"
@@ -127,11 +129,95 @@ static int run_analyze(int argc, char **argv)
     }
 }
 
+// `vuke bench [--transform T] [--json]` (src/benchmark.rs:11-67): transform-only inputs per second -- no k*G, no hashing
+// to an address, no match.  On the device that is a vk_search sweep against a key no input produces; the reference
+// feeds one input a million times, here distinct seeds are swept (same work per input for every transform).
+static int run_bench(int argc, char **argv)
+{
+    std::string tname = "sha256";
+    bool json = false;
+    int device = 0;
+    double seconds = 5.0;
+    try {
+        for (int i = 2; i < argc; i++) {
+            std::string a = argv[i];
+            auto need = [&](const char *opt) -> const char * {
+                if (i + 1 >= argc) throw std::invalid_argument(std::string("a value is required for '") + opt + "'");
+                return argv[++i];
+            };
+            if (a == "--transform") tname = need("--transform");
+            else if (a == "--json") json = true;
+            else if (a == "--device") device = atoi(need("--device"));
+            else if (a == "--seconds") seconds = atof(need("--seconds"));
+            else throw std::invalid_argument("unexpected argument '" + a + "'");
+        }
+        Transform t = TransformType::from_str(tname);
+        vk_transform_spec sp = t.spec();
+        const uint32_t k = sp.kind;
+        if (k == VK_T_ELECTRUM || k == VK_T_MULTIBIT || k == VK_T_ARMORY)
+            throw std::invalid_argument(std::string("bench: '") + t.name() + "' has no transform-only sweep on the device (measure it with scan / generate)");
+        if ((k == VK_T_LCG || k == VK_T_XORSHIFT) && sp.variant == VK_VARIANT_ALL) sp.variant = 0; // one generator per sweep
+        vk_search_target tg;
+        memset(&tg, 0, sizeof tg);
+        if (k == VK_T_MT64 || k == VK_T_XORSHIFT) { // cascade-only generators: one draw against a 64-bit target (chance 2^-64 per seed)
+            tg.mode = VK_SEARCH_CASCADE;
+            tg.n_cascade = 1;
+            tg.bits[0] = 64;
+            tg.targets[0] = ~0ull;
+        } else {
+            tg.mode = VK_SEARCH_EXACT; // key = 0x55..55: not an output of any of these transforms over the swept seeds
+            memset(tg.key, 0x55, 32);
+        }
+        vk_engine *engine = nullptr;
+        vk_engine_opts opts{};
+        opts.window_bits = 8;
+        opts.batch = 1;
+        if (vk_engine_create_ex(device, &opts, &engine) != VK_OK) {
+            fprintf(stderr, "GPU engine unavailable: %s\n", vk_last_error(nullptr));
+            return 1;
+        }
+        struct Guard { vk_engine *e; ~Guard() { vk_engine_destroy(e); } } guard{engine};
+        if (!json) {
+            printf("Running Benchmark for %s...\n", t.name());
+            printf("Time: 1 warmup sweep + %.0fs measure (approx)\n", seconds);
+        }
+        const uint64_t chunk = (1ull << 30) - 1; // seeds lo .. lo + chunk, inside u32 for the 32-bit generators
+        vk_search_result r;
+        check_rc(engine, vk_search(engine, &sp, 0, (1ull << 24) - 1, &tg, &r));
+        uint64_t count = 0, lo = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        double dur = 0;
+        do {
+            check_rc(engine, vk_search(engine, &sp, lo, lo + chunk, &tg, &r));
+            if (r.found) throw std::runtime_error("bench: the sentinel key matched; pick another transform");
+            count += r.seeds_checked;
+            lo = (lo + chunk + 1) & 0x7FFFFFFFull; // stays below every generator's seed ceiling
+            dur = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        } while (dur < seconds);
+        const double speed = (double)count / dur;
+        if (json)
+            printf("{ \"name\": \"%s\", \"ops_per_sec\": %llu, \"total_ops\": %llu, \"duration_secs\": %f }\n", t.name(), (unsigned long long)speed,
+                   (unsigned long long)count, dur);
+        else
+            printf("------------------------------------------------\nResult: %.2f Million Inputs/sec\nTotal:  %llu inputs in %.2fs\n"
+                   "------------------------------------------------\n",
+                   speed / 1e6, (unsigned long long)count, dur);
+        return 0;
+    } catch (const EngineError &e) {
+        fprintf(stderr, "Error: GPU engine failure (%d): %s\n", e.code, e.what());
+        return 1;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 2;
+    }
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) return usage(nullptr);
     const std::string cmd = argv[1];
     if (cmd == "analyze") return run_analyze(argc, argv);
+    if (cmd == "bench") return run_bench(argc, argv);
     if (cmd != "generate" && cmd != "scan" && cmd != "single") return usage("unknown subcommand");
     std::vector<std::string> tnames;
     std::string targets, outpath, single_value;
