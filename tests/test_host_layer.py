@@ -210,3 +210,31 @@ def test_analyze_key_and_cascade_parsers(host):
     assert "at least 2 targets" in casc("5:0x15") and "empty input" in casc("  ")
     assert "exceeds 5-bit maximum" in casc("5:0x25,10:0x202") and "bits must be 1-64" in casc("0:1,5:0x15")
     assert "duplicate target" in casc("5:0x15,5:0x15") and "expected 'bits:target'" in casc("5-0x15,10:0x202")
+
+
+def test_fast_analyzers_run_without_a_device():
+    """`vuke analyze KEY --fast` = direct + heuristic (src/analyze/{direct,heuristic}.rs and their tests): key bytes only."""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "vuke_amd", "lib", "vuke-hip")
+    run = lambda *a: subprocess.run([exe, "analyze", *a], capture_output=True, text=True, timeout=60)
+    r = run("0x2a", "--fast")                                   # direct.rs test_small_number
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == ("Private Key: " + "0" * 62 + "2a\nBit Length:  6\nHamming Weight: 3\n---\nAnalysis:\n"
+                        "  ? direct: POSSIBLE (bit_length=6, fits in u64, BE padding detected (31 leading zero bytes))\n"
+                        "  ? heuristic: POSSIBLE (low entropy (0.20), unusual hamming weight (3))\n")
+    r = run(b"test".hex() + "00" * 28, "--fast", "--json")      # direct.rs test_ascii_string
+    d = json.loads(r.stdout)
+    assert d["private_key"] == b"test".hex() + "00" * 28 and d["bit_length"] == 255 and d["leading_zeros"] == 0
+    assert d["results"][0] == {"analyzer": "direct", "status": "possible", "details": 'LE padding detected (28 trailing zero bytes), ASCII string: "test"'}
+    r = run("ab" * 32, "--fast")                                 # one repeated byte is not a "pattern"; 0xab has 5 bits set
+    assert "  \u2717 direct: NOT_FOUND (no direct patterns detected)\n" in r.stdout
+    assert "  ? heuristic: POSSIBLE (low entropy (0.00), unusual hamming weight (160))\n" in r.stdout
+    r = run("0123456789abcdef" * 4, "--fast")                    # heuristic.rs: 8-byte repeating pattern
+    assert "repeating byte pattern" in r.stdout and "low entropy (3.00)" in r.stdout
+    r = run("c4bbcb1fbec99d65bf59d85c8cb62ee2db963f0fe106f483d9afa73bd4e39a8a", "--fast")
+    assert "direct: NOT_FOUND" in r.stdout and "? heuristic: UNKNOWN (entropy=" in r.stdout
+    r = run("0x15", "--fast", "--mask", "5")
+    assert r.stdout.count("UNKNOWN (masked analysis not supported)") == 2
+    r = run("0xff", "--fast", "--mask", "5")
+    assert "Warning: key has 8 bits but mask is 5 bits. Key will be treated as already masked." in r.stderr

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 
@@ -222,6 +223,77 @@ AnalysisResult Sha256ChainAnalyzer::analyze(const Key &key, const AnalysisConfig
     return {name(), AnalysisStatus::Confirmed, std::string(head) + ", chain_index=" + std::to_string(r.index)};
 }
 
+// ---------------------------------------------------------------- direct / heuristic (host only)
+uint16_t calculate_bit_length(const Key &key)
+{
+    for (int i = 0; i < 32; i++)
+        if (key[i]) return (uint16_t)(256 - 8 * i - __builtin_clz((unsigned)key[i]) + 24);
+    return 0;
+}
+
+AnalysisResult DirectAnalyzer::analyze(const Key &key, const AnalysisConfig &cfg) const
+{ // src/analyze/direct.rs:11-66
+    if (cfg.mask_bits) return {name(), AnalysisStatus::Unknown, "masked analysis not supported"};
+    std::vector<std::string> obs;
+    int lead = 0, trail = 0;
+    while (lead < 32 && key[lead] == 0) lead++;
+    while (trail < 32 && key[31 - trail] == 0) trail++;
+    const uint16_t bits = calculate_bit_length(key);
+    if (bits <= 64) obs.push_back("bit_length=" + std::to_string(bits) + ", fits in u64");
+    if (lead >= 24) obs.push_back("BE padding detected (" + std::to_string(lead) + " leading zero bytes)");
+    if (trail >= 24) obs.push_back("LE padding detected (" + std::to_string(trail) + " trailing zero bytes)");
+    size_t nn = 0; // is_ascii_string, :69-79
+    while (nn < 32 && key[nn] != 0) nn++;
+    bool ascii = nn >= 3 && nn <= 31;
+    for (size_t i = nn; i < 32 && ascii; i++) ascii = key[i] == 0;
+    for (size_t i = 0; i < nn && ascii; i++) ascii = key[i] >= 0x20 && key[i] <= 0x7e;
+    if (ascii) obs.push_back("ASCII string: \"" + std::string(key.begin(), key.begin() + (long)nn) + "\"");
+    if (obs.empty()) return {name(), AnalysisStatus::NotFound, "no direct patterns detected"};
+    std::string d;
+    for (auto &o : obs) d += (d.empty() ? "" : ", ") + o;
+    return {name(), AnalysisStatus::Possible, d};
+}
+
+AnalysisResult HeuristicAnalyzer::analyze(const Key &key, const AnalysisConfig &cfg) const
+{ // src/analyze/heuristic.rs:11-52
+    if (cfg.mask_bits) return {name(), AnalysisStatus::Unknown, "masked analysis not supported"};
+    uint32_t counts[256] = {0};
+    unsigned hamming = 0;
+    for (uint8_t b : key) {
+        counts[b]++;
+        hamming += (unsigned)__builtin_popcount(b);
+    }
+    double entropy = 0.0; // Shannon entropy of the byte histogram, :55-69
+    for (uint32_t c : counts)
+        if (c) {
+            const double p = c / 32.0;
+            entropy -= p * std::log2(p);
+        }
+    bool repeating = false; // :71-82
+    for (int len = 1; len <= 8 && !repeating; len++) {
+        if (32 % len) continue;
+        bool rep = true, same = true;
+        for (int i = 0; i < 32 && rep; i++) rep = key[i] == key[i % len];
+        for (int i = 1; i < len; i++) same = same && key[i] == key[0];
+        repeating = rep && !same;
+    }
+    char buf[64];
+    std::vector<std::string> obs;
+    if (entropy < 4.0) {
+        snprintf(buf, sizeof buf, "low entropy (%.2f)", entropy);
+        obs.push_back(buf);
+    }
+    if (hamming < 104 || hamming > 152) obs.push_back("unusual hamming weight (" + std::to_string(hamming) + ")");
+    if (repeating) obs.push_back("repeating byte pattern");
+    if (obs.empty()) {
+        snprintf(buf, sizeof buf, "entropy=%.2f, hamming=%u", entropy, hamming);
+        return {name(), AnalysisStatus::Unknown, buf};
+    }
+    std::string d;
+    for (auto &o : obs) d += (d.empty() ? "" : ", ") + o;
+    return {name(), AnalysisStatus::Possible, d};
+}
+
 // ---------------------------------------------------------------- key_parser.rs
 static bool valid_scalar(const Key &k)
 {
@@ -330,6 +402,39 @@ std::string format_results(const Key &key, const std::vector<AnalysisResult> &re
         out += std::string("  ") + r.symbol() + " " + r.analyzer + ": " + st + " " + (r.details.empty() ? "" : "(" + r.details + ")") + "\n";
     }
     return out;
+}
+
+std::string format_results_json(const Key &key, const std::vector<AnalysisResult> &results)
+{ // src/analyze/output.rs:27-78
+    int hw = 0;
+    for (uint8_t b : key) hw += __builtin_popcount(b);
+    const std::string hex = hex_encode(key.data(), 32);
+    size_t lz = 0;
+    while (lz < 64 && hex[lz] == '0') lz++; // KeyMetadata::leading_zeros: zero hex digits (src/analyze/mod.rs:266-281)
+    auto esc = [](const std::string &s) {
+        std::string r;
+        for (unsigned char c : s) {
+            if (c == '\\') r += "\\\\";
+            else if (c == '"') r += "\\\"";
+            else if (c == '\n') r += "\\n";
+            else if (c == '\r') r += "\\r";
+            else if (c == '\t') r += "\\t";
+            else if (c < 0x20 || c == 0x7f) {
+                char b[8];
+                snprintf(b, sizeof b, "\\u%04x", c);
+                r += b;
+            } else r += (char)c;
+        }
+        return r;
+    };
+    std::string rows;
+    for (size_t i = 0; i < results.size(); i++) {
+        const AnalysisResult &r = results[i];
+        rows += std::string("    {\"analyzer\": \"") + r.analyzer + "\", \"status\": \"" + r.status_str() + "\"" +
+                (!r.details.empty() ? ", \"details\": \"" + esc(r.details) + "\"" : "") + "}" + (i + 1 < results.size() ? ",\n" : "");
+    }
+    return "{\n  \"private_key\": \"" + hex + "\",\n  \"bit_length\": " + std::to_string(calculate_bit_length(key)) + ",\n  \"hamming_weight\": " +
+           std::to_string(hw) + ",\n  \"leading_zeros\": " + std::to_string(lz) + ",\n  \"results\": [\n" + rows + "\n  ]\n}";
 }
 
 } // namespace vuke

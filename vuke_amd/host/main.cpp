@@ -23,7 +23,7 @@ static int usage(const char *msg)
     fprintf(stderr, "Usage: vuke-hip <generate|scan> [OPTIONS] <SOURCE>\n"
                     "       vuke-hip single <PASSPHRASE> --transform <T>\n"
                     "       vuke-hip bench [--transform <T>] [--json]      transform-only inputs/s (the reference's `vuke bench`)\n"
-                    "       vuke-hip analyze <KEY> [--mask BITS] [--cascade b:t,b:t,...] [--analyzer milksad|lcg[:variant][:endian]|mt64|xorshift[:variant]|sha256_chain[:variant]]...\n"
+                    "       vuke-hip analyze <KEY> [--fast] [--json] [--mask BITS] [--cascade b:t,b:t,...] [--analyzer milksad|lcg[:variant][:endian]|mt64|xorshift[:variant]|sha256_chain[:variant]]...\n"
                     "  --transform <T>...   sha256 | double_sha256 | md5 | direct | armory | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] |\n"
                     "                       sha256_chain[:variant] | electrum[:change] | multibit\n"
                     "  sources: range --start A --end B | timestamps --start YYYY-MM-DD --end YYYY-MM-DD [--microseconds] |\n"
@@ -69,6 +69,7 @@ static int run_analyze(int argc, char **argv)
     int device = 0;
     uint64_t mt64_limit = (1ull << 40) - 1;
     uint32_t chain_depth = 10; // DEFAULT_CHAIN_DEPTH (src/sha256_chain.rs:82)
+    bool fast = false, json = false;
     try {
         for (int i = 2; i < argc; i++) {
             std::string a = argv[i];
@@ -81,6 +82,8 @@ static int run_analyze(int argc, char **argv)
                 if (m < 1 || m > 64) throw std::invalid_argument("--mask must be 1..64");
                 mask = (uint8_t)m;
             } else if (a == "--cascade") cascade_s = need("--cascade");
+            else if (a == "--fast") fast = true;
+            else if (a == "--json") json = true;
             else if (a == "--analyzer") names.push_back(need("--analyzer"));
             else if (a == "--device") device = atoi(need("--device"));
             else if (a == "--mt64-limit" || a == "--seed-limit") mt64_limit = parse_u64(need("--seed-limit")); // bound for the 64-bit seed spaces
@@ -89,23 +92,33 @@ static int run_analyze(int argc, char **argv)
             else throw std::invalid_argument("unexpected argument '" + a + "'");
         }
         if (key_s.empty()) throw std::invalid_argument("analyze needs a KEY (hex, WIF or decimal)");
-        if (names.empty()) names = {"milksad", "lcg"};
+        // AnalyzerType::fast() / all() (src/analyze/mod.rs:199-218, src/main.rs:1534-1535)
+        if (names.empty()) names = fast ? std::vector<std::string>{"direct", "heuristic"}
+                                        : std::vector<std::string>{"milksad", "mt64", "lcg", "xorshift", "sha256_chain", "direct", "heuristic"};
         Key key = parse_private_key(key_s);
+        if (mask && calculate_bit_length(key) > *mask) // src/main.rs:1495-1503
+            fprintf(stderr, "Warning: key has %u bits but mask is %u bits. Key will be treated as already masked.\n", calculate_bit_length(key), *mask);
         AnalysisConfig cfg;
         cfg.mask_bits = mask;
         if (!cascade_s.empty()) cfg.cascade_targets = parse_cascade(cascade_s);
         vk_engine *engine = nullptr;
-        vk_engine_opts opts{};
-        opts.window_bits = 8; // the analyzers never touch the k*G table or the inversion workspace: keep both tiny
-        opts.batch = 1;
-        if (vk_engine_create_ex(device, &opts, &engine) != VK_OK) {
-            fprintf(stderr, "GPU engine unavailable: %s\n", vk_last_error(nullptr));
-            return 1;
+        bool device_needed = false; // direct / heuristic look at the key bytes only: `analyze --fast` runs without a GPU
+        for (const std::string &n : names) device_needed = device_needed || (n != "direct" && n != "heuristic");
+        if (device_needed) {
+            vk_engine_opts opts{};
+            opts.window_bits = 8; // the analyzers never touch the k*G table or the inversion workspace: keep both tiny
+            opts.batch = 1;
+            if (vk_engine_create_ex(device, &opts, &engine) != VK_OK) {
+                fprintf(stderr, "GPU engine unavailable: %s\n", vk_last_error(nullptr));
+                return 1;
+            }
         }
         struct Guard { vk_engine *e; ~Guard() { vk_engine_destroy(e); } } guard{engine};
         std::vector<AnalysisResult> results;
         for (const std::string &n : names) {
-            if (n == "milksad") results.push_back(MilksadAnalyzer(engine).analyze(key, cfg));
+            if (n == "direct") results.push_back(DirectAnalyzer().analyze(key, cfg));
+            else if (n == "heuristic") results.push_back(HeuristicAnalyzer().analyze(key, cfg));
+            else if (n == "milksad") results.push_back(MilksadAnalyzer(engine).analyze(key, cfg));
             else if (n == "mt64") results.push_back(Mt64Analyzer(engine, mt64_limit).analyze(key, cfg));
             else if (n == "lcg" || n.rfind("lcg:", 0) == 0) {
                 Transform t = TransformType::from_str(n); // same grammar as the transform (src/lcg.rs:247-277)
@@ -116,9 +129,10 @@ static int run_analyze(int argc, char **argv)
             } else if (n == "sha256_chain" || n.rfind("sha256_chain:", 0) == 0) {
                 Transform t = TransformType::from_str(n); // Sha256ChainConfig::parse (src/sha256_chain.rs:187-217)
                 results.push_back(Sha256ChainAnalyzer(engine, t.spec().variant, chain_depth).analyze(key, cfg));
-            } else throw std::invalid_argument("analyzer '" + n + "' is not on the device path (built: milksad, lcg[:variant][:endian], mt64, xorshift[:variant], sha256_chain[:variant])");
+            } else throw std::invalid_argument("analyzer '" + n + "' is not built (built: milksad, lcg[:variant][:endian], mt64, xorshift[:variant], sha256_chain[:variant], direct, heuristic)");
         }
-        fputs(format_results(key, results).c_str(), stdout);
+        if (json) puts(format_results_json(key, results).c_str());
+        else fputs(format_results(key, results).c_str(), stdout);
         return 0;
     } catch (const EngineError &e) {
         fprintf(stderr, "Error: GPU engine failure (%d): %s\n", e.code, e.what());

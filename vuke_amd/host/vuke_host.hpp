@@ -293,6 +293,23 @@ private:
     vk_engine *engine_;
     uint32_t variant_, depth_;
 };
+// host-only analyzers of the reference's default set: cheap pattern checks on the key bytes, no search
+class DirectAnalyzer : public Analyzer { // src/analyze/direct.rs
+public:
+    const char *name() const override { return "direct"; }
+    bool is_brute_force() const override { return false; }
+    bool supports_gpu() const override { return false; }
+    AnalysisResult analyze(const Key &key, const AnalysisConfig &config) const override;
+};
+class HeuristicAnalyzer : public Analyzer { // src/analyze/heuristic.rs
+public:
+    const char *name() const override { return "heuristic"; }
+    bool is_brute_force() const override { return false; }
+    bool supports_gpu() const override { return false; }
+    AnalysisResult analyze(const Key &key, const AnalysisConfig &config) const override;
+};
+uint16_t calculate_bit_length(const Key &key);                                     // src/analyze/mod.rs:30-35
+std::string format_results_json(const Key &key, const std::vector<AnalysisResult> &results); // src/analyze/output.rs:27-60
 Key parse_private_key(const std::string &input);                              // src/analyze/key_parser.rs:32-48
 std::vector<std::pair<uint8_t, uint64_t>> parse_cascade(const std::string &input); // :131-166
 std::string format_results(const Key &key, const std::vector<AnalysisResult> &results); // src/analyze/output.rs:3-25
