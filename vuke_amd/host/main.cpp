@@ -37,7 +37,8 @@ static int usage(const char *msg)
                     "  --device <N>         GPU index (default 0)\n"
                     "  --devices <LIST|all> several GPUs: a range source is cut into one contiguous block per GPU\n"
                     "  --window-bits <W>    k*G table window width (default 24)\n"
-                    "  --layout <L>         uniform (default) | signed9 (120 GB table, 8 additions per key)\n");
+                    "  --layout <L>         auto (default: signed9 for range sources of 2^30 inputs or more, else uniform) |\n"
+                    "                       uniform (11.8 GB table, 10 additions per key) | signed9 (120 GB table, 8 additions per key)\n");
     return 2;
 }
 
@@ -240,6 +241,7 @@ int main(int argc, char **argv)
     uint64_t start = 0, end = 0;
     int device = 0;
     unsigned window_bits = 0, layout = VK_LAYOUT_UNIFORM;
+    bool layout_auto = true;
     try {
         for (int i = 2; i < argc; i++) {
             std::string a = argv[i];
@@ -257,7 +259,12 @@ int main(int argc, char **argv)
             else if (a == "--device") device = atoi(need("--device"));
             else if (a == "--devices") devices_s = need("--devices");
             else if (a == "--window-bits") window_bits = (unsigned)atoi(need("--window-bits"));
-            else if (a == "--layout") layout = std::string(need("--layout")) == "signed9" ? VK_LAYOUT_SIGNED9 : VK_LAYOUT_UNIFORM;
+            else if (a == "--layout") {
+                const std::string l = need("--layout");
+                if (l != "auto" && l != "uniform" && l != "signed9") throw std::invalid_argument("--layout takes auto, uniform or signed9");
+                layout_auto = l == "auto";
+                layout = l == "signed9" ? VK_LAYOUT_SIGNED9 : VK_LAYOUT_UNIFORM;
+            }
             else if (a == "range") have_range = true;
             else if (a == "wordlist") have_wordlist = true;
             else if (a == "stdin") { have_wordlist = true; wordlist_file = "-"; }
@@ -304,6 +311,8 @@ int main(int argc, char **argv)
         if (devs.empty()) devs.push_back(device);
         vk_engine_opts opts{};
         opts.window_bits = window_bits;
+        // a sweep long enough to repay building (0.35 s) and holding the 120 GB table takes the faster geometry on its own
+        if (layout_auto && window_bits == 0 && have_range && end - start >= (1ull << 30) - 1) layout = VK_LAYOUT_SIGNED9;
         opts.layout = layout;
         std::vector<vk_engine *> engines(devs.size(), nullptr);
         struct Guard { std::vector<vk_engine *> &v; ~Guard() { for (vk_engine *e : v) vk_engine_destroy(e); } } guard{engines};
