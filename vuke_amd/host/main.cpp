@@ -316,7 +316,7 @@ int main(int argc, char **argv)
         opts.layout = layout;
         std::vector<vk_engine *> engines(devs.size(), nullptr);
         struct Guard { std::vector<vk_engine *> &v; ~Guard() { for (vk_engine *e : v) vk_engine_destroy(e); } } guard{engines};
-        {
+        for (int attempt = 0;; attempt++) {
             std::vector<int> rcs(devs.size(), VK_OK);
             std::vector<std::string> msgs(devs.size());
             std::vector<std::thread> th; // the k*G tables are built side by side
@@ -326,11 +326,23 @@ int main(int argc, char **argv)
                     if (rcs[i] != VK_OK) msgs[i] = vk_last_error(nullptr); // the creation error is thread local
                 });
             for (auto &t : th) t.join();
+            size_t bad = devs.size();
             for (size_t i = 0; i < devs.size(); i++)
-                if (rcs[i] != VK_OK) {
-                    fprintf(stderr, "GPU engine unavailable (device %d): %s\n", devs[i], msgs[i].c_str());
-                    return 1;
+                if (rcs[i] != VK_OK && bad == devs.size()) bad = i;
+            if (bad == devs.size()) break;
+            // the automatic choice of the 120 GB table must not cost the run on a smaller or shared device
+            const bool no_device = rcs[bad] == VK_E_NO_DEVICE;
+            if (attempt == 0 && layout_auto && opts.layout == VK_LAYOUT_SIGNED9 && !no_device) {
+                for (vk_engine *&e : engines) {
+                    vk_engine_destroy(e);
+                    e = nullptr;
                 }
+                fprintf(stderr, "9-window table unavailable (%s); using the default 24-bit uniform table\n", msgs[bad].c_str());
+                opts.layout = VK_LAYOUT_UNIFORM;
+                continue;
+            }
+            fprintf(stderr, "GPU engine unavailable (device %d): %s\n", devs[bad], msgs[bad].c_str());
+            return 1;
         }
         vk_engine *engine = engines[0];
         for (const Transform &t : transforms)
