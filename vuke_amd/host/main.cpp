@@ -345,6 +345,11 @@ int main(int argc, char **argv)
             return 1;
         }
         vk_engine *engine = engines[0];
+        const bool timing = getenv("VUKE_HIP_TIMING") != nullptr; // stage times on stderr
+        const auto t_start = std::chrono::steady_clock::now();
+        auto stamp = [&](const char *what) {
+            if (timing) fprintf(stderr, "[timing] %s at %.3f s after engine creation\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+        };
         for (const Transform &t : transforms)
             if (t.spec().kind == VK_T_MULTIBIT) {
                 if (bip39_file.empty()) throw std::invalid_argument("multibit needs --bip39-wordlist <FILE> (the 2048-word BIP-39 English list)");
@@ -392,7 +397,9 @@ int main(int argc, char **argv)
             Matcher m = Matcher::load(targets);
             fprintf(stderr, "Loaded %zu targets.\n", m.count());
             fprintf(stderr, "Scanning...\n");
+            stamp("targets loaded");
             stats = source.process(transforms, &m, *out);
+            stamp("source processed");
         } else {
             fprintf(stderr, "Generating keys...\n");
             stats = source.process(transforms, nullptr, *out);
