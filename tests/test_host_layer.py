@@ -238,3 +238,19 @@ def test_fast_analyzers_run_without_a_device():
     assert r.stdout.count("UNKNOWN (masked analysis not supported)") == 2
     r = run("0xff", "--fast", "--mask", "5")
     assert "Warning: key has 8 bits but mask is 5 bits. Key will be treated as already masked." in r.stderr
+
+
+def test_timestamp_source_dates(host):
+    """TimestampSource::from_dates: start 00:00:00 .. end 23:59:59 UTC (src/source/timestamps.rs:21-43), checked against calendar.timegm."""
+    import calendar
+    host.vkh_timestamp_range.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lo, hi = C.c_uint64(), C.c_uint64()
+    for a, b in (("1970-01-01", "1970-01-01"), ("2009-01-03", "2009-01-09"), ("2011-01-01", "2013-12-31"), ("2000-02-29", "2000-03-01"),
+                 ("2024-02-29", "2024-02-29"), ("2038-01-19", "2038-01-20"), ("2100-02-28", "2100-03-01")):
+        assert host.vkh_timestamp_range(a.encode(), b.encode(), C.byref(lo), C.byref(hi)) == 0
+        ya, ma, da = map(int, a.split("-"))
+        yb, mb, db = map(int, b.split("-"))
+        assert (lo.value, hi.value) == (calendar.timegm((ya, ma, da, 0, 0, 0)), calendar.timegm((yb, mb, db, 23, 59, 59))), (a, b)
+    for bad in (("2011-02-29", "2011-03-01"), ("2100-02-29", "2100-03-01"), ("2011-13-01", "2011-12-01"), ("2011-1-1x", "2011-01-02"),
+                ("", "2011-01-02"), ("2011-01-02", "2011-01-01")):
+        assert host.vkh_timestamp_range(bad[0].encode(), bad[1].encode(), C.byref(lo), C.byref(hi)) == -1, bad

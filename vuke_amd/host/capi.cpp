@@ -111,6 +111,19 @@ int vkh_matcher_check(const char *path, const uint8_t key[32], const uint8_t hc[
 
 extern "C" {
 // parse_private_key (src/analyze/key_parser.rs:32-48): 0 on success
+// TimestampSource::from_dates (src/source/timestamps.rs:21-43): the inclusive second range of two dates; -1 on a bad date
+int vkh_timestamp_range(const char *start_date, const char *end_date, uint64_t *lo, uint64_t *hi)
+{
+    try {
+        HipTimestampSource s(nullptr, start_date, end_date, false);
+        *lo = s.start;
+        *hi = s.end;
+        return 0;
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
+
 int vkh_parse_key(const char *s, uint8_t out[32])
 {
     try {
