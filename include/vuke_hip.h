@@ -117,8 +117,10 @@ typedef struct vk_engine vk_engine;
 
 typedef struct vk_engine_opts {
     uint32_t window_bits;  /* fixed-base window width of the k*G table: 4..26 (0 = default 24: 11.8 GB) */
-    uint32_t batch;        /* keys per lane sharing one field inversion (0 = default) */
-    uint32_t blocks_per_cu;/* resident 256-thread workgroups per CU to launch (0 = default) */
+    uint32_t batch;        /* keys per lane sharing one field inversion (0 = default 128; the workspace, 128 B x batch x
+                              lanes, is allocated when the engine is created) */
+    uint32_t blocks_per_cu;/* 256-thread workgroups per CU to launch (0 = what the sweep kernel's occupancy allows);
+                              tiles are handed out dynamically, so the value only sizes the grid and the workspace */
     uint32_t layout;       /* VK_LAYOUT_*: 0 = uniform unsigned window_bits-wide windows (default) */
     void *stream;          /* hipStream_t to run on (NULL = engine creates its own) */
 } vk_engine_opts;
