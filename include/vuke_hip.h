@@ -170,6 +170,12 @@ int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint
 int vk_derive_batch(vk_engine *e, const uint8_t *keys /* n*32 */, size_t n, uint8_t *normalised /* n*32 */,
                     uint8_t *h160_c /* n*20 */, uint8_t *h160_u /* n*20 */);
 
+/* The same with the public key itself: pub_xy = n*64 bytes, affine X || Y big-endian (SEC1 compressed = 02|03 || X by the
+ * parity of Y, uncompressed = 04 || X || Y: DerivedKey::pubkey_compressed / pubkey_uncompressed, src/derive.rs:98-99).
+ * Any output pointer may be NULL. */
+int vk_derive_batch_pub(vk_engine *e, const uint8_t *keys /* n*32 */, size_t n, uint8_t *normalised, uint8_t *h160_c, uint8_t *h160_u,
+                        uint8_t *pub_xy /* n*64 */);
+
 /* Transform::apply_batch for numeric inputs: keys_out = n*slots*32, valid = n*slots. */
 int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, const uint64_t *seeds, size_t n,
                        uint8_t *keys_out, uint8_t *valid);

@@ -60,7 +60,7 @@ SEARCH_EXACT, SEARCH_MASKED, SEARCH_CASCADE = 0, 1, 2
 
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
-    "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_transform_batch",
+    "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
     "vk_transform_strings", "vk_scan_keys", "vk_bip39_wordlist_set", "vk_search",
     "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field",
 ]
@@ -90,6 +90,7 @@ def load():
     L.vk_sweep.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_generate.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, vp, vp, vp, vp, C.POINTER(SweepStats)]
     L.vk_derive_batch.argtypes = [vp, cp, sz, vp, vp, vp]
+    L.vk_derive_batch_pub.argtypes = [vp, cp, sz, vp, vp, vp, vp]
     L.vk_transform_batch.argtypes = [vp, C.POINTER(TransformSpec), C.POINTER(u64), sz, vp, vp]
     L.vk_transform_strings.argtypes = [vp, C.POINTER(TransformSpec), cp, C.POINTER(u32), sz, vp, vp]
     L.vk_bip39_wordlist_set.argtypes = [vp, cp]
@@ -175,6 +176,19 @@ class Engine:
         rn, rc, ru = norm.raw, hc.raw, hu.raw  # .raw copies the whole buffer: take it once
         return ([rn[32 * i:32 * i + 32] for i in range(n)], [rc[20 * i:20 * i + 20] for i in range(n)],
                 [ru[20 * i:20 * i + 20] for i in range(n)])
+
+    def derive_pubkeys(self, keys):
+        """KeyDeriver::derive with the public keys: per key (normalised, pub33, pub65, h160_c, h160_u)."""
+        n = len(keys)
+        norm, hc, hu, xy = (C.create_string_buffer(n * 32), C.create_string_buffer(n * 20), C.create_string_buffer(n * 20),
+                            C.create_string_buffer(n * 64))
+        self._chk(self._L.vk_derive_batch_pub(self._e, b"".join(keys), n, norm, hc, hu, xy))
+        rn, rc, ru, rx = norm.raw, hc.raw, hu.raw, xy.raw
+        out = []
+        for i in range(n):
+            x, y = rx[64 * i:64 * i + 32], rx[64 * i + 32:64 * i + 64]
+            out.append((rn[32 * i:32 * i + 32], bytes([2 | (y[31] & 1)]) + x, b"\x04" + x + y, rc[20 * i:20 * i + 20], ru[20 * i:20 * i + 20]))
+        return out
 
     def transform_batch(self, spec, seeds):
         n = len(seeds)

@@ -351,6 +351,7 @@ struct launch_io {
     u32 *out_h160c = nullptr;
     u32 *out_h160u = nullptr;
     unsigned char *out_valid = nullptr;
+    u32 *out_pub = nullptr;
 };
 
 
@@ -415,6 +416,7 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     p.out_h160c = io.out_h160c;
     p.out_h160u = io.out_h160u;
     p.out_valid = io.out_valid;
+    p.out_pub = io.out_pub;
 
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
     if (!(vk_launch_sweep_g0(kind, p, grid, e->stream) || vk_launch_sweep_g1(kind, p, grid, e->stream) ||
@@ -564,7 +566,8 @@ extern "C" int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t lo
     return VK_OK;
 }
 
-extern "C" int vk_derive_batch(vk_engine *e, const uint8_t *keys, size_t n, uint8_t *normalised, uint8_t *h160_c, uint8_t *h160_u)
+extern "C" int vk_derive_batch_pub(vk_engine *e, const uint8_t *keys, size_t n, uint8_t *normalised, uint8_t *h160_c, uint8_t *h160_u,
+                                   uint8_t *pub_xy)
 {
     if (!e) return VK_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
@@ -572,13 +575,15 @@ extern "C" int vk_derive_batch(vk_engine *e, const uint8_t *keys, size_t n, uint
     if (!keys) return fail(e, VK_E_INVALID_ARG, "keys is NULL");
     HIPCHK(e, hipSetDevice(e->device));
     const size_t chunk = 1u << 22;
-    u32 *d_in = nullptr, *d_priv = nullptr, *d_hc = nullptr, *d_hu = nullptr;
+    u32 *d_in = nullptr, *d_priv = nullptr, *d_hc = nullptr, *d_hu = nullptr, *d_pub = nullptr;
     const size_t cn = std::min(n, chunk);
     HIPCHK(e, hipMalloc(&d_in, cn * 32));
     HIPCHK(e, hipMalloc(&d_priv, cn * 32));
     HIPCHK(e, hipMalloc(&d_hc, cn * 20));
     HIPCHK(e, hipMalloc(&d_hu, cn * 20));
+    if (pub_xy) HIPCHK(e, hipMalloc(&d_pub, cn * 64));
     auto cleanup = [&]() {
+        (void)hipFree(d_pub);
         (void)hipFree(d_in);
         (void)hipFree(d_priv);
         (void)hipFree(d_hc);
@@ -598,6 +603,7 @@ extern "C" int vk_derive_batch(vk_engine *e, const uint8_t *keys, size_t n, uint
         io.out_priv = d_priv;
         io.out_h160c = d_hc;
         io.out_h160u = d_hu;
+        io.out_pub = d_pub;
         vk_sweep_stats st;
         memset(&st, 0, sizeof st);
         int rc = run_range(e, spec, VK_T_RAWKEYS, 1, 0, m - 1, flags, io, &st);
@@ -608,6 +614,7 @@ extern "C" int vk_derive_batch(vk_engine *e, const uint8_t *keys, size_t n, uint
         if (normalised && c == hipSuccess) c = hipMemcpy(normalised + done * 32, d_priv, m * 32, hipMemcpyDeviceToHost);
         if (h160_c && c == hipSuccess) c = hipMemcpy(h160_c + done * 20, d_hc, m * 20, hipMemcpyDeviceToHost);
         if (h160_u && c == hipSuccess) c = hipMemcpy(h160_u + done * 20, d_hu, m * 20, hipMemcpyDeviceToHost);
+        if (pub_xy && c == hipSuccess) c = hipMemcpy(pub_xy + done * 64, d_pub, m * 64, hipMemcpyDeviceToHost);
         if (c != hipSuccess) {
             cleanup();
             return fail(e, VK_E_HIP, "hipMemcpy D2H failed in vk_derive_batch");
@@ -615,6 +622,11 @@ extern "C" int vk_derive_batch(vk_engine *e, const uint8_t *keys, size_t n, uint
     }
     cleanup();
     return VK_OK;
+}
+
+extern "C" int vk_derive_batch(vk_engine *e, const uint8_t *keys, size_t n, uint8_t *normalised, uint8_t *h160_c, uint8_t *h160_u)
+{
+    return vk_derive_batch_pub(e, keys, n, normalised, h160_c, h160_u, nullptr);
 }
 
 template <u32 KIND>

@@ -60,6 +60,7 @@ struct vk_sweep_params {
     u32 *out_h160c;    // n_items x 5 words
     u32 *out_h160u;
     unsigned char *out_valid;
+    u32 *out_pub;      // n_items x 16 words: affine X || Y, big-endian bytes (vk_derive_batch_pub)
     vk_win_desc wins[VK_MAX_WIN];
 };
 
@@ -271,6 +272,13 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
                     if (p.out_h160u && (p.flags & VK_F_UNCOMPRESSED)) {
 #pragma unroll
                         for (int i = 0; i < 5; i++) p.out_h160u[item * 5 + i] = hu[i];
+                    }
+                    if (p.out_pub) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            p.out_pub[item * 16 + i] = bswap32(FE_BE(x, i));
+                            p.out_pub[item * 16 + 8 + i] = bswap32(FE_BE(y, i));
+                        }
                     }
                 }
             }

@@ -82,11 +82,16 @@ std::vector<DerivedKey> KeyDeriver::derive(const std::vector<Key> &keys) const
     std::vector<DerivedKey> out;
     if (keys.empty()) return out;
     const size_t n = keys.size();
-    std::vector<uint8_t> in(n * 32), norm(n * 32), hc(n * 20), hu(n * 20);
+    std::vector<uint8_t> in(n * 32), norm(n * 32), hc(n * 20), hu(n * 20), xy(n * 64);
     for (size_t i = 0; i < n; i++) memcpy(&in[32 * i], keys[i].data(), 32);
-    check_rc(engine_, vk_derive_batch(engine_, in.data(), n, norm.data(), hc.data(), hu.data()));
+    check_rc(engine_, vk_derive_batch_pub(engine_, in.data(), n, norm.data(), hc.data(), hu.data(), xy.data()));
     out.resize(n);
-    for (size_t i = 0; i < n; i++) out[i] = from_device(&norm[32 * i], &hc[20 * i], &hu[20 * i], net_);
+    for (size_t i = 0; i < n; i++) {
+        out[i] = from_device(&norm[32 * i], &hc[20 * i], &hu[20 * i], net_);
+        const uint8_t *x = &xy[64 * i], *y = x + 32; // src/derive.rs:98-99,150-151: serialize() / serialize_uncompressed() as hex
+        out[i].pubkey_compressed = ((y[31] & 1) ? "03" : "02") + hex_encode(x, 32);
+        out[i].pubkey_uncompressed = "04" + hex_encode(x, 64);
+    }
     return out;
 }
 

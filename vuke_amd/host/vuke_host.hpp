@@ -41,7 +41,7 @@ struct DerivedKey { // src/derive.rs:12-41
     std::string private_key_hex, private_key_decimal, private_key_binary;
     uint16_t bit_length = 0, hamming_weight = 0;
     uint8_t leading_zeros = 0;
-    std::string pubkey_compressed, pubkey_uncompressed; // not produced by the device path (unused by console output)
+    std::string pubkey_compressed, pubkey_uncompressed; // hex SEC1; filled by KeyDeriver::derive (vk_derive_batch_pub), empty in the bulk generate path
     std::string wif_compressed, wif_uncompressed;
     std::string p2pkh_compressed, p2pkh_uncompressed, p2wpkh;
     uint8_t h160_c[20]{}, h160_u[20]{};
