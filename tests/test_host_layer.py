@@ -254,3 +254,54 @@ def test_timestamp_source_dates(host):
     for bad in (("2011-02-29", "2011-03-01"), ("2100-02-29", "2100-03-01"), ("2011-13-01", "2011-12-01"), ("2011-1-1x", "2011-01-02"),
                 ("", "2011-01-02"), ("2011-01-02", "2011-01-01")):
         assert host.vkh_timestamp_range(bad[0].encode(), bad[1].encode(), C.byref(lo), C.byref(hi)) == -1, bad
+
+
+def test_storage_output_writes_the_19_column_parquet_record(host, vko, tmp_path):
+    """StorageOutput: files readable by pyarrow, schema = src/storage/schema.rs:78-111 field for field,
+    values = the oracle's DerivedKey, partition layout and rotation = src/storage/parquet_backend.rs:86-131."""
+    import datetime
+    import glob
+    pa = pytest.importorskip("pyarrow")
+    pq = pytest.importorskip("pyarrow.parquet")
+    rnd = random.Random(33)
+    n = 2500
+    keys = [bytes(31) + b"\x01", bytes.fromhex("c4bbcb1fbec99d65bf59d85c8cb62ee2db963f0fe106f483d9afa73bd4e39a8a")] + [rnd.getrandbits(rnd.choice([8, 64, 200, 256])).to_bytes(32, "big") for _ in range(n - 2)]
+    ds = [vko.derive(k) for k in keys]
+    raw = b"".join(bytes(d.raw) for d in ds)
+    hc, hu = b"".join(bytes(d.h160_c) for d in ds), b"".join(bytes(d.h160_u) for d in ds)
+    xy = b"".join(bytes(d.pub65)[1:] for d in ds)
+    sources = [f"src{i}[x:{i % 7}]".encode() for i in range(n)]
+    matched = [ds[i].p2pkh_compressed if i % 500 == 3 else b"" for i in range(n)]
+    host.vkh_storage_write.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                       C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+    nfiles = host.vkh_storage_write(str(tmp_path).encode(), b"sha256_chain:iterated", 1000, n, raw, hc, hu, xy, (C.c_char_p * n)(*sources), (C.c_char_p * n)(*matched))
+    assert nfiles == 3                                           # 1000 + 1000 + 500 records
+    today = datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d")
+    files = sorted(glob.glob(str(tmp_path / "transform=sha256_chain:iterated" / f"date={today}" / "chunk_*.parquet")))
+    assert [os.path.basename(f) for f in files] == ["chunk_0001.parquet", "chunk_0002.parquet", "chunk_0003.parquet"]
+    tables = [pq.read_table(f) for f in files]
+    assert [t.num_rows for t in tables] == [1000, 1000, 500]
+    t = pa.concat_tables(tables)
+    utf8 = lambda name, nullable: pa.field(name, pa.string(), nullable=nullable)
+    want_schema = pa.schema([
+        utf8("source", False), utf8("transform", False), utf8("chain", False), pa.field("timestamp", pa.timestamp("ms", tz="UTC"), nullable=False),
+        utf8("matched_target", True), pa.field("private_key_raw", pa.binary(32), nullable=False), utf8("private_key_hex", False),
+        utf8("private_key_decimal", False), utf8("private_key_binary", False), pa.field("private_key_bit_length", pa.uint16(), nullable=False),
+        pa.field("private_key_hamming_weight", pa.uint16(), nullable=False), pa.field("private_key_leading_zeros", pa.uint8(), nullable=False),
+        utf8("pubkey_compressed", True), utf8("pubkey_uncompressed", True), utf8("address_p2pkh_compressed", True),
+        utf8("address_p2pkh_uncompressed", True), utf8("address_p2wpkh", True), utf8("wif_compressed", True), utf8("wif_uncompressed", True)])
+    assert t.schema.equals(want_schema), t.schema
+    col = lambda name: t.column(name).to_pylist()
+    assert col("source") == [s.decode() for s in sources] and set(col("transform")) == {"sha256_chain:iterated"} and set(col("chain")) == {"bitcoin"}
+    assert col("matched_target") == [m.decode() if m else None for m in matched]
+    assert col("private_key_raw") == [bytes(d.raw) for d in ds]
+    for name, get in (("private_key_hex", lambda d: d.private_key_hex), ("private_key_decimal", lambda d: d.private_key_decimal),
+                      ("private_key_binary", lambda d: d.private_key_binary), ("address_p2pkh_compressed", lambda d: d.p2pkh_compressed),
+                      ("address_p2pkh_uncompressed", lambda d: d.p2pkh_uncompressed), ("address_p2wpkh", lambda d: d.p2wpkh),
+                      ("wif_compressed", lambda d: d.wif_compressed), ("wif_uncompressed", lambda d: d.wif_uncompressed)):
+        assert col(name) == [get(d).decode() for d in ds], name
+    assert col("pubkey_compressed") == [bytes(d.pub33).hex() for d in ds] and col("pubkey_uncompressed") == [bytes(d.pub65).hex() for d in ds]
+    assert col("private_key_bit_length") == [d.bit_length for d in ds] and col("private_key_hamming_weight") == [d.hamming_weight for d in ds]
+    assert col("private_key_leading_zeros") == [d.leading_zeros for d in ds]
+    now = datetime.datetime.now(datetime.timezone.utc)
+    assert all(abs((now - ts).total_seconds()) < 600 for ts in col("timestamp")[::250])

@@ -77,6 +77,12 @@ DerivedKey KeyDeriver::from_device_compact(const uint8_t k[32], const uint8_t hc
     return d;
 }
 
+void KeyDeriver::set_pubkeys(DerivedKey &d, const uint8_t xy[64])
+{ // src/derive.rs:98-99,150-151: serialize() / serialize_uncompressed() as hex
+    d.pubkey_compressed = ((xy[63] & 1) ? "03" : "02") + hex_encode(xy, 32);
+    d.pubkey_uncompressed = "04" + hex_encode(xy, 64);
+}
+
 std::vector<DerivedKey> KeyDeriver::derive(const std::vector<Key> &keys) const
 {
     std::vector<DerivedKey> out;
@@ -88,9 +94,7 @@ std::vector<DerivedKey> KeyDeriver::derive(const std::vector<Key> &keys) const
     out.resize(n);
     for (size_t i = 0; i < n; i++) {
         out[i] = from_device(&norm[32 * i], &hc[20 * i], &hu[20 * i], net_);
-        const uint8_t *x = &xy[64 * i], *y = x + 32; // src/derive.rs:98-99,150-151: serialize() / serialize_uncompressed() as hex
-        out[i].pubkey_compressed = ((y[31] & 1) ? "03" : "02") + hex_encode(x, 32);
-        out[i].pubkey_uncompressed = "04" + hex_encode(x, 64);
+        set_pubkeys(out[i], &xy[64 * i]);
     }
     return out;
 }

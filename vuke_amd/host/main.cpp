@@ -13,6 +13,7 @@
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
+#include <sys/stat.h>
 #include <thread>
 
 using namespace vuke;
@@ -31,6 +32,8 @@ static int usage(const char *msg)
                     "  --targets <FILE>     (scan) one address per line\n"
                     "  -v, --verbose        (generate) all key formats\n"
                     "  -o, --output <FILE>  write to FILE instead of stdout\n"
+                    "  --storage <DIR>      also write the 19-column Parquet record (DIR/transform=T/date=D/chunk_NNNN.parquet,\n"
+                    "                       uncompressed pages); --chunk-records <N> per file (default 1000000)\n"
                     "  --network <N>        bitcoin | testnet | signet | regtest: used by `single`; parsed and ignored by generate / scan\n"
                     "                       exactly like the reference (src/main.rs:464,499)\n"
                     "  --bip39-wordlist <F> 2048-word BIP-39 list (required by --transform multibit)\n"
@@ -237,7 +240,8 @@ int main(int argc, char **argv)
     std::vector<std::string> tnames;
     std::string targets, outpath, single_value;
     bool verbose = false, have_range = false, have_start = false, have_end = false, have_wordlist = false, have_timestamps = false, microseconds = false;
-    std::string wordlist_file, bip39_file, start_s, end_s, network = "bitcoin", devices_s;
+    std::string wordlist_file, bip39_file, start_s, end_s, network = "bitcoin", devices_s, storage_dir;
+    uint64_t chunk_records = 1000000; // DEFAULT_CHUNK_RECORDS, src/storage/parquet_backend.rs:13
     uint64_t start = 0, end = 0;
     int device = 0;
     unsigned window_bits = 0, layout = VK_LAYOUT_UNIFORM;
@@ -258,6 +262,12 @@ int main(int argc, char **argv)
             else if (a == "--network") network = need("--network");
             else if (a == "--device") device = atoi(need("--device"));
             else if (a == "--devices") devices_s = need("--devices");
+            else if (a == "--storage") storage_dir = need("--storage");
+            else if (a == "--chunk-records") chunk_records = parse_u64(need("--chunk-records"));
+            else if (a == "--compression") {
+                const std::string c = need("--compression");
+                if (c != "none") throw std::invalid_argument("--compression: this build writes uncompressed Parquet pages only (use 'none')");
+            }
             else if (a == "--window-bits") window_bits = (unsigned)atoi(need("--window-bits"));
             else if (a == "--layout") {
                 const std::string l = need("--layout");
@@ -385,6 +395,15 @@ int main(int argc, char **argv)
         if (!outpath.empty()) out = ConsoleOutput::to_file(outpath, verbose);
         else if (verbose) out = ConsoleOutput::verbose();
         else out = std::make_unique<ConsoleOutput>();
+        // --storage DIR: the same records also go to Parquet chunks (MultiOutput, src/main.rs:666-672)
+        std::unique_ptr<StorageOutput> storage;
+        std::unique_ptr<MultiOutput> multi;
+        Output *sink = out.get();
+        if (!storage_dir.empty()) {
+            storage = std::make_unique<StorageOutput>(storage_dir, transforms[0].name(), chunk_records);
+            multi = std::make_unique<MultiOutput>(std::vector<Output *>{out.get(), storage.get()});
+            sink = multi.get();
+        }
         std::unique_ptr<Source> source_ptr;
         if (have_wordlist) source_ptr = std::make_unique<HipWordlistSource>(engine, wordlist_file);
         else if (have_timestamps) source_ptr = std::make_unique<HipTimestampSource>(engine, start_s, end_s, microseconds);
@@ -398,15 +417,37 @@ int main(int argc, char **argv)
             fprintf(stderr, "Loaded %zu targets.\n", m.count());
             fprintf(stderr, "Scanning...\n");
             stamp("targets loaded");
-            stats = source.process(transforms, &m, *out);
+            stats = source.process(transforms, &m, *sink);
             stamp("source processed");
         } else {
             fprintf(stderr, "Generating keys...\n");
-            stats = source.process(transforms, nullptr, *out);
+            stats = source.process(transforms, nullptr, *sink);
         }
-        out->flush();
+        sink->flush();
         fprintf(stderr, "Done. Inputs: %llu, Keys: %llu, Matches: %llu\n", (unsigned long long)stats.inputs_processed,
                 (unsigned long long)stats.keys_generated, (unsigned long long)stats.matches_found);
+        if (storage) { // print_storage_summary_inline, src/main.rs:995-1018
+            const std::vector<std::string> paths = storage->finish();
+            auto fmt = [](uint64_t b) {
+                char buf[32];
+                if (b >= (1ull << 30)) snprintf(buf, sizeof buf, "%.1f GB", b / 1073741824.0);
+                else if (b >= (1ull << 20)) snprintf(buf, sizeof buf, "%.1f MB", b / 1048576.0);
+                else if (b >= 1024) snprintf(buf, sizeof buf, "%.1f KB", b / 1024.0);
+                else snprintf(buf, sizeof buf, "%llu B", (unsigned long long)b);
+                return std::string(buf);
+            };
+            std::vector<uint64_t> sizes;
+            uint64_t total = 0;
+            for (auto &pth : paths) {
+                struct stat sb;
+                sizes.push_back(stat(pth.c_str(), &sb) == 0 ? (uint64_t)sb.st_size : 0);
+                total += sizes.back();
+            }
+            if (!paths.empty()) {
+                fprintf(stderr, "\nStorage: %zu files written (%s total)\n", paths.size(), fmt(total).c_str());
+                for (size_t i = 0; i < paths.size(); i++) fprintf(stderr, "  %s (%s)\n", paths[i].c_str(), fmt(sizes[i]).c_str());
+            }
+        }
         return 0;
     } catch (const EngineError &e) {
         fprintf(stderr, "Error: GPU engine failure (%d): %s\n", e.code, e.what());

@@ -1,0 +1,386 @@
+// parquet.cpp -- the reference's 19-column result record as Parquet files: StorageOutput + a minimal
+// Parquet writer (PLAIN encoding, uncompressed, one data page per column per row group, Thrift compact metadata).
+//
+// Schema and column semantics: src/storage/schema.rs:78-111 (result_schema) and :137-262 (records_to_batch);
+// partition layout `DIR/transform=<first transform>/date=<UTC date>/chunk_NNNN.parquet` and record-count rotation:
+// src/storage/parquet_backend.rs:86-140; console + storage fan-out: src/main.rs:666-672 (MultiOutput).
+// The reference compresses with ZSTD by default; this writer stores pages uncompressed (`--compression none`), which
+// every Parquet reader accepts.  Cloud upload, Iceberg and the DuckDB query layer are out of scope.
+#include "vuke_host.hpp"
+
+#include <chrono>
+#include <cstring>
+#include <ctime>
+#include <stdexcept>
+#include <sys/stat.h>
+
+namespace vuke {
+
+namespace {
+
+// ---- Thrift compact protocol (just what parquet.thrift's metadata needs)
+class Thrift {
+public:
+    std::string out;
+    void begin() { stack_.push_back(last_); last_ = 0; }
+    void end()
+    {
+        out.push_back(0);
+        last_ = stack_.back();
+        stack_.pop_back();
+    }
+    void field(int id, int type)
+    {
+        const int delta = id - last_;
+        if (delta > 0 && delta <= 15) out.push_back((char)((delta << 4) | type));
+        else {
+            out.push_back((char)type);
+            varint(zigzag((int64_t)id));
+        }
+        last_ = id;
+    }
+    void i32(int id, int32_t v) { field(id, 5); varint(zigzag(v)); }
+    void i64(int id, int64_t v) { field(id, 6); varint(zigzag(v)); }
+    void i8(int id, int8_t v) { field(id, 3); out.push_back((char)v); }
+    void boolean(int id, bool v) { field(id, v ? 1 : 2); }
+    void str(int id, const std::string &s) { field(id, 8); binary(s); }
+    void binary(const std::string &s) { varint(s.size()); out += s; }
+    void list(int id, int elem_type, size_t n)
+    {
+        field(id, 9);
+        if (n < 15) out.push_back((char)((n << 4) | (unsigned)elem_type));
+        else {
+            out.push_back((char)(0xF0 | elem_type));
+            varint(n);
+        }
+    }
+    void struct_field(int id) { field(id, 12); begin(); }
+    void raw_i32(int32_t v) { varint(zigzag(v)); } // list element
+    void varint(uint64_t v)
+    {
+        while (v >= 0x80) {
+            out.push_back((char)(v | 0x80));
+            v >>= 7;
+        }
+        out.push_back((char)v);
+    }
+
+private:
+    static uint64_t zigzag(int64_t v) { return ((uint64_t)v << 1) ^ (uint64_t)(v >> 63); }
+    int last_ = 0;
+    std::vector<int> stack_;
+};
+
+enum PType { P_INT32 = 1, P_INT64 = 2, P_BYTE_ARRAY = 6, P_FIXED = 7 };
+enum Logical { L_STRING, L_TS_MILLIS_UTC, L_UINT16, L_UINT8, L_NONE };
+struct ColumnDef {
+    const char *name;
+    PType type;
+    bool optional;
+    Logical logical;
+};
+// src/storage/schema.rs:78-111, in order
+const ColumnDef COLS[19] = {
+    {"source", P_BYTE_ARRAY, false, L_STRING},
+    {"transform", P_BYTE_ARRAY, false, L_STRING},
+    {"chain", P_BYTE_ARRAY, false, L_STRING},
+    {"timestamp", P_INT64, false, L_TS_MILLIS_UTC},
+    {"matched_target", P_BYTE_ARRAY, true, L_STRING},
+    {"private_key_raw", P_FIXED, false, L_NONE},
+    {"private_key_hex", P_BYTE_ARRAY, false, L_STRING},
+    {"private_key_decimal", P_BYTE_ARRAY, false, L_STRING},
+    {"private_key_binary", P_BYTE_ARRAY, false, L_STRING},
+    {"private_key_bit_length", P_INT32, false, L_UINT16},
+    {"private_key_hamming_weight", P_INT32, false, L_UINT16},
+    {"private_key_leading_zeros", P_INT32, false, L_UINT8},
+    {"pubkey_compressed", P_BYTE_ARRAY, true, L_STRING},
+    {"pubkey_uncompressed", P_BYTE_ARRAY, true, L_STRING},
+    {"address_p2pkh_compressed", P_BYTE_ARRAY, true, L_STRING},
+    {"address_p2pkh_uncompressed", P_BYTE_ARRAY, true, L_STRING},
+    {"address_p2wpkh", P_BYTE_ARRAY, true, L_STRING},
+    {"wif_compressed", P_BYTE_ARRAY, true, L_STRING},
+    {"wif_uncompressed", P_BYTE_ARRAY, true, L_STRING},
+};
+
+void put_le32(std::string &s, uint32_t v)
+{
+    for (int i = 0; i < 4; i++) s.push_back((char)(v >> (8 * i)));
+}
+void put_le64(std::string &s, uint64_t v)
+{
+    for (int i = 0; i < 8; i++) s.push_back((char)(v >> (8 * i)));
+}
+
+// one column of one row group while it is being filled
+struct ColumnBuf {
+    std::string values;        // PLAIN-encoded non-null values
+    std::vector<uint8_t> defs; // definition level per row (optional columns)
+    void str(const std::string &v)
+    {
+        put_le32(values, (uint32_t)v.size());
+        values += v;
+    }
+    void opt_str(const std::string *v)
+    {
+        defs.push_back(v ? 1 : 0);
+        if (v) str(*v);
+    }
+};
+
+std::string rle_levels(const std::vector<uint8_t> &defs)
+{ // RLE / bit-packed hybrid, bit width 1, RLE runs only
+    Thrift t;
+    size_t i = 0;
+    while (i < defs.size()) {
+        size_t j = i;
+        while (j < defs.size() && defs[j] == defs[i]) j++;
+        t.varint((uint64_t)(j - i) << 1);
+        t.out.push_back((char)defs[i]);
+        i = j;
+    }
+    return t.out;
+}
+
+struct ChunkMeta {
+    int64_t data_page_offset, size, num_values;
+};
+struct RowGroupMeta {
+    std::vector<ChunkMeta> cols;
+    int64_t rows, bytes;
+};
+
+} // namespace
+
+struct StorageOutput::Impl {
+    std::string base_dir, transform, date;
+    uint64_t max_chunk_records;
+    uint32_t chunk_index = 0;
+    FILE *fp = nullptr;
+    std::string path;
+    uint64_t file_pos = 0, chunk_records = 0, total_records = 0;
+    std::vector<RowGroupMeta> groups;
+    ColumnBuf cols[19];
+    uint64_t group_rows = 0;
+    std::vector<std::string> completed;
+    std::mutex mu;
+
+    static void mkdirs(const std::string &p)
+    {
+        for (size_t i = 1; i <= p.size(); i++)
+            if (i == p.size() || p[i] == '/') {
+                const std::string d = p.substr(0, i);
+                if (mkdir(d.c_str(), 0777) != 0 && errno != EEXIST) throw std::runtime_error("cannot create directory " + d);
+            }
+    }
+    void open_chunk()
+    { // generate_chunk_path, src/storage/parquet_backend.rs:86-108
+        if (date.empty()) {
+            const time_t now = time(nullptr);
+            struct tm tmv;
+            gmtime_r(&now, &tmv);
+            char b[16];
+            strftime(b, sizeof b, "%Y-%m-%d", &tmv);
+            date = b;
+        }
+        const std::string dir = base_dir + "/transform=" + transform + "/date=" + date;
+        mkdirs(dir);
+        char name[32];
+        snprintf(name, sizeof name, "/chunk_%04u.parquet", ++chunk_index);
+        path = dir + name;
+        fp = fopen(path.c_str(), "wb");
+        if (!fp) throw std::runtime_error("cannot create " + path);
+        fwrite("PAR1", 1, 4, fp);
+        file_pos = 4;
+        chunk_records = 0;
+        groups.clear();
+    }
+    void write(const std::string &s)
+    {
+        if (fwrite(s.data(), 1, s.size(), fp) != s.size()) throw std::runtime_error("write failed: " + path);
+        file_pos += s.size();
+    }
+    void flush_group()
+    {
+        if (group_rows == 0) return;
+        RowGroupMeta g;
+        g.rows = (int64_t)group_rows;
+        g.bytes = 0;
+        for (int c = 0; c < 19; c++) {
+            std::string body;
+            if (COLS[c].optional) {
+                const std::string lv = rle_levels(cols[c].defs);
+                put_le32(body, (uint32_t)lv.size());
+                body += lv;
+            }
+            body += cols[c].values;
+            Thrift h; // PageHeader
+            h.begin();
+            h.i32(1, 0); // DATA_PAGE
+            h.i32(2, (int32_t)body.size());
+            h.i32(3, (int32_t)body.size());
+            h.struct_field(5); // DataPageHeader
+            h.i32(1, (int32_t)group_rows);
+            h.i32(2, 0); // PLAIN
+            h.i32(3, 3); // RLE
+            h.i32(4, 3);
+            h.end();
+            h.end();
+            ChunkMeta m;
+            m.data_page_offset = (int64_t)file_pos;
+            m.size = (int64_t)(h.out.size() + body.size());
+            m.num_values = (int64_t)group_rows;
+            write(h.out);
+            write(body);
+            g.bytes += m.size;
+            g.cols.push_back(m);
+            cols[c].values.clear();
+            cols[c].defs.clear();
+        }
+        groups.push_back(g);
+        group_rows = 0;
+    }
+    void close_chunk()
+    {
+        if (!fp) return;
+        flush_group();
+        Thrift t; // FileMetaData
+        t.begin();
+        t.i32(1, 1);
+        t.list(2, 12, 20); // schema: root + 19 leaves
+        t.begin();
+        t.str(4, "arrow_schema");
+        t.i32(5, 19);
+        t.end();
+        for (const ColumnDef &c : COLS) {
+            t.begin();
+            t.i32(1, c.type);
+            if (c.type == P_FIXED) t.i32(2, 32);
+            t.i32(3, c.optional ? 1 : 0);
+            t.str(4, c.name);
+            if (c.logical == L_STRING) t.i32(6, 0);        // UTF8
+            if (c.logical == L_TS_MILLIS_UTC) t.i32(6, 9); // TIMESTAMP_MILLIS
+            if (c.logical == L_UINT16) t.i32(6, 12);       // UINT_16
+            if (c.logical == L_UINT8) t.i32(6, 11);        // UINT_8
+            if (c.logical != L_NONE) {
+                t.struct_field(10); // LogicalType union
+                if (c.logical == L_STRING) {
+                    t.struct_field(1);
+                    t.end();
+                } else if (c.logical == L_TS_MILLIS_UTC) {
+                    t.struct_field(8);
+                    t.boolean(1, true);
+                    t.struct_field(2); // TimeUnit
+                    t.struct_field(1); // MILLIS
+                    t.end();
+                    t.end();
+                    t.end();
+                } else {
+                    t.struct_field(10); // IntType
+                    t.i8(1, c.logical == L_UINT16 ? 16 : 8);
+                    t.boolean(2, false);
+                    t.end();
+                }
+                t.end();
+            }
+            t.end();
+        }
+        int64_t rows = 0;
+        for (auto &g : groups) rows += g.rows;
+        t.i64(3, rows);
+        t.list(4, 12, groups.size());
+        for (auto &g : groups) {
+            t.begin();
+            t.list(1, 12, 19);
+            for (int c = 0; c < 19; c++) {
+                t.begin(); // ColumnChunk
+                t.i64(2, g.cols[c].data_page_offset);
+                t.struct_field(3); // ColumnMetaData
+                t.i32(1, COLS[c].type);
+                t.list(2, 5, 2);
+                t.raw_i32(0);
+                t.raw_i32(3);
+                t.list(3, 8, 1);
+                t.binary(COLS[c].name);
+                t.i32(4, 0); // UNCOMPRESSED
+                t.i64(5, g.cols[c].num_values);
+                t.i64(6, g.cols[c].size);
+                t.i64(7, g.cols[c].size);
+                t.i64(9, g.cols[c].data_page_offset);
+                t.end();
+                t.end();
+            }
+            t.i64(2, g.bytes);
+            t.i64(3, g.rows);
+            t.end();
+        }
+        t.str(6, "vuke-hip (MI355X engine) parquet writer");
+        t.end();
+        std::string tail = t.out;
+        put_le32(tail, (uint32_t)t.out.size());
+        tail += "PAR1";
+        write(tail);
+        fclose(fp);
+        fp = nullptr;
+        completed.push_back(path);
+    }
+    void add(const std::string &source, const std::string &tf, const DerivedKey &d, const std::string *matched)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!fp) open_chunk();
+        const int64_t now_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+        cols[0].str(source);
+        cols[1].str(tf);
+        cols[2].str("bitcoin");
+        put_le64(cols[3].values, (uint64_t)now_ms);
+        cols[4].opt_str(matched);
+        cols[5].values.append((const char *)d.raw.data(), 32);
+        cols[6].str(d.private_key_hex);
+        cols[7].str(d.private_key_decimal);
+        cols[8].str(d.private_key_binary);
+        put_le32(cols[9].values, d.bit_length);
+        put_le32(cols[10].values, d.hamming_weight);
+        put_le32(cols[11].values, d.leading_zeros);
+        cols[12].opt_str(d.pubkey_compressed.empty() ? nullptr : &d.pubkey_compressed);
+        cols[13].opt_str(d.pubkey_uncompressed.empty() ? nullptr : &d.pubkey_uncompressed);
+        cols[14].opt_str(&d.p2pkh_compressed);
+        cols[15].opt_str(&d.p2pkh_uncompressed);
+        cols[16].opt_str(&d.p2wpkh);
+        cols[17].opt_str(&d.wif_compressed);
+        cols[18].opt_str(&d.wif_uncompressed);
+        group_rows++;
+        chunk_records++;
+        total_records++;
+        if (group_rows == 65536) flush_group();
+        if (max_chunk_records && chunk_records >= max_chunk_records) close_chunk(); // should_rotate, :110-131
+    }
+};
+
+StorageOutput::StorageOutput(const std::string &base_dir, const std::string &transform_name, uint64_t max_chunk_records) : impl_(new Impl)
+{
+    impl_->base_dir = base_dir;
+    impl_->transform = transform_name;
+    impl_->max_chunk_records = max_chunk_records;
+}
+StorageOutput::~StorageOutput()
+{
+    try {
+        finish();
+    } catch (...) {
+    }
+    delete impl_;
+}
+void StorageOutput::key(const std::string &source, const std::string &transform, const DerivedKey &d) { impl_->add(source, transform, d, nullptr); }
+void StorageOutput::hit(const std::string &source, const std::string &transform, const DerivedKey &d, const MatchInfo &m)
+{
+    impl_->add(source, transform, d, &m.address);
+}
+void StorageOutput::flush() {}
+std::vector<std::string> StorageOutput::finish()
+{
+    std::lock_guard<std::mutex> lk(impl_->mu);
+    impl_->close_chunk();
+    return impl_->completed;
+}
+uint64_t StorageOutput::records() const { return impl_->total_records; }
+
+} // namespace vuke

@@ -161,7 +161,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
         check_rc(engine_, vk_targets_set(engine_, h160.data(), kind.data(), kind.size()));
     }
     const uint32_t flags = VK_F_COMPRESSED | VK_F_UNCOMPRESSED;
-    const bool full = output.needs_full_record();
+    const bool full = output.needs_full_record(), want_pub = output.needs_pubkeys();
     LineReader reader(fp);
     LineBatch b;
     std::vector<uint8_t> keys, valid, flat;
@@ -217,8 +217,8 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                     output.hit(label_of((size_t)hits[i].seed), t.name(), derived[i], mi);
                 }
             } else {
-                std::vector<uint8_t> norm(m * 32), hc(m * 20), hu(m * 20);
-                check_rc(engine_, vk_derive_batch(engine_, flat.data(), m, norm.data(), hc.data(), hu.data()));
+                std::vector<uint8_t> norm(m * 32), hc(m * 20), hu(m * 20), xy(want_pub ? m * 64 : 0);
+                check_rc(engine_, vk_derive_batch_pub(engine_, flat.data(), m, norm.data(), hc.data(), hu.data(), want_pub ? xy.data() : nullptr));
                 for (size_t lo = 0; lo < m; lo += 1u << 18) { // bounded text buffers: ~1 KB per key
                     const size_t cnt = std::min<size_t>(1u << 18, m - lo);
                     std::vector<DerivedKey> derived(cnt);
@@ -227,6 +227,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                         for (size_t i = a0; i < a1; i++) {
                             derived[i] = full ? KeyDeriver::from_device(&norm[32 * (lo + i)], &hc[20 * (lo + i)], &hu[20 * (lo + i)])
                                               : KeyDeriver::from_device_compact(&norm[32 * (lo + i)], &hc[20 * (lo + i)], &hu[20 * (lo + i)]);
+                            if (want_pub) KeyDeriver::set_pubkeys(derived[i], &xy[64 * (lo + i)]);
                             labels[i] = label_of(lo + i);
                         }
                     });
@@ -325,7 +326,7 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
     ProcessStats st;
     st.inputs_processed = end - start + 1; // src/source/range.rs:32
     const uint32_t flags = VK_F_COMPRESSED | VK_F_UNCOMPRESSED;
-    const bool full = output.needs_full_record();
+    const bool full = output.needs_full_record(), want_pub = output.needs_pubkeys();
     if (matcher) {
         std::vector<uint8_t> h160, kind;
         matcher->device_targets(h160, kind);
@@ -397,12 +398,19 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
                 vk_sweep_stats ss;
                 check_rc(engine_, vk_generate(engine_, &t.spec(), lo, hi, flags, priv.data(), hc.data(), hu.data(), valid.data(), &ss));
                 st.keys_generated += ss.keys;
+                std::vector<uint8_t> xy;
+                if (want_pub) { // the record carries the public keys: a second pass over the (already normalised) keys fetches X || Y
+                    xy.resize(n * 64);
+                    check_rc(engine_, vk_derive_batch_pub(engine_, priv.data(), n, nullptr, nullptr, nullptr, xy.data()));
+                }
                 std::vector<DerivedKey> derived(n);
                 parallel_for(n, [&](size_t a, size_t b) {
                     for (size_t i = a; i < b; i++)
-                        if (valid[i])
+                        if (valid[i]) {
                             derived[i] = full ? KeyDeriver::from_device(&priv[32 * i], &hc[20 * i], &hu[20 * i])
                                               : KeyDeriver::from_device_compact(&priv[32 * i], &hc[20 * i], &hu[20 * i]);
+                            if (want_pub) KeyDeriver::set_pubkeys(derived[i], &xy[64 * i]);
+                        }
                 });
                 for (size_t i = 0; i < n; i++)
                     if (valid[i]) output.key(t.label(lo + i / k, (uint32_t)(i % k)), t.name(), derived[i]);

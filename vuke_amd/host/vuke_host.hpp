@@ -61,6 +61,8 @@ public:
     DerivedKey derive(const Key &key) const { return derive(std::vector<Key>{key})[0]; }
     // assemble from values the device already produced
     static DerivedKey from_device(const uint8_t normalised[32], const uint8_t h160_c[20], const uint8_t h160_u[20], Network net = Network::Bitcoin);
+    // pubkey_compressed / pubkey_uncompressed from the affine point X || Y (64 bytes, big-endian)
+    static void set_pubkeys(DerivedKey &d, const uint8_t xy[64]);
     // the two fields the compact CSV line prints (private_key_hex, p2pkh_compressed); every other text field stays empty
     static DerivedKey from_device_compact(const uint8_t normalised[32], const uint8_t h160_c[20], const uint8_t h160_u[20]);
 
@@ -132,6 +134,60 @@ public:
     // false: key() reads only private_key_hex and p2pkh_compressed (the reference builds all fourteen fields for every
     // key regardless; at three million keys that is most of generate's wall time)
     virtual bool needs_full_record() const { return true; }
+    // true: key() also reads pubkey_compressed / pubkey_uncompressed (the bulk generate path fetches them only on request)
+    virtual bool needs_pubkeys() const { return false; }
+};
+
+// MultiOutput (src/output/multi.rs): the same record to every sink, in order
+class MultiOutput : public Output {
+public:
+    explicit MultiOutput(std::vector<Output *> sinks) : sinks_(std::move(sinks)) {}
+    void key(const std::string &source, const std::string &transform, const DerivedKey &d) override
+    {
+        for (Output *o : sinks_) o->key(source, transform, d);
+    }
+    void hit(const std::string &source, const std::string &transform, const DerivedKey &d, const MatchInfo &m) override
+    {
+        for (Output *o : sinks_) o->hit(source, transform, d, m);
+    }
+    void flush() override
+    {
+        for (Output *o : sinks_) o->flush();
+    }
+    bool needs_full_record() const override
+    {
+        for (Output *o : sinks_)
+            if (o->needs_full_record()) return true;
+        return false;
+    }
+    bool needs_pubkeys() const override
+    {
+        for (Output *o : sinks_)
+            if (o->needs_pubkeys()) return true;
+        return false;
+    }
+
+private:
+    std::vector<Output *> sinks_;
+};
+
+// StorageOutput (src/output/storage.rs + src/storage/parquet_backend.rs): the 19-column result record
+// (src/storage/schema.rs:78-111) as uncompressed Parquet files under
+// DIR/transform=<name>/date=<UTC date>/chunk_NNNN.parquet, a new chunk every max_chunk_records records (0 = never).
+class StorageOutput : public Output {
+public:
+    StorageOutput(const std::string &base_dir, const std::string &transform_name, uint64_t max_chunk_records = 1000000);
+    ~StorageOutput() override;
+    void key(const std::string &source, const std::string &transform, const DerivedKey &d) override;
+    void hit(const std::string &source, const std::string &transform, const DerivedKey &d, const MatchInfo &m) override;
+    void flush() override;
+    bool needs_pubkeys() const override { return true; }
+    std::vector<std::string> finish(); // closes the open chunk; paths of every file written
+    uint64_t records() const;
+
+private:
+    struct Impl;
+    Impl *impl_;
 };
 
 class ConsoleOutput : public Output { // src/output/console.rs
