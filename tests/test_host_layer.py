@@ -256,7 +256,8 @@ def test_timestamp_source_dates(host):
         assert host.vkh_timestamp_range(bad[0].encode(), bad[1].encode(), C.byref(lo), C.byref(hi)) == -1, bad
 
 
-def test_storage_output_writes_the_19_column_parquet_record(host, vko, tmp_path):
+@pytest.mark.parametrize("compression", ["zstd", "gzip", "none"])
+def test_storage_output_writes_the_19_column_parquet_record(host, vko, tmp_path, compression):
     """StorageOutput: files readable by pyarrow, schema = src/storage/schema.rs:78-111 field for field,
     values = the oracle's DerivedKey, partition layout and rotation = src/storage/parquet_backend.rs:86-131."""
     import datetime
@@ -273,14 +274,17 @@ def test_storage_output_writes_the_19_column_parquet_record(host, vko, tmp_path)
     sources = [f"src{i}[x:{i % 7}]".encode() for i in range(n)]
     matched = [ds[i].p2pkh_compressed if i % 500 == 3 else b"" for i in range(n)]
     host.vkh_storage_write.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
-                                       C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
-    nfiles = host.vkh_storage_write(str(tmp_path).encode(), b"sha256_chain:iterated", 1000, n, raw, hc, hu, xy, (C.c_char_p * n)(*sources), (C.c_char_p * n)(*matched))
+                                       C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_char_p]
+    nfiles = host.vkh_storage_write(str(tmp_path).encode(), b"sha256_chain:iterated", 1000, n, raw, hc, hu, xy, (C.c_char_p * n)(*sources), (C.c_char_p * n)(*matched),
+                                    compression.encode())
     assert nfiles == 3                                           # 1000 + 1000 + 500 records
+    assert host.vkh_storage_write(str(tmp_path / "x").encode(), b"t", 0, 0, raw, hc, hu, xy, (C.c_char_p * n)(*sources), (C.c_char_p * n)(*matched), b"snappy") == -1
     today = datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d")
     files = sorted(glob.glob(str(tmp_path / "transform=sha256_chain:iterated" / f"date={today}" / "chunk_*.parquet")))
     assert [os.path.basename(f) for f in files] == ["chunk_0001.parquet", "chunk_0002.parquet", "chunk_0003.parquet"]
     tables = [pq.read_table(f) for f in files]
     assert [t.num_rows for t in tables] == [1000, 1000, 500]
+    assert pq.read_metadata(files[0]).row_group(0).column(8).compression == {"zstd": "ZSTD", "gzip": "GZIP", "none": "UNCOMPRESSED"}[compression]
     t = pa.concat_tables(tables)
     utf8 = lambda name, nullable: pa.field(name, pa.string(), nullable=nullable)
     want_schema = pa.schema([

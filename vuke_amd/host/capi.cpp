@@ -127,10 +127,10 @@ int vkh_timestamp_range(const char *start_date, const char *end_date, uint64_t *
 // StorageOutput without a device: n records (key, hash160s, X || Y, source, optional matched address) -> Parquet chunks
 // under `dir`; returns the number of files written.  matched[i] = "" means a plain key record.
 int vkh_storage_write(const char *dir, const char *transform, uint64_t chunk_records, size_t n, const uint8_t *keys, const uint8_t *hc,
-                      const uint8_t *hu, const uint8_t *xy, const char *const *sources, const char *const *matched)
+                      const uint8_t *hu, const uint8_t *xy, const char *const *sources, const char *const *matched, const char *compression)
 {
     try {
-        StorageOutput out(dir, transform, chunk_records);
+        StorageOutput out(dir, transform, chunk_records, compression);
         for (size_t i = 0; i < n; i++) {
             DerivedKey d = KeyDeriver::from_device(keys + 32 * i, hc + 20 * i, hu + 20 * i);
             KeyDeriver::set_pubkeys(d, xy + 64 * i);

@@ -33,7 +33,8 @@ static int usage(const char *msg)
                     "  -v, --verbose        (generate) all key formats\n"
                     "  -o, --output <FILE>  write to FILE instead of stdout\n"
                     "  --storage <DIR>      also write the 19-column Parquet record (DIR/transform=T/date=D/chunk_NNNN.parquet,\n"
-                    "                       uncompressed pages); --chunk-records <N> per file (default 1000000)\n"
+                    "                       --chunk-records <N> per file (default 1000000), --compression zstd|gzip|none (default zstd),\n"
+                    "                       --compression-level <L> (default 3)\n"
                     "  --network <N>        bitcoin | testnet | signet | regtest: used by `single`; parsed and ignored by generate / scan\n"
                     "                       exactly like the reference (src/main.rs:464,499)\n"
                     "  --bip39-wordlist <F> 2048-word BIP-39 list (required by --transform multibit)\n"
@@ -242,6 +243,8 @@ int main(int argc, char **argv)
     bool verbose = false, have_range = false, have_start = false, have_end = false, have_wordlist = false, have_timestamps = false, microseconds = false;
     std::string wordlist_file, bip39_file, start_s, end_s, network = "bitcoin", devices_s, storage_dir;
     uint64_t chunk_records = 1000000; // DEFAULT_CHUNK_RECORDS, src/storage/parquet_backend.rs:13
+    std::string compression = "zstd";   // src/main.rs:134-141
+    int compression_level = 3;
     uint64_t start = 0, end = 0;
     int device = 0;
     unsigned window_bits = 0, layout = VK_LAYOUT_UNIFORM;
@@ -264,10 +267,8 @@ int main(int argc, char **argv)
             else if (a == "--devices") devices_s = need("--devices");
             else if (a == "--storage") storage_dir = need("--storage");
             else if (a == "--chunk-records") chunk_records = parse_u64(need("--chunk-records"));
-            else if (a == "--compression") {
-                const std::string c = need("--compression");
-                if (c != "none") throw std::invalid_argument("--compression: this build writes uncompressed Parquet pages only (use 'none')");
-            }
+            else if (a == "--compression") compression = need("--compression");
+            else if (a == "--compression-level") compression_level = atoi(need("--compression-level"));
             else if (a == "--window-bits") window_bits = (unsigned)atoi(need("--window-bits"));
             else if (a == "--layout") {
                 const std::string l = need("--layout");
@@ -400,7 +401,7 @@ int main(int argc, char **argv)
         std::unique_ptr<MultiOutput> multi;
         Output *sink = out.get();
         if (!storage_dir.empty()) {
-            storage = std::make_unique<StorageOutput>(storage_dir, transforms[0].name(), chunk_records);
+            storage = std::make_unique<StorageOutput>(storage_dir, transforms[0].name(), chunk_records, compression, compression_level);
             multi = std::make_unique<MultiOutput>(std::vector<Output *>{out.get(), storage.get()});
             sink = multi.get();
         }

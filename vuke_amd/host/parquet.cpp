@@ -1,18 +1,22 @@
 // parquet.cpp -- the reference's 19-column result record as Parquet files: StorageOutput + a minimal
-// Parquet writer (PLAIN encoding, uncompressed, one data page per column per row group, Thrift compact metadata).
+// Parquet writer (PLAIN encoding, one data page per column per row group, Thrift compact metadata).
 //
 // Schema and column semantics: src/storage/schema.rs:78-111 (result_schema) and :137-262 (records_to_batch);
 // partition layout `DIR/transform=<first transform>/date=<UTC date>/chunk_NNNN.parquet` and record-count rotation:
 // src/storage/parquet_backend.rs:86-140; console + storage fan-out: src/main.rs:666-672 (MultiOutput).
-// The reference compresses with ZSTD by default; this writer stores pages uncompressed (`--compression none`), which
-// every Parquet reader accepts.  Cloud upload, Iceberg and the DuckDB query layer are out of scope.
+// Page compression (src/main.rs:134-141): none, gzip (zlib) and zstd -- the reference's default, level 3 -- through
+// libzstd.so.1 loaded at run time (the image ships the library without its header); snappy and lz4 are not available
+// here.  Cloud upload, Iceberg and the DuckDB query layer are out of scope.
 #include "vuke_host.hpp"
 
 #include <chrono>
 #include <cstring>
 #include <ctime>
+#include <dlfcn.h>
 #include <stdexcept>
 #include <sys/stat.h>
+#include <thread>
+#include <zlib.h>
 
 namespace vuke {
 
@@ -142,8 +146,43 @@ std::string rle_levels(const std::vector<uint8_t> &defs)
 }
 
 struct ChunkMeta {
-    int64_t data_page_offset, size, num_values;
+    int64_t data_page_offset, size, raw_size, num_values;
 };
+
+// parquet.thrift CompressionCodec: UNCOMPRESSED = 0, GZIP = 2, ZSTD = 6
+std::string compress_page(int codec, int level, const std::string &in)
+{
+    if (codec == 0) return in;
+    if (codec == 2) {
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        if (deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("zlib: deflateInit2 failed");
+        std::string out(deflateBound(&z, in.size()) + 32, '\0');
+        z.next_in = (Bytef *)in.data();
+        z.avail_in = (uInt)in.size();
+        z.next_out = (Bytef *)&out[0];
+        z.avail_out = (uInt)out.size();
+        const int rc = deflate(&z, Z_FINISH);
+        deflateEnd(&z);
+        if (rc != Z_STREAM_END) throw std::runtime_error("zlib: deflate failed");
+        out.resize(z.total_out);
+        return out;
+    }
+    // zstd: the three entry points of the stable API, resolved once
+    typedef size_t (*bound_fn)(size_t);
+    typedef size_t (*comp_fn)(void *, size_t, const void *, size_t, int);
+    typedef unsigned (*err_fn)(size_t);
+    static void *lib = dlopen("libzstd.so.1", RTLD_NOW);
+    static bound_fn bound = lib ? (bound_fn)dlsym(lib, "ZSTD_compressBound") : nullptr;
+    static comp_fn comp = lib ? (comp_fn)dlsym(lib, "ZSTD_compress") : nullptr;
+    static err_fn iserr = lib ? (err_fn)dlsym(lib, "ZSTD_isError") : nullptr;
+    if (!bound || !comp || !iserr) throw std::runtime_error("--compression zstd: libzstd.so.1 is not available on this machine (use gzip or none)");
+    std::string out(bound(in.size()), '\0');
+    const size_t n = comp(&out[0], out.size(), in.data(), in.size(), level);
+    if (iserr(n)) throw std::runtime_error("zstd: compression failed");
+    out.resize(n);
+    return out;
+}
 struct RowGroupMeta {
     std::vector<ChunkMeta> cols;
     int64_t rows, bytes;
@@ -154,6 +193,7 @@ struct RowGroupMeta {
 struct StorageOutput::Impl {
     std::string base_dir, transform, date;
     uint64_t max_chunk_records;
+    int codec = 0, level = 3;
     uint32_t chunk_index = 0;
     FILE *fp = nullptr;
     std::string path;
@@ -205,19 +245,35 @@ struct StorageOutput::Impl {
         RowGroupMeta g;
         g.rows = (int64_t)group_rows;
         g.bytes = 0;
+        // page bodies are built and compressed column by column on their own threads, then written in schema order
+        std::string body[19], packed[19];
+        std::exception_ptr err[19];
+        {
+            std::vector<std::thread> th;
+            for (int c = 0; c < 19; c++)
+                th.emplace_back([&, c]() {
+                    try {
+                        if (COLS[c].optional) {
+                            const std::string lv = rle_levels(cols[c].defs);
+                            put_le32(body[c], (uint32_t)lv.size());
+                            body[c] += lv;
+                        }
+                        body[c] += cols[c].values;
+                        packed[c] = compress_page(codec, level, body[c]);
+                    } catch (...) {
+                        err[c] = std::current_exception();
+                    }
+                });
+            for (auto &t : th) t.join();
+        }
+        for (int c = 0; c < 19; c++)
+            if (err[c]) std::rethrow_exception(err[c]);
         for (int c = 0; c < 19; c++) {
-            std::string body;
-            if (COLS[c].optional) {
-                const std::string lv = rle_levels(cols[c].defs);
-                put_le32(body, (uint32_t)lv.size());
-                body += lv;
-            }
-            body += cols[c].values;
             Thrift h; // PageHeader
             h.begin();
             h.i32(1, 0); // DATA_PAGE
-            h.i32(2, (int32_t)body.size());
-            h.i32(3, (int32_t)body.size());
+            h.i32(2, (int32_t)body[c].size());
+            h.i32(3, (int32_t)packed[c].size());
             h.struct_field(5); // DataPageHeader
             h.i32(1, (int32_t)group_rows);
             h.i32(2, 0); // PLAIN
@@ -227,11 +283,12 @@ struct StorageOutput::Impl {
             h.end();
             ChunkMeta m;
             m.data_page_offset = (int64_t)file_pos;
-            m.size = (int64_t)(h.out.size() + body.size());
+            m.size = (int64_t)(h.out.size() + packed[c].size());
+            m.raw_size = (int64_t)(h.out.size() + body[c].size());
             m.num_values = (int64_t)group_rows;
             write(h.out);
-            write(body);
-            g.bytes += m.size;
+            write(packed[c]);
+            g.bytes += m.raw_size;
             g.cols.push_back(m);
             cols[c].values.clear();
             cols[c].defs.clear();
@@ -301,9 +358,9 @@ struct StorageOutput::Impl {
                 t.raw_i32(3);
                 t.list(3, 8, 1);
                 t.binary(COLS[c].name);
-                t.i32(4, 0); // UNCOMPRESSED
+                t.i32(4, codec);
                 t.i64(5, g.cols[c].num_values);
-                t.i64(6, g.cols[c].size);
+                t.i64(6, g.cols[c].raw_size);
                 t.i64(7, g.cols[c].size);
                 t.i64(9, g.cols[c].data_page_offset);
                 t.end();
@@ -355,11 +412,23 @@ struct StorageOutput::Impl {
     }
 };
 
-StorageOutput::StorageOutput(const std::string &base_dir, const std::string &transform_name, uint64_t max_chunk_records) : impl_(new Impl)
+StorageOutput::StorageOutput(const std::string &base_dir, const std::string &transform_name, uint64_t max_chunk_records, const std::string &compression,
+                             int level)
+    : impl_(new Impl)
 {
     impl_->base_dir = base_dir;
     impl_->transform = transform_name;
     impl_->max_chunk_records = max_chunk_records;
+    impl_->level = level;
+    if (compression == "none") impl_->codec = 0;
+    else if (compression == "gzip") impl_->codec = 2;
+    else if (compression == "zstd") impl_->codec = 6;
+    else {
+        delete impl_;
+        throw std::invalid_argument("compression '" + compression + "' is not available in this build (none, gzip, zstd)");
+    }
+    if (impl_->codec == 2 && (level < 0 || level > 9)) impl_->level = 6;
+    if (impl_->codec) (void)compress_page(impl_->codec, impl_->level, std::string("probe")); // fail now, not at the first page
 }
 StorageOutput::~StorageOutput()
 {
