@@ -130,7 +130,7 @@ int vkh_storage_write(const char *dir, const char *transform, uint64_t chunk_rec
                       const uint8_t *hu, const uint8_t *xy, const char *const *sources, const char *const *matched, const char *compression)
 {
     try {
-        StorageOutput out(dir, transform, chunk_records, compression);
+        StorageOutput out(dir, transform, chunk_records, compression, 3, 0);
         for (size_t i = 0; i < n; i++) {
             DerivedKey d = KeyDeriver::from_device(keys + 32 * i, hc + 20 * i, hu + 20 * i);
             KeyDeriver::set_pubkeys(d, xy + 64 * i);

@@ -33,7 +33,8 @@ static int usage(const char *msg)
                     "  -v, --verbose        (generate) all key formats\n"
                     "  -o, --output <FILE>  write to FILE instead of stdout\n"
                     "  --storage <DIR>      also write the 19-column Parquet record (DIR/transform=T/date=D/chunk_NNNN.parquet,\n"
-                    "                       --chunk-records <N> per file (default 1000000), --compression zstd|gzip|none (default zstd),\n"
+                    "                       --chunk-records <N> / --chunk-bytes <N[K|M|G]> per file (defaults 1000000 / 100M),\n"
+                    "                       --compression zstd|gzip|none (default zstd),\n"
                     "                       --compression-level <L> (default 3)\n"
                     "  --network <N>        bitcoin | testnet | signet | regtest: used by `single`; parsed and ignored by generate / scan\n"
                     "                       exactly like the reference (src/main.rs:464,499)\n"
@@ -243,6 +244,7 @@ int main(int argc, char **argv)
     bool verbose = false, have_range = false, have_start = false, have_end = false, have_wordlist = false, have_timestamps = false, microseconds = false;
     std::string wordlist_file, bip39_file, start_s, end_s, network = "bitcoin", devices_s, storage_dir;
     uint64_t chunk_records = 1000000; // DEFAULT_CHUNK_RECORDS, src/storage/parquet_backend.rs:13
+    uint64_t chunk_bytes = 100ull << 20; // 100M, src/main.rs:130-132
     std::string compression = "zstd";   // src/main.rs:134-141
     int compression_level = 3;
     uint64_t start = 0, end = 0;
@@ -267,6 +269,15 @@ int main(int argc, char **argv)
             else if (a == "--devices") devices_s = need("--devices");
             else if (a == "--storage") storage_dir = need("--storage");
             else if (a == "--chunk-records") chunk_records = parse_u64(need("--chunk-records"));
+            else if (a == "--chunk-bytes") { // parse_byte_size, src/main.rs:29-46
+                std::string v = need("--chunk-bytes");
+                uint64_t mul = 1;
+                if (!v.empty() && strchr("kKmMgG", v.back())) {
+                    mul = (v.back() == 'k' || v.back() == 'K') ? 1024ull : (v.back() == 'm' || v.back() == 'M') ? 1048576ull : 1073741824ull;
+                    v.pop_back();
+                }
+                chunk_bytes = parse_u64(v.c_str()) * mul;
+            }
             else if (a == "--compression") compression = need("--compression");
             else if (a == "--compression-level") compression_level = atoi(need("--compression-level"));
             else if (a == "--window-bits") window_bits = (unsigned)atoi(need("--window-bits"));
@@ -401,7 +412,7 @@ int main(int argc, char **argv)
         std::unique_ptr<MultiOutput> multi;
         Output *sink = out.get();
         if (!storage_dir.empty()) {
-            storage = std::make_unique<StorageOutput>(storage_dir, transforms[0].name(), chunk_records, compression, compression_level);
+            storage = std::make_unique<StorageOutput>(storage_dir, transforms[0].name(), chunk_records, compression, compression_level, chunk_bytes);
             multi = std::make_unique<MultiOutput>(std::vector<Output *>{out.get(), storage.get()});
             sink = multi.get();
         }

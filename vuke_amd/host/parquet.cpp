@@ -192,7 +192,7 @@ struct RowGroupMeta {
 
 struct StorageOutput::Impl {
     std::string base_dir, transform, date;
-    uint64_t max_chunk_records;
+    uint64_t max_chunk_records, max_chunk_bytes = 0, chunk_bytes = 0;
     int codec = 0, level = 3;
     uint32_t chunk_index = 0;
     FILE *fp = nullptr;
@@ -232,6 +232,7 @@ struct StorageOutput::Impl {
         fwrite("PAR1", 1, 4, fp);
         file_pos = 4;
         chunk_records = 0;
+        chunk_bytes = 0;
         groups.clear();
     }
     void write(const std::string &s)
@@ -384,6 +385,8 @@ struct StorageOutput::Impl {
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!fp) open_chunk();
+        size_t before = 0;
+        for (const ColumnBuf &c : cols) before += c.values.size();
         const int64_t now_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
         cols[0].str(source);
         cols[1].str(tf);
@@ -404,18 +407,23 @@ struct StorageOutput::Impl {
         cols[16].opt_str(&d.p2wpkh);
         cols[17].opt_str(&d.wif_compressed);
         cols[18].opt_str(&d.wif_uncompressed);
+        size_t after = 0;
+        for (const ColumnBuf &c : cols) after += c.values.size();
+        chunk_bytes += after - before; // the record's in-memory size (the reference adds get_array_memory_size of each batch, :212)
         group_rows++;
         chunk_records++;
         total_records++;
         if (group_rows == 65536) flush_group();
-        if (max_chunk_records && chunk_records >= max_chunk_records) close_chunk(); // should_rotate, :110-131
+        if ((max_chunk_records && chunk_records >= max_chunk_records) || (max_chunk_bytes && chunk_bytes >= max_chunk_bytes))
+            close_chunk(); // should_rotate, :110-131
     }
 };
 
 StorageOutput::StorageOutput(const std::string &base_dir, const std::string &transform_name, uint64_t max_chunk_records, const std::string &compression,
-                             int level)
+                             int level, uint64_t max_chunk_bytes)
     : impl_(new Impl)
 {
+    impl_->max_chunk_bytes = max_chunk_bytes;
     impl_->base_dir = base_dir;
     impl_->transform = transform_name;
     impl_->max_chunk_records = max_chunk_records;

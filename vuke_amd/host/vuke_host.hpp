@@ -173,12 +173,13 @@ private:
 
 // StorageOutput (src/output/storage.rs + src/storage/parquet_backend.rs): the 19-column result record
 // (src/storage/schema.rs:78-111) as Parquet files under
-// DIR/transform=<name>/date=<UTC date>/chunk_NNNN.parquet, a new chunk every max_chunk_records records (0 = never).
+// DIR/transform=<name>/date=<UTC date>/chunk_NNNN.parquet, a new chunk every max_chunk_records records or
+// max_chunk_bytes of record data, whichever comes first (0 = no such limit; defaults 1 000 000 and 100 MiB as the reference).
 class StorageOutput : public Output {
 public:
     // compression: "zstd" (the reference's default, level 3), "gzip", "none"; snappy / lz4 are not available in this build
     StorageOutput(const std::string &base_dir, const std::string &transform_name, uint64_t max_chunk_records = 1000000,
-                  const std::string &compression = "zstd", int level = 3);
+                  const std::string &compression = "zstd", int level = 3, uint64_t max_chunk_bytes = 100ull << 20);
     ~StorageOutput() override;
     void key(const std::string &source, const std::string &transform, const DerivedKey &d) override;
     void hit(const std::string &source, const std::string &transform, const DerivedKey &d, const MatchInfo &m) override;
