@@ -185,6 +185,11 @@ int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, const uint64_t 
  * caller; the library embeds none. */
 int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words /* 16384 bytes */);
 
+/* BIP-39 passphrase of the multibit chain: salt = "mnemonic" || passphrase in both stretches (src/multibit.rs:87-101,
+ * 165-168).  Empty by default -- MultibitTransform always passes "" (src/transform/multibit.rs:15-21); the multibit-hd
+ * analyzer takes one (src/analyze/multibit.rs:47-52).  At most 96 bytes; stays set until changed. */
+int vk_multibit_passphrase_set(vk_engine *e, const uint8_t *passphrase, size_t len);
+
 /* Transform::apply_batch for string inputs (Input::from_string; wordlist / stdin sources).  String i is
  * data[offsets[i] .. offsets[i+1]).  slots = vk_slots_per_string(t): the hash transforms (sha256, double_sha256, md5,
  * direct) and armory emit one key per string of any length, sha256_chain variants x depth, VK_T_ELECTRUM (strings up to 64

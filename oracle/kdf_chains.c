@@ -132,6 +132,18 @@ static int ckd(const uint8_t k[32], const uint8_t c[32], uint32_t index, int har
 int vko_multibit_keys(const char *const *wl, const uint8_t *mnemonic, size_t len, uint32_t count, uint8_t *keys, uint8_t *valid,
                       uint8_t seed1_out[64], uint8_t seed2_out[64])
 {
+    return vko_multibit_keys_pass(wl, mnemonic, len, (const uint8_t *)"", 0, count, keys, valid, seed1_out, seed2_out);
+}
+
+/* The same with a BIP-39 passphrase: salt = "mnemonic" || passphrase for both stretches (src/multibit.rs:87-101,165-168);
+ * the transform always passes "", the multibit-hd analyzer takes --passphrase (src/analyze/multibit.rs:47-52). */
+int vko_multibit_keys_pass(const char *const *wl, const uint8_t *mnemonic, size_t len, const uint8_t *pass, size_t passlen, uint32_t count,
+                           uint8_t *keys, uint8_t *valid, uint8_t seed1_out[64], uint8_t seed2_out[64])
+{
+    uint8_t salt[8 + 256];
+    if (passlen > 256) return 0;
+    memcpy(salt, "mnemonic", 8);
+    memcpy(salt + 8, pass, passlen);
     memset(valid, 0, count);
     /* split_whitespace + validate_mnemonic (:143-160) */
     size_t nwords = 0, i = 0;
@@ -147,11 +159,11 @@ int vko_multibit_keys(const char *const *wl, const uint8_t *mnemonic, size_t len
     if (!(nwords == 12 || nwords == 15 || nwords == 18 || nwords == 21 || nwords == 24)) return 0;
     /* NB the reference checks the count first; both are errors, so the order does not matter */
     uint8_t seed1[64], seed2[64], I[64];
-    vko_pbkdf2_hmac_sha512(mnemonic, len, (const uint8_t *)"mnemonic", 8, 2048, seed1, 64); /* password = the string as given */
+    vko_pbkdf2_hmac_sha512(mnemonic, len, salt, 8 + passlen, 2048, seed1, 64); /* password = the string as given */
     char buggy[512];
     size_t bl = vko_multibit_buggy_mnemonic(wl, seed1, buggy, sizeof buggy);
     if (!bl) return 0;
-    vko_pbkdf2_hmac_sha512((const uint8_t *)buggy, bl, (const uint8_t *)"mnemonic", 8, 2048, seed2, 64);
+    vko_pbkdf2_hmac_sha512((const uint8_t *)buggy, bl, salt, 8 + passlen, 2048, seed2, 64);
     if (seed1_out) memcpy(seed1_out, seed1, 64);
     if (seed2_out) memcpy(seed2_out, seed2, 64);
     vko_hmac_sha512((const uint8_t *)"Bitcoin seed", 12, seed2, 64, I); /* :242-254 */

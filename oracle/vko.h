@@ -108,6 +108,8 @@ int vko_electrum_label(const char *seed, uint32_t for_change, uint32_t index, ch
 size_t vko_multibit_buggy_mnemonic(const char *const *wl, const uint8_t seed[64], char *out, size_t cap);
 int vko_multibit_keys(const char *const *wl, const uint8_t *mnemonic, size_t len, uint32_t count, uint8_t *keys, uint8_t *valid,
                       uint8_t seed1_out[64], uint8_t seed2_out[64]);
+int vko_multibit_keys_pass(const char *const *wl, const uint8_t *mnemonic, size_t len, const uint8_t *pass, size_t passlen, uint32_t count,
+                           uint8_t *keys, uint8_t *valid, uint8_t seed1_out[64], uint8_t seed2_out[64]);
 int vko_multibit_label(const char *mnemonic, uint32_t index, char *out, size_t cap);
 
 /* ------------------------------------------------------- secp256k1/derive */

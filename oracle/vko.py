@@ -102,6 +102,7 @@ def lib():
         L.vko_multibit_buggy_mnemonic.restype = sz
         L.vko_multibit_keys.argtypes = [C.POINTER(cp), cp, sz, u32, cp, cp, cp, cp]
         L.vko_multibit_label.argtypes = [cp, u32, cp, sz]
+        L.vko_multibit_keys_pass.argtypes = [C.POINTER(cp), cp, sz, cp, sz, u32, cp, cp, cp, cp]
         L.vko_milksad_draws.argtypes = [u32, u32, cp]
         L.vko_mt64_draws.argtypes = [u64, u32, cp]
         L.vko_search.argtypes = [C.POINTER(Spec), u64, u64, u32, cp, u32, cp, C.POINTER(u64), C.POINTER(u64), cp, C.POINTER(u32)]
@@ -302,11 +303,13 @@ def multibit_buggy_mnemonic(wl, seed64):
     return o.raw[:n].decode()
 
 
-def multibit_keys(wl, mnemonic, count=20):
-    """MultibitTransform::apply_batch for one string input: (seed1, seed2, [(label, key)]) or None if skipped."""
+def multibit_keys(wl, mnemonic, count=20, passphrase=b""):
+    """MultibitTransform::apply_batch for one string input: (seed1, seed2, [(label, key)]) or None if skipped.
+    passphrase: the BIP-39 passphrase of the multibit-hd analyzer (the transform always uses the empty one)."""
     m = mnemonic.encode() if isinstance(mnemonic, str) else mnemonic
+    pw = passphrase.encode() if isinstance(passphrase, str) else passphrase
     keys, valid, s1, s2 = _out(32 * count), _out(count), _out(64), _out(64)
-    if not lib().vko_multibit_keys(wl.arr, m, len(m), count, keys, valid, s1, s2):
+    if not lib().vko_multibit_keys_pass(wl.arr, m, len(m), pw, len(pw), count, keys, valid, s1, s2):
         return None
     out = []
     for i in range(count):

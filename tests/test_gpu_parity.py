@@ -364,6 +364,28 @@ def test_multibit_chain(eng, vko):
     assert sum(1 for r in got for k in r if k is not None) == 21 * 20
 
 
+def test_multibit_passphrase(eng, vko):
+    """vk_multibit_passphrase_set: salt = "mnemonic" || passphrase in both stretches (multibit-hd analyzer)."""
+    from tests.test_oracle_multibit import synthetic_wordlist
+    from vuke_amd import _ffi as ffi
+    words = synthetic_wordlist()
+    wl = vko.Wordlist(words)
+    eng.bip39_wordlist_set(words)
+    rnd = random.Random(41)
+    ms = [" ".join(rnd.choice(words) for _ in range(n)) for n in (12, 24, 18)]
+    spec = ffi.spec(ffi.T_MULTIBIT, 0, 0, 4)
+    try:
+        for pw in (b"TREZOR", b"p" * 96, b""):
+            eng.multibit_passphrase_set(pw)
+            got = eng.transform_strings(spec, [m.encode() for m in ms])
+            for m, row in zip(ms, got):
+                assert row == [k for _, k in vko.multibit_keys(wl, m, count=4, passphrase=pw)[2]], (pw, m)
+        with pytest.raises(Exception):
+            eng.multibit_passphrase_set(b"q" * 97)
+    finally:
+        eng.multibit_passphrase_set(b"")
+
+
 def test_analyzer_search(eng, vko):
     """analyzer brute force (exact / masked / cascade) for milksad, lcg, mt64 on the device."""
     from vuke_amd import _ffi as ffi

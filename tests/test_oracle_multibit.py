@@ -21,14 +21,14 @@ def synthetic_wordlist(seed=39):
     return sorted(words)
 
 
-def py_multibit(words, mnemonic, count):
+def py_multibit(words, mnemonic, count, passphrase=b""):
     toks = mnemonic.split()
     if len(toks) not in (12, 15, 18, 21, 24) or any(t not in words for t in toks):
         return None
-    seed1 = hashlib.pbkdf2_hmac("sha512", mnemonic.encode(), b"mnemonic", 2048)
+    seed1 = hashlib.pbkdf2_hmac("sha512", mnemonic.encode(), b"mnemonic" + passphrase, 2048)
     bits = "".join(f"{b:08b}" for b in seed1) + "".join(f"{b:08b}" for b in hashlib.sha256(seed1).digest())[:16]
     buggy = " ".join(words[int(bits[11 * i:11 * i + 11], 2)] for i in range(48))
-    seed2 = hashlib.pbkdf2_hmac("sha512", buggy.encode(), b"mnemonic", 2048)
+    seed2 = hashlib.pbkdf2_hmac("sha512", buggy.encode(), b"mnemonic" + passphrase, 2048)
     I = hmac.new(b"Bitcoin seed", seed2, hashlib.sha512).digest()
     N = pyref.N
 
@@ -70,6 +70,11 @@ def test_synthetic_wordlist_vs_python(vko):
         assert (got[0], got[1]) == (seed1, seed2), m
         assert vko.multibit_buggy_mnemonic(wl, seed1) == buggy
         assert [k for _, k in got[2]] == keys
+    # BIP-39 passphrase (multibit-hd analyzer, src/analyze/multibit.rs:47-52): salt = "mnemonic" || passphrase, both stretches
+    for pw in (b"TREZOR", b"x" * 96, "z\u00fc".encode()):
+        seed1, seed2, _, keys = py_multibit(words, cases[0], 3, pw)
+        got = vko.multibit_keys(wl, cases[0], count=3, passphrase=pw)
+        assert (got[0], got[1], [k for _, k in got[2]]) == (seed1, seed2, keys), pw
     toks = cases[0].split()
     assert vko.multibit_keys(wl, cases[0], count=2)[2][1][0] == f"{toks[0]} {toks[1]}...{toks[-2]} {toks[-1]}[m/0'/0/1]"
 

@@ -61,7 +61,7 @@ SEARCH_EXACT, SEARCH_MASKED, SEARCH_CASCADE = 0, 1, 2
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
     "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
-    "vk_transform_strings", "vk_scan_keys", "vk_bip39_wordlist_set", "vk_search",
+    "vk_transform_strings", "vk_scan_keys", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
     "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field",
 ]
 
@@ -205,6 +205,11 @@ class Engine:
         assert len(words) == 2048
         blob = b"".join((w if isinstance(w, bytes) else w.encode()).ljust(8, b"\0") for w in words)
         self._chk(self._L.vk_bip39_wordlist_set(self._e, blob))
+
+    def multibit_passphrase_set(self, passphrase=b""):
+        pw = passphrase.encode() if isinstance(passphrase, str) else passphrase
+        self._L.vk_multibit_passphrase_set.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        self._chk(self._L.vk_multibit_passphrase_set(self._e, pw, len(pw)))
 
     def transform_strings(self, spec, strings, raw=False):
         """Transform::apply_batch for string inputs: per input a list of keys (None where nothing is emitted).

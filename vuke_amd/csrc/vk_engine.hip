@@ -32,6 +32,7 @@ struct vk_engine {
     vk_win_desc wins[VK_MAX_WIN];
     u64 table_entries = 0;
     u64 *d_wordlist = nullptr;     // BIP-39 list, 2048 x 8 bytes (vk_bip39_wordlist_set)
+    vk_mb_pass mb_pass = {};       // BIP-39 passphrase of the multibit chain (vk_multibit_passphrase_set; empty by default)
     vk_win_desc *d_wins = nullptr; // device copy of wins (kernels that take the layout by pointer)
     double table_build_seconds = 0.0;
     u32 batch = 128;
@@ -712,6 +713,18 @@ extern "C" int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words)
     return VK_OK;
 }
 
+extern "C" int vk_multibit_passphrase_set(vk_engine *e, const uint8_t *passphrase, size_t len)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (len && !passphrase) return fail(e, VK_E_INVALID_ARG, "passphrase is NULL");
+    if (len > VK_MULTIBIT_MAX_PASS) return fail(e, VK_E_UNSUPPORTED, "multibit passphrase longer than 96 bytes");
+    memset(&e->mb_pass, 0, sizeof e->mb_pass);
+    e->mb_pass.len = (u32)len;
+    if (len) memcpy(e->mb_pass.b, passphrase, len);
+    return VK_OK;
+}
+
 extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
                                     uint8_t *keys_out, uint8_t *valid)
 {
@@ -747,7 +760,7 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
                                (u64)n, slots, d_keys, d_valid, vk_ec_ctx{e->table, e->d_wins, e->nwin});
         else if (t->kind == VK_T_MULTIBIT)
             hipLaunchKernelGGL(vk_multibit_kernel, dim3((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_data, d_offs, (u64)n,
-                               t->chain_depth, e->d_wordlist, e->table, e->d_wins, e->nwin, d_keys, d_valid);
+                               t->chain_depth, e->d_wordlist, e->table, e->d_wins, e->nwin, d_keys, d_valid, e->mb_pass);
         else
             hipLaunchKernelGGL(vk_electrum_kernel, dim3((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_data, d_offs, (u64)n,
                                t->variant, t->chain_depth, 100000u, e->table, e->d_wins, e->nwin, d_keys, d_valid);

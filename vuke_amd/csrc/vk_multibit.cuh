@@ -206,8 +206,16 @@ __device__ __noinline__ void pbkdf2_tail_2048(u64 t[8], const u64 ist[8], const 
     }
 }
 
-// PBKDF2-HMAC-SHA512(password, "mnemonic", 2048, 64 bytes); pw may be overwritten (padding)
-__device__ __noinline__ void pbkdf2_mnemonic(u64 seed[8], unsigned char *pw, u32 pwlen)
+// BIP-39 passphrase appended to the salt "mnemonic" (the transform passes none; the multibit-hd analyzer may): at most
+// VK_MULTIBIT_MAX_PASS bytes so that salt || INT(1) stays inside one SHA-512 block
+#define VK_MULTIBIT_MAX_PASS 96
+struct vk_mb_pass {
+    u32 len;
+    unsigned char b[VK_MULTIBIT_MAX_PASS];
+};
+
+// PBKDF2-HMAC-SHA512(password, "mnemonic" || passphrase, 2048, 64 bytes); pw may be overwritten (padding)
+__device__ __noinline__ void pbkdf2_mnemonic(u64 seed[8], unsigned char *pw, u32 pwlen, const vk_mb_pass &pass)
 {
     u64 ist[8], ost[8];
     unsigned char key[128];
@@ -224,9 +232,11 @@ __device__ __noinline__ void pbkdf2_mnemonic(u64 seed[8], unsigned char *pw, u32
     unsigned char salt[128];
     const char s[8] = {'m', 'n', 'e', 'm', 'o', 'n', 'i', 'c'};
     for (int i = 0; i < 8; i++) salt[i] = (unsigned char)s[i];
-    salt[8] = 0; salt[9] = 0; salt[10] = 0; salt[11] = 1;
+    const u32 pl = pass.len;
+    for (u32 i = 0; i < pl; i++) salt[8 + i] = pass.b[i];
+    salt[8 + pl] = 0; salt[9 + pl] = 0; salt[10 + pl] = 0; salt[11 + pl] = 1;
     u64 u1[8];
-    hmac512_final(u1, ist, ost, salt, 12);
+    hmac512_final(u1, ist, ost, salt, 12 + pl);
     pbkdf2_tail_2048(seed, ist, ost, u1);
 }
 
@@ -274,7 +284,7 @@ VK_DEV bool mb_is_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n
 __global__ void __launch_bounds__(VK_BLOCK) vk_multibit_kernel(const unsigned char *__restrict__ data, const u32 *__restrict__ offs, u64 n, u32 count,
                                                                  const u64 *__restrict__ wordlist /* 2048 x 8 bytes, zero padded, as LE u64 */,
                                                                  const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin,
-                                                                 u32 *__restrict__ keys_out, unsigned char *__restrict__ valid_out)
+                                                                 u32 *__restrict__ keys_out, unsigned char *__restrict__ valid_out, const vk_mb_pass pass)
 {
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
     if (idx >= n) return;
@@ -307,7 +317,7 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_multibit_kernel(const unsigned ch
     unsigned char buf[640];
     for (u32 j = 0; j < len; j++) buf[j] = mn[j];
     u64 seed[8];
-    pbkdf2_mnemonic(seed, buf, len);
+    pbkdf2_mnemonic(seed, buf, len, pass);
     // ---- 512 + 16 checksum bits -> 48 words joined by spaces
     unsigned char bits[66];
     for (int j = 0; j < 8; j++) store_be64(bits + 8 * j, seed[j]);
@@ -335,7 +345,7 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_multibit_kernel(const unsigned ch
         }
     }
     // ---- seed2 = PBKDF2(48-word string); (k, c) = HMAC("Bitcoin seed", seed2)
-    pbkdf2_mnemonic(seed, buf, bl);
+    pbkdf2_mnemonic(seed, buf, bl, pass);
     u64 ist[8], ost[8], I[8];
     {
         const char bs[12] = {'B', 'i', 't', 'c', 'o', 'i', 'n', ' ', 's', 'e', 'e', 'd'};

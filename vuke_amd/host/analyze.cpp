@@ -9,7 +9,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cerrno>
 #include <cstring>
+#include <fstream>
 #include <stdexcept>
 
 namespace vuke {
@@ -221,6 +223,77 @@ AnalysisResult Sha256ChainAnalyzer::analyze(const Key &key, const AnalysisConfig
     if (!r.found)
         return {name(), AnalysisStatus::NotFound, "checked " + std::to_string(total) + " seeds, variants=[" + names + "], chain_depth=" + std::to_string(depth_)};
     return {name(), AnalysisStatus::Confirmed, std::string(head) + ", chain_index=" + std::to_string(r.index)};
+}
+
+// ---------------------------------------------------------------- multibit-hd (src/analyze/multibit.rs)
+AnalysisResult MultibitAnalyzer::analyze(const Key &key, const AnalysisConfig &) const
+{
+    if (!mnemonic_ && !file_) return {name(), AnalysisStatus::Unknown, "requires --mnemonic or --mnemonic-file to check"};
+    check_rc(engine_, vk_multibit_passphrase_set(engine_, (const uint8_t *)passphrase_.data(), passphrase_.size()));
+    struct Reset { vk_engine *e; ~Reset() { vk_multibit_passphrase_set(e, nullptr, 0); } } reset{engine_};
+    const vk_transform_spec sp{VK_T_MULTIBIT, 0, 0, depth_};
+    const Transform t(sp);
+    // index of the first derivation of `m` that equals the key (check_mnemonic, :47-61), over a batch of mnemonics
+    auto first_hit = [&](const std::vector<std::string> &batch, size_t &which, uint32_t &index) {
+        std::vector<uint8_t> data;
+        std::vector<uint32_t> offs{0};
+        for (const std::string &m : batch) {
+            const std::string u = m.size() <= 256 ? m : std::string(); // longer than any 24-word mnemonic of the list: cannot validate
+            data.insert(data.end(), u.begin(), u.end());
+            offs.push_back((uint32_t)data.size());
+        }
+        std::vector<uint8_t> keys(batch.size() * depth_ * 32), valid(batch.size() * depth_);
+        check_rc(engine_, vk_transform_strings(engine_, &sp, data.data(), offs.data(), batch.size(), keys.data(), valid.data()));
+        for (size_t i = 0; i < batch.size(); i++)
+            for (uint32_t j = 0; j < depth_; j++)
+                if (valid[i * depth_ + j] && memcmp(&keys[32 * (i * depth_ + j)], key.data(), 32) == 0) {
+                    which = i;
+                    index = j;
+                    return true;
+                }
+        return false;
+    };
+    auto shown = [&](const std::string &m) { // truncate_mnemonic: the label without its "[m/0'/0/i]" suffix
+        const std::string l = t.label(m, 0);
+        return l.substr(0, l.rfind('['));
+    };
+    size_t which = 0;
+    uint32_t index = 0;
+    if (mnemonic_) { // analyze_single_mnemonic, :63-88
+        if (first_hit({*mnemonic_}, which, index))
+            return {name(), AnalysisStatus::Confirmed, "mnemonic=\"" + shown(*mnemonic_) + "\", path=m/0'/0/" + std::to_string(index) + ", passphrase=\"" +
+                                                           (passphrase_.empty() ? "<empty>" : "<set>") + "\""};
+        return {name(), AnalysisStatus::NotFound, "mnemonic does not produce this key (checked " + std::to_string(depth_) + " derivations)"};
+    }
+    std::ifstream f(*file_); // analyze_mnemonic_file, :90-150
+    if (!f) return {name(), AnalysisStatus::Unknown, "Failed to open mnemonic file: " + std::string(strerror(errno))};
+    std::vector<std::string> batch;
+    std::vector<size_t> line_no;
+    size_t lines = 0;
+    std::string line;
+    auto run = [&]() -> std::optional<AnalysisResult> {
+        if (batch.empty()) return std::nullopt;
+        if (first_hit(batch, which, index))
+            return AnalysisResult{name(), AnalysisStatus::Confirmed,
+                                  "mnemonic=\"" + shown(batch[which]) + "\", path=m/0'/0/" + std::to_string(index) + ", line=" + std::to_string(line_no[which])};
+        batch.clear();
+        line_no.clear();
+        return std::nullopt;
+    };
+    auto ws = [](unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; };
+    while (std::getline(f, line)) {
+        lines++;
+        size_t a = 0, b = line.size();
+        while (a < b && ws((unsigned char)line[a])) a++;
+        while (b > a && ws((unsigned char)line[b - 1])) b--;
+        if (a == b || line[a] == '#') continue;
+        batch.emplace_back(line, a, b - a);
+        line_no.push_back(lines);
+        if (batch.size() == 65536)
+            if (auto r = run()) return *r;
+    }
+    if (auto r = run()) return *r;
+    return {name(), AnalysisStatus::NotFound, "checked " + std::to_string(lines) + " mnemonics \xC3\x97 " + std::to_string(depth_) + " derivations"};
 }
 
 // ---------------------------------------------------------------- direct / heuristic (host only)

@@ -76,6 +76,8 @@ static int run_analyze(int argc, char **argv)
     uint64_t mt64_limit = (1ull << 40) - 1;
     uint32_t chain_depth = 10; // DEFAULT_CHAIN_DEPTH (src/sha256_chain.rs:82)
     bool fast = false, json = false;
+    std::optional<std::string> mnemonic, mnemonic_file;
+    std::string passphrase, bip39_file;
     try {
         for (int i = 2; i < argc; i++) {
             std::string a = argv[i];
@@ -89,6 +91,10 @@ static int run_analyze(int argc, char **argv)
                 mask = (uint8_t)m;
             } else if (a == "--cascade") cascade_s = need("--cascade");
             else if (a == "--fast") fast = true;
+            else if (a == "--mnemonic") mnemonic = need("--mnemonic");
+            else if (a == "--mnemonic-file") mnemonic_file = need("--mnemonic-file");
+            else if (a == "--passphrase") passphrase = need("--passphrase");
+            else if (a == "--bip39-wordlist") bip39_file = need("--bip39-wordlist");
             else if (a == "--json") json = true;
             else if (a == "--analyzer") names.push_back(need("--analyzer"));
             else if (a == "--device") device = atoi(need("--device"));
@@ -108,11 +114,14 @@ static int run_analyze(int argc, char **argv)
         cfg.mask_bits = mask;
         if (!cascade_s.empty()) cfg.cascade_targets = parse_cascade(cascade_s);
         vk_engine *engine = nullptr;
-        bool device_needed = false; // direct / heuristic look at the key bytes only: `analyze --fast` runs without a GPU
-        for (const std::string &n : names) device_needed = device_needed || (n != "direct" && n != "heuristic");
+        bool device_needed = false, ec_needed = false; // direct / heuristic look at the key bytes only: `analyze --fast` runs without a GPU
+        for (const std::string &n : names) {
+            device_needed = device_needed || (n != "direct" && n != "heuristic");
+            ec_needed = ec_needed || n == "multibit-hd" || n == "multibit"; // CKD needs serP(k*G)
+        }
         if (device_needed) {
             vk_engine_opts opts{};
-            opts.window_bits = 8; // the analyzers never touch the k*G table or the inversion workspace: keep both tiny
+            opts.window_bits = ec_needed ? 16 : 8; // the search analyzers never touch the k*G table or the inversion workspace: keep both tiny
             opts.batch = 1;
             if (vk_engine_create_ex(device, &opts, &engine) != VK_OK) {
                 fprintf(stderr, "GPU engine unavailable: %s\n", vk_last_error(nullptr));
@@ -122,7 +131,11 @@ static int run_analyze(int argc, char **argv)
         struct Guard { vk_engine *e; ~Guard() { vk_engine_destroy(e); } } guard{engine};
         std::vector<AnalysisResult> results;
         for (const std::string &n : names) {
-            if (n == "direct") results.push_back(DirectAnalyzer().analyze(key, cfg));
+            if (n == "multibit-hd" || n == "multibit") { // src/analyze/mod.rs:225-229
+                if (bip39_file.empty()) throw std::invalid_argument("multibit-hd needs --bip39-wordlist <FILE> (the 2048-word BIP-39 English list)");
+                load_bip39_wordlist(engine, bip39_file);
+                results.push_back(MultibitAnalyzer(engine, mnemonic, mnemonic_file, passphrase).analyze(key, cfg));
+            } else if (n == "direct") results.push_back(DirectAnalyzer().analyze(key, cfg));
             else if (n == "heuristic") results.push_back(HeuristicAnalyzer().analyze(key, cfg));
             else if (n == "milksad") results.push_back(MilksadAnalyzer(engine).analyze(key, cfg));
             else if (n == "mt64") results.push_back(Mt64Analyzer(engine, mt64_limit).analyze(key, cfg));
@@ -135,7 +148,7 @@ static int run_analyze(int argc, char **argv)
             } else if (n == "sha256_chain" || n.rfind("sha256_chain:", 0) == 0) {
                 Transform t = TransformType::from_str(n); // Sha256ChainConfig::parse (src/sha256_chain.rs:187-217)
                 results.push_back(Sha256ChainAnalyzer(engine, t.spec().variant, chain_depth).analyze(key, cfg));
-            } else throw std::invalid_argument("analyzer '" + n + "' is not built (built: milksad, lcg[:variant][:endian], mt64, xorshift[:variant], sha256_chain[:variant], direct, heuristic)");
+            } else throw std::invalid_argument("analyzer '" + n + "' is not a known analyzer (milksad, lcg[:variant][:endian], mt64, xorshift[:variant], sha256_chain[:variant], multibit-hd, direct, heuristic)");
         }
         if (json) puts(format_results_json(key, results).c_str());
         else fputs(format_results(key, results).c_str(), stdout);

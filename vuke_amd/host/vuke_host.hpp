@@ -352,6 +352,25 @@ private:
     vk_engine *engine_;
     uint32_t variant_, depth_;
 };
+// multibit-hd (src/analyze/multibit.rs): does a mnemonic -- or any line of a mnemonic file -- reach the key through the
+// seed-as-entropy chain at m/0'/0/0..depth-1?  The chains run on the device (vk_transform_strings, VK_T_MULTIBIT), a file
+// in batches of 2^16 mnemonics; needs the BIP-39 word list loaded into the engine.
+class MultibitAnalyzer : public Analyzer {
+public:
+    MultibitAnalyzer(vk_engine *e, std::optional<std::string> mnemonic, std::optional<std::string> mnemonic_file, std::string passphrase,
+                     uint32_t depth = 20)
+        : engine_(e), mnemonic_(std::move(mnemonic)), file_(std::move(mnemonic_file)), passphrase_(std::move(passphrase)), depth_(depth) {}
+    const char *name() const override { return "multibit-hd"; }
+    bool is_brute_force() const override { return file_.has_value(); }
+    AnalysisResult analyze(const Key &key, const AnalysisConfig &config) const override;
+
+private:
+    vk_engine *engine_;
+    std::optional<std::string> mnemonic_, file_;
+    std::string passphrase_;
+    uint32_t depth_;
+};
+
 // host-only analyzers of the reference's default set: cheap pattern checks on the key bytes, no search
 class DirectAnalyzer : public Analyzer { // src/analyze/direct.rs
 public:
