@@ -46,9 +46,38 @@ struct vk_engine {
     u64 *d_stats = nullptr;
     uint4 *work = nullptr;
     size_t work_bytes = 0;
+    // device scratch for the batch entry points (inputs / outputs of one call), kept between calls: a hipMalloc +
+    // hipFree pair per buffer per call cost more than the kernel for batches of a few hundred keys
+    void *scr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scr_cap[6] = {0, 0, 0, 0, 0, 0};
     std::mutex mu;
     std::string err;
 };
+
+// slot `i` of the engine's scratch, at least `bytes` long (contents undefined); nullptr + e->err on failure
+static void *scratch(vk_engine *e, int i, size_t bytes)
+{
+    if (bytes == 0) bytes = 1;
+    if (e->scr_cap[i] >= bytes) return e->scr[i];
+    if (e->scr[i]) {
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipFree(e->scr[i]);
+        e->scr[i] = nullptr;
+        e->scr_cap[i] = 0;
+    }
+    const size_t cap = bytes + bytes / 4; // grow with slack so a slowly growing caller does not reallocate every time
+    hipError_t c = hipMalloc(&e->scr[i], cap);
+    if (c != hipSuccess) {
+        e->scr[i] = nullptr;
+        e->err = std::string("hipMalloc of ") + std::to_string(cap) + " scratch bytes failed: " + hipGetErrorString(c);
+        return nullptr;
+    }
+    e->scr_cap[i] = cap;
+    return e->scr[i];
+}
+#define SCRATCH(e, var, type, slot, bytes)                 \
+    type var = (type)scratch((e), (slot), (bytes));        \
+    if (!var) return VK_E_HIP
 
 #define HIPCHK(e, call)                                                                             \
     do {                                                                                            \
@@ -143,6 +172,8 @@ extern "C" void vk_engine_destroy(vk_engine *e)
     if (!e) return;
     if (e->device >= 0) (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void *p : e->scr)
+        if (p) (void)hipFree(p);
     if (e->table) (void)hipFree(e->table);
     if (e->tgt) (void)hipFree(e->tgt);
     if (e->d_hits) (void)hipFree(e->d_hits);
@@ -511,20 +542,13 @@ extern "C" int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t lo
     memset(&local, 0, sizeof local);
     HIPCHK(e, hipSetDevice(e->device));
     const vk_spec_dev spec = to_dev(t);
-    const u64 chunk_inputs = std::max<u64>(1, (1ull << 24) / slots);
-    u32 *d_priv = nullptr, *d_hc = nullptr, *d_hu = nullptr;
-    unsigned char *d_valid = nullptr;
+    const u64 chunk_inputs = std::min<u64>(std::max<u64>(1, (1ull << 24) / slots), hi - lo + 1);
     const u64 chunk_items = chunk_inputs * slots;
-    HIPCHK(e, hipMalloc(&d_priv, chunk_items * 32));
-    HIPCHK(e, hipMalloc(&d_hc, chunk_items * 20));
-    HIPCHK(e, hipMalloc(&d_hu, chunk_items * 20));
-    HIPCHK(e, hipMalloc(&d_valid, chunk_items));
-    auto cleanup = [&]() {
-        (void)hipFree(d_priv);
-        (void)hipFree(d_hc);
-        (void)hipFree(d_hu);
-        (void)hipFree(d_valid);
-    };
+    SCRATCH(e, d_priv, u32 *, 1, chunk_items * 32);
+    SCRATCH(e, d_hc, u32 *, 2, chunk_items * 20);
+    SCRATCH(e, d_hu, u32 *, 3, chunk_items * 20);
+    SCRATCH(e, d_valid, unsigned char *, 4, chunk_items);
+    auto cleanup = [&]() {};
     u64 cur = lo, done_items = 0;
     for (;;) {
         const u64 left = hi - cur;
@@ -576,20 +600,17 @@ extern "C" int vk_derive_batch_pub(vk_engine *e, const uint8_t *keys, size_t n, 
     if (!keys) return fail(e, VK_E_INVALID_ARG, "keys is NULL");
     HIPCHK(e, hipSetDevice(e->device));
     const size_t chunk = 1u << 22;
-    u32 *d_in = nullptr, *d_priv = nullptr, *d_hc = nullptr, *d_hu = nullptr, *d_pub = nullptr;
     const size_t cn = std::min(n, chunk);
-    HIPCHK(e, hipMalloc(&d_in, cn * 32));
-    HIPCHK(e, hipMalloc(&d_priv, cn * 32));
-    HIPCHK(e, hipMalloc(&d_hc, cn * 20));
-    HIPCHK(e, hipMalloc(&d_hu, cn * 20));
-    if (pub_xy) HIPCHK(e, hipMalloc(&d_pub, cn * 64));
-    auto cleanup = [&]() {
-        (void)hipFree(d_pub);
-        (void)hipFree(d_in);
-        (void)hipFree(d_priv);
-        (void)hipFree(d_hc);
-        (void)hipFree(d_hu);
-    };
+    SCRATCH(e, d_in, u32 *, 0, cn * 32);
+    SCRATCH(e, d_priv, u32 *, 1, cn * 32);
+    SCRATCH(e, d_hc, u32 *, 2, cn * 20);
+    SCRATCH(e, d_hu, u32 *, 3, cn * 20);
+    u32 *d_pub = nullptr;
+    if (pub_xy) {
+        d_pub = (u32 *)scratch(e, 5, cn * 64);
+        if (!d_pub) return VK_E_HIP;
+    }
+    auto cleanup = [&]() {};
     vk_spec_dev spec = {VK_T_RAWKEYS, 0, 0, 0};
     const u32 flags = (h160_u ? VK_F_UNCOMPRESSED : 0u) | ((h160_c || !h160_u) ? VK_F_COMPRESSED : 0u) | VK_F_EMIT;
     for (size_t done = 0; done < n; done += chunk) {
@@ -652,18 +673,11 @@ extern "C" int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, cons
     if ((u64)n * slots > (1ull << 31)) return fail(e, VK_E_INVALID_ARG, "too many keys for one vk_transform_batch call (max 2^31)");
     HIPCHK(e, hipSetDevice(e->device));
     const vk_spec_dev spec = to_dev(t);
-    u64 *d_seeds = nullptr;
-    u32 *d_keys = nullptr;
-    unsigned char *d_valid = nullptr;
     const u64 items = (u64)n * slots;
-    HIPCHK(e, hipMalloc(&d_seeds, n * 8));
-    HIPCHK(e, hipMalloc(&d_keys, items * 32));
-    HIPCHK(e, hipMalloc(&d_valid, items));
-    auto cleanup = [&]() {
-        (void)hipFree(d_seeds);
-        (void)hipFree(d_keys);
-        (void)hipFree(d_valid);
-    };
+    SCRATCH(e, d_seeds, u64 *, 0, n * 8);
+    SCRATCH(e, d_keys, u32 *, 1, items * 32);
+    SCRATCH(e, d_valid, unsigned char *, 4, items);
+    auto cleanup = [&]() {};
     hipError_t c = hipMemcpy(d_seeds, seeds, n * 8, hipMemcpyHostToDevice);
     if (c == hipSuccess) {
         switch (t->kind) {
@@ -744,13 +758,12 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
     }
     HIPCHK(e, hipSetDevice(e->device));
     const size_t bytes = offsets[n], items = n * slots;
-    unsigned char *d_data = nullptr, *d_valid = nullptr;
-    u32 *d_offs = nullptr, *d_keys = nullptr;
-    hipError_t c = hipMalloc(&d_data, bytes ? bytes : 1);
-    if (c == hipSuccess) c = hipMalloc(&d_offs, (n + 1) * 4);
-    if (c == hipSuccess) c = hipMalloc(&d_keys, items * 32);
-    if (c == hipSuccess) c = hipMalloc(&d_valid, items);
-    if (c == hipSuccess && bytes) c = hipMemcpy(d_data, data, bytes, hipMemcpyHostToDevice);
+    SCRATCH(e, d_data, unsigned char *, 0, bytes);
+    SCRATCH(e, d_offs, u32 *, 2, (n + 1) * 4);
+    SCRATCH(e, d_keys, u32 *, 1, items * 32);
+    SCRATCH(e, d_valid, unsigned char *, 4, items);
+    hipError_t c = hipSuccess;
+    if (bytes) c = hipMemcpy(d_data, data, bytes, hipMemcpyHostToDevice);
     if (c == hipSuccess) c = hipMemcpy(d_offs, offsets, (n + 1) * 4, hipMemcpyHostToDevice);
     if (c == hipSuccess) c = hipMemsetAsync(d_keys, 0, items * 32, e->stream);
     if (c == hipSuccess) c = hipMemsetAsync(d_valid, 0, items, e->stream);
@@ -769,10 +782,6 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
     if (c == hipSuccess) c = hipStreamSynchronize(e->stream);
     if (c == hipSuccess) c = hipMemcpy(keys_out, d_keys, items * 32, hipMemcpyDeviceToHost);
     if (c == hipSuccess) c = hipMemcpy(valid, d_valid, items, hipMemcpyDeviceToHost);
-    (void)hipFree(d_data);
-    (void)hipFree(d_offs);
-    (void)hipFree(d_keys);
-    (void)hipFree(d_valid);
     if (c != hipSuccess) {
         e->err = std::string("vk_transform_strings: ") + hipGetErrorString(c);
         return VK_E_HIP;
@@ -791,8 +800,7 @@ extern "C" int vk_scan_keys(vk_engine *e, const uint8_t *keys, size_t n, uint32_
     if (n == 0) return VK_OK;
     if (!keys) return fail(e, VK_E_INVALID_ARG, "keys is NULL");
     HIPCHK(e, hipSetDevice(e->device));
-    u32 *d_in = nullptr;
-    HIPCHK(e, hipMalloc(&d_in, n * 32));
+    SCRATCH(e, d_in, u32 *, 0, n * 32);
     hipError_t c = hipMemcpy(d_in, keys, n * 32, hipMemcpyHostToDevice);
     int rc = VK_OK;
     if (c != hipSuccess) rc = fail(e, VK_E_HIP, "hipMemcpy H2D failed in vk_scan_keys");
@@ -804,7 +812,6 @@ extern "C" int vk_scan_keys(vk_engine *e, const uint8_t *keys, size_t n, uint32_
         vk_spec_dev spec = {VK_T_RAWKEYS, 0, 0, 0};
         rc = run_range(e, spec, VK_T_RAWKEYS, 1, 0, n - 1, flags, io, out);
     }
-    (void)hipFree(d_in);
     if (rc) return rc;
     out->inputs = n;
     out->hits_dropped = out->matches > (hits ? hit_cap : 0) ? out->matches - (hits ? hit_cap : 0) : 0;
