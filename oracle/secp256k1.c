@@ -51,7 +51,6 @@ static uint64_t add4(uint64_t r[4], const uint64_t a[4], const uint64_t b[4])
     return carry;
 }
 static int fe_is_zero(const fe *a) { return (a->v[0] | a->v[1] | a->v[2] | a->v[3]) == 0; }
-static int fe_eq(const fe *a, const fe *b) { return memcmp(a, b, sizeof *a) == 0; }
 
 static void fe_add(fe *r, const fe *a, const fe *b)
 {
