@@ -61,11 +61,6 @@ static void fe_sub(fe *r, const fe *a, const fe *b)
 {
     if (sub4(r->v, a->v, b->v)) add4(r->v, r->v, FE_P.v);
 }
-static void fe_neg(fe *r, const fe *a)
-{
-    if (fe_is_zero(a)) { *r = *a; return; }
-    sub4(r->v, FE_P.v, a->v);
-}
 static void fe_mul(fe *r, const fe *a, const fe *b)
 {
     uint64_t t[8] = {0};
