@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--algo", type=int, default=0, help="0 = Jacobian chain (default), 1 = VK_ALGO_TREE (experimental, see DESIGN.md section 8)")
     # rehearsal knobs (not used by the driver): run the N-rank path on a box with fewer GPUs than ranks
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal)")
     ap.add_argument("--share-device", type=int, default=-1, help="put every rank on this one GPU (rehearsal only)")
@@ -102,7 +103,7 @@ def main():
     from vuke_amd import _ffi as ffi
 
     try:
-        eng = vuke_amd.Engine(local_rank, window_bits=args.window_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=args.layout)
+        eng = vuke_amd.Engine(local_rank, window_bits=args.window_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=args.layout, algo=args.algo)
     except vuke_amd.VkError as exc:
         if args.layout == 0 or exc.code != ffi.VK_E_HIP:
             raise

@@ -115,6 +115,11 @@ typedef struct vk_engine vk_engine;
 #define VK_LAYOUT_UNIFORM 0u
 #define VK_LAYOUT_SIGNED9 1u /* 9 signed-digit windows (4 x 29 + 5 x 28 bits): 8 additions per key, 120 GB table */
 
+/* summation of the table points */
+#define VK_ALGO_CHAIN 0u /* one Jacobian chain: 8 additions, 90 field multiplications per key */
+#define VK_ALGO_TREE 1u  /* first tree level as four affine additions under a second batch inversion: 70 multiplications per key,
+                            17 cooperative table reads instead of 9; built for milksad, lcg and raw keys, other kinds use the chain */
+
 typedef struct vk_engine_opts {
     uint32_t window_bits;  /* fixed-base window width of the k*G table: 4..26 (0 = default 24: 11.8 GB) */
     uint32_t batch;        /* keys per lane sharing one field inversion (0 = default 128; the workspace, 128 B x batch x
@@ -123,6 +128,8 @@ typedef struct vk_engine_opts {
                               tiles are handed out dynamically, so the value only sizes the grid and the workspace */
     uint32_t layout;       /* VK_LAYOUT_*: 0 = uniform unsigned window_bits-wide windows (default) */
     void *stream;          /* hipStream_t to run on (NULL = engine creates its own) */
+    uint32_t algo;         /* VK_ALGO_*: how the nine table points of a key are summed (layout VK_LAYOUT_SIGNED9 only) */
+    uint32_t _pad;
 } vk_engine_opts;
 
 typedef struct vk_engine_info_t {

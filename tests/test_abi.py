@@ -37,7 +37,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_ffi.Hit) == 72
     assert C.sizeof(_ffi.SweepStats) == 80
     assert C.sizeof(_ffi.TransformSpec) == 16
-    assert C.sizeof(_ffi.EngineOpts) == 24
+    assert C.sizeof(_ffi.EngineOpts) == 32
 
 
 def test_slots_per_input_without_gpu(built):

@@ -614,3 +614,36 @@ def test_search_over_hash_transforms(eng, vko):
         assert (r["found"], (r["seed"], r["index"]) if r["found"] else None) == (want is not None, want), kind
     with pytest.raises(Exception):
         eng.search(ffi.spec(ffi.T_SHA256), 0, 10, cascade=[(8, 0x80), (8, 0x81)])
+
+
+def test_tree_summation_algo(vko):
+    """VK_ALGO_TREE (vk_sweep_tree_kernel): first tree level of the table sum in affine coordinates under a second batch
+    inversion, quad-cooperative table reads.  Same counters, digest and hits as the oracle, for every launch shape."""
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+    e = vuke_amd.Engine(0, layout=1, algo=1, batch=64, blocks_per_cu=2)
+    try:
+        cases = [(ffi.T_MILKSAD, vko.T_MILKSAD, 0, 0), (ffi.T_MILKSAD, vko.T_MILKSAD, 5000, 5000 + 8191), (ffi.T_MILKSAD, vko.T_MILKSAD, 123, 123 + 70000),
+                 (ffi.T_MILKSAD, vko.T_MILKSAD, 2**32 - 300, 2**32 + 100), (ffi.T_LCG, vko.T_LCG, 2**31 - 500, 2**31 + 500), (ffi.T_LCG, vko.T_LCG, 0, 3000)]
+        for gk, ok, lo, hi in cases:
+            for flags in (1, 3):
+                st, _ = e.sweep(ffi.spec(gk), lo, hi, flags=flags)
+                ost, _ = vko.sweep(vko.spec(ok), lo, hi, flags=flags, nthreads=8)
+                assert (st["inputs"], st["keys"], st["digest"]) == (ost["inputs"], ost["keys"], ost["digest"]), (gk, lo, hi, flags)
+        # raw keys incl. the edge scalars (zero digits in every position, top-window special entry)
+        rnd = random.Random(5)
+        keys = [be(1), be(2), be(N - 1), be(N - 2), be(2**255), be(2**256 - 2**228 - 1), be(2**29), be(2**58 + 1), be(1 << 228), be((1 << 116) - 1), CHBS]
+        keys += [be(1 << i) for i in range(0, 256, 7)] + [be((1 << i) - 1) for i in range(1, 256, 11)] + [be(rnd.getrandbits(256) % N or 1) for _ in range(200)]
+        norm, hc, hu = e.derive_batch(keys)
+        for k, n, c, u in zip(keys, norm, hc, hu):
+            d = vko.derive(k)
+            assert (n, c, u) == (bytes(d.raw), bytes(d.h160_c), bytes(d.h160_u)), k.hex()
+        # planted hits
+        planted = [7, 4096, 65535, 70001]
+        d = [vko.derive(vko.milksad_key(s)) for s in planted]
+        e.targets_set([bytes(x.h160_c) for x in d], [0] * len(d))
+        st, hits = e.sweep(ffi.spec(ffi.T_MILKSAD), 0, 80000, flags=1)
+        e.targets_set([], [])
+        assert st["matches"] == 4 and [h["seed"] for h in hits] == planted
+    finally:
+        e.close()

@@ -36,7 +36,7 @@ class SweepStats(C.Structure):
 
 class EngineOpts(C.Structure):
     _fields_ = [("window_bits", C.c_uint32), ("batch", C.c_uint32), ("blocks_per_cu", C.c_uint32),
-                ("layout", C.c_uint32), ("stream", C.c_void_p)]
+                ("layout", C.c_uint32), ("stream", C.c_void_p), ("algo", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class EngineInfo(C.Structure):
@@ -115,11 +115,11 @@ class VkError(RuntimeError):
 class Engine:
     """One engine per GPU (vk_engine).  Raises VkError when no gfx950 device is usable."""
 
-    def __init__(self, device=0, window_bits=0, batch=0, blocks_per_cu=0, stream=None, layout=0):
+    def __init__(self, device=0, window_bits=0, batch=0, blocks_per_cu=0, stream=None, layout=0, algo=0):
         L = load()
         self._L = L
         self._e = C.c_void_p()
-        opts = EngineOpts(window_bits, batch, blocks_per_cu, layout, stream)
+        opts = EngineOpts(window_bits, batch, blocks_per_cu, layout, stream, algo, 0)
         rc = L.vk_engine_create_ex(device, C.byref(opts), C.byref(self._e))
         if rc != VK_OK:
             raise VkError(rc, (L.vk_last_error(None) or b"").decode())

@@ -155,6 +155,89 @@ VK_DEV void fe_cond_negate(fe &y, bool neg)
     }
 }
 
+// ---- quad-cooperative table reads ------------------------------------------------------------------------------
+// A lane reading its own 64-byte entry with four 16-byte loads makes every load instruction touch 64 different lines;
+// the per-CU L1 miss path then sustains only ~19 G entries/s chip-wide (tools/gather_bench.hip).  Here the four lanes of
+// a quad read one whole entry per instruction (16 lines per instruction, ~50 G entries/s) and hand the quarters to
+// their owner through a per-wave LDS tile.  Every lane of the wave must take part (no divergence around these calls).
+struct quad_regs {
+    u32 r[16]; // quarter (lane & 3) of the entries of quad lanes 0..3, four words each (plain words: stays in VGPRs across the loop)
+};
+VK_DEV void quad_put(quad_regs &v, int i, const uint4 &t)
+{
+    v.r[4 * i] = t.x; v.r[4 * i + 1] = t.y; v.r[4 * i + 2] = t.z; v.r[4 * i + 3] = t.w;
+}
+VK_DEV uint4 quad_get(const quad_regs &v, int i) { return make_uint4(v.r[4 * i], v.r[4 * i + 1], v.r[4 * i + 2], v.r[4 * i + 3]); }
+VK_DEV void quad_gather_issue(quad_regs &v, const uint4 *__restrict__ table, u64 entry)
+{
+    const u32 lo = (u32)entry, hi = (u32)(entry >> 32);
+    const u32 q = threadIdx.x & 3u;
+    const u32 l0 = __builtin_amdgcn_update_dpp(0u, lo, 0x00, 0xF, 0xF, false), h0 = __builtin_amdgcn_update_dpp(0u, hi, 0x00, 0xF, 0xF, false);
+    const u32 l1 = __builtin_amdgcn_update_dpp(0u, lo, 0x55, 0xF, 0xF, false), h1 = __builtin_amdgcn_update_dpp(0u, hi, 0x55, 0xF, 0xF, false);
+    const u32 l2 = __builtin_amdgcn_update_dpp(0u, lo, 0xAA, 0xF, 0xF, false), h2 = __builtin_amdgcn_update_dpp(0u, hi, 0xAA, 0xF, 0xF, false);
+    const u32 l3 = __builtin_amdgcn_update_dpp(0u, lo, 0xFF, 0xF, 0xF, false), h3 = __builtin_amdgcn_update_dpp(0u, hi, 0xFF, 0xF, 0xF, false);
+    quad_put(v, 0, table[((((u64)h0 << 32) | l0) << 2) + q]);
+    quad_put(v, 1, table[((((u64)h1 << 32) | l1) << 2) + q]);
+    quad_put(v, 2, table[((((u64)h2 << 32) | l2) << 2) + q]);
+    quad_put(v, 3, table[((((u64)h3 << 32) | l3) << 2) + q]);
+}
+// tile = this wave's 64 x 5 uint4 of LDS: entry slots of 80 bytes (64 + 16 of padding) so that neither the quarter
+// writes nor the whole-entry reads of sixteen consecutive lanes share a bank
+#define VK_GTILE_STRIDE 5
+VK_DEV void quad_gather_commit(fe &x, fe &y, const quad_regs &v, uint4 *tile)
+{
+    const u32 lane = threadIdx.x & 63u, base = lane & ~3u, q = lane & 3u;
+    tile[(base + 0) * VK_GTILE_STRIDE + q] = quad_get(v, 0);
+    tile[(base + 1) * VK_GTILE_STRIDE + q] = quad_get(v, 1);
+    tile[(base + 2) * VK_GTILE_STRIDE + q] = quad_get(v, 2);
+    tile[(base + 3) * VK_GTILE_STRIDE + q] = quad_get(v, 3);
+    const uint4 a = tile[lane * VK_GTILE_STRIDE + 0], b = tile[lane * VK_GTILE_STRIDE + 1], c = tile[lane * VK_GTILE_STRIDE + 2],
+                d = tile[lane * VK_GTILE_STRIDE + 3];
+    x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
+    x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+    y.v[0] = c.x; y.v[1] = c.y; y.v[2] = c.z; y.v[3] = c.w;
+    y.v[4] = d.x; y.v[5] = d.y; y.v[6] = d.z; y.v[7] = d.w;
+}
+
+// ecmult_table with cooperative reads: the whole wave calls it (lanes without a key pass k = 1)
+VK_DEV void ecmult_table_coop(jac &acc, const u32 k[8], const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin, uint4 *tile)
+{
+    bool inf = true, zone = false;
+    fe_set_zero(acc.x);
+    fe_set_zero(acc.y);
+    fe_set_one(acc.z);
+    u32 carry = 0;
+    bool neg;
+    u32 d = window_digit(k, wins[0], carry, neg);
+    quad_regs v;
+    quad_gather_issue(v, table, wins[0].base + d);
+#pragma unroll 1
+    for (u32 w = 0; w < nwin; w++) {
+        fe cx, cy;
+        quad_gather_commit(cx, cy, v, tile);
+        const u32 cd = d;
+        const bool cneg = neg;
+        if (w + 1 < nwin) {
+            d = window_digit(k, wins[w + 1], carry, neg);
+            quad_gather_issue(v, table, wins[w + 1].base + d);
+        }
+        if (cd != 0) {
+            fe_cond_negate(cy, cneg);
+            if (inf) {
+                acc.x = cx;
+                acc.y = cy;
+                inf = false;
+                zone = true;
+            } else if (zone) {
+                jac_aadd(acc, acc.x, acc.y, cx, cy);
+                zone = false;
+            } else {
+                jac_madd(acc, acc, cx, cy);
+            }
+        }
+    }
+}
+
 // acc = k*G, k in [1, n).  Returns Jacobian (z = 1 possible).
 // No special cases are needed in the adder: after windows 0..i-1 the accumulator is s*G with
 // |s| < 2^off_i (s != 0 unless all digits so far were zero, in which case it is still "infinity"),

@@ -29,6 +29,7 @@ struct vk_engine {
     int cu_count = 0;
     u32 W = 24, nwin = 11; // default: 11 windows x 2^24 entries x 64 B = 11.8 GB of the 288 GB HBM
     u32 layout = 0;        // 0 uniform unsigned W-bit windows, 1 nine signed windows (VK_LAYOUT_SIGNED9)
+    u32 algo = 0;          // VK_ALGO_CHAIN / VK_ALGO_TREE (signed9 only)
     vk_win_desc wins[VK_MAX_WIN];
     u64 table_entries = 0;
     u64 *d_wordlist = nullptr;     // BIP-39 list, 2048 x 8 bytes (vk_bip39_wordlist_set)
@@ -237,6 +238,11 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
         }
         e->table_entries = (u64)e->nwin << e->W;
     }
+    if (opts && opts->algo) {
+        if (opts->algo != VK_ALGO_TREE) return fail(e, VK_E_INVALID_ARG, "unknown algo");
+        if (e->layout != VK_LAYOUT_SIGNED9) return fail(e, VK_E_INVALID_ARG, "VK_ALGO_TREE needs VK_LAYOUT_SIGNED9 (nine windows)");
+        e->algo = opts->algo;
+    }
     if (opts && opts->batch) {
         if (opts->batch > 1024) return fail(e, VK_E_INVALID_ARG, "batch must be <= 1024");
         e->batch = opts->batch;
@@ -263,7 +269,7 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     HIPCHK(e, hipMemcpy(e->d_wins, e->wins, sizeof e->wins, hipMemcpyHostToDevice));
     // batch-inversion workspace for the full grid, once (a multi-GB hipMalloc inside a sweep call costs seconds);
     // run_range only grows it for specs whose slots per input exceed the batch
-    e->work_bytes = (size_t)e->cu_count * e->blocks_per_cu * VK_BLOCK * e->batch * 8 * sizeof(uint4);
+    e->work_bytes = (size_t)e->cu_count * e->blocks_per_cu * VK_BLOCK * e->batch * (e->algo == VK_ALGO_TREE ? 19 : 8) * sizeof(uint4);
     HIPCHK(e, hipMalloc(&e->work, e->work_bytes));
     // the k*G table: affine points (64 B each), built on the device window by window in two phases
     HIPCHK(e, hipMalloc(&e->table, e->table_entries * 64));
@@ -406,7 +412,8 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     const u64 tile_inputs = (u64)VK_BLOCK * R;
     const u64 ntiles = span / tile_inputs + 1;
     const u32 grid = (u32)std::min<u64>(ntiles, max_grid);
-    const size_t need = (size_t)grid * VK_BLOCK * B * 8 * sizeof(uint4);
+    const bool tree = e->algo == VK_ALGO_TREE && (kind == VK_T_MILKSAD || kind == VK_T_RAWKEYS || kind == VK_T_LCG);
+    const size_t need = (size_t)grid * VK_BLOCK * B * (tree ? 19 : 8) * sizeof(uint4);
     if (need > e->work_bytes) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         if (e->work) HIPCHK(e, hipFree(e->work));
@@ -451,7 +458,9 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     p.out_pub = io.out_pub;
 
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    if (!(vk_launch_sweep_g0(kind, p, grid, e->stream) || vk_launch_sweep_g1(kind, p, grid, e->stream) ||
+    if (tree) {
+        if (!vk_launch_sweep_tree(kind, p, grid, e->stream)) return fail(e, VK_E_UNSUPPORTED, "transform kind not built for VK_ALGO_TREE");
+    } else if (!(vk_launch_sweep_g0(kind, p, grid, e->stream) || vk_launch_sweep_g1(kind, p, grid, e->stream) ||
           vk_launch_sweep_g2(kind, p, grid, e->stream) || vk_launch_sweep_g3(kind, p, grid, e->stream)))
         return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
     HIPCHK(e, hipGetLastError());

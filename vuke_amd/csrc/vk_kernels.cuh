@@ -142,6 +142,10 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
     const u64 nth = VK_BLOCK;
     uint4 *wk = p.work + (u64)blockIdx.x * ((u64)B * 8 * VK_BLOCK) + tid;
     __shared__ u64 s_tile;
+#ifdef VK_COOP_GATHER
+    __shared__ uint4 s_gather[VK_BLOCK * VK_GTILE_STRIDE]; // one 64-entry tile per wave (quad_gather_commit)
+    uint4 *gtile = s_gather + (tid & ~63u) * VK_GTILE_STRIDE;
+#endif
 
 #pragma unroll 1
     for (;;) {
@@ -160,6 +164,21 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
             const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
             u32 kw[8];
             jac P;
+#ifdef VK_COOP_GATHER
+            {
+                const bool have = item_key<KIND>(kw, p, off, sub);
+                u32 k[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) k[i] = have ? kw[7 - i] : (i == 0 ? 1u : 0u); // lanes without a key walk the table with k = 1
+                scalar_normalize(k);
+                ecmult_table_coop(P, k, p.table, p.wins, p.nwin, gtile);
+                if (!have) {
+                    fe_set_zero(P.x);
+                    fe_set_zero(P.y);
+                    fe_set_one(P.z);
+                }
+            }
+#else
             if (item_key<KIND>(kw, p, off, sub)) {
                 u32 k[8];
 #pragma unroll
@@ -171,6 +190,7 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
                 fe_set_zero(P.y);
                 fe_set_one(P.z);
             }
+#endif
             if (b == 0) c = P.z;
             else fe_mul(c, c, P.z);
             uint4 *it = wk + (u64)b * 8 * nth;

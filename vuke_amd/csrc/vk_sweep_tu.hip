@@ -2,9 +2,12 @@
 // heavy translation units build side by side (build.sh).
 #include "../../include/vuke_hip.h"
 #include "vk_sweep_launch.h"
+#if VK_SWEEP_GROUP == 4
+#include "vk_sweep_tree.cuh"
+#endif
 
 #ifndef VK_SWEEP_GROUP
-#error "compile with -DVK_SWEEP_GROUP=0..3"
+#error "compile with -DVK_SWEEP_GROUP=0..4"
 #endif
 
 template <u32 KIND>
@@ -45,6 +48,21 @@ bool vk_launch_sweep_g2(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_
     case VK_T_LCG: launch<VK_T_LCG>(p, grid, s); return true;
     case VK_T_XORSHIFT: launch<VK_T_XORSHIFT>(p, grid, s); return true;
     case VK_T_SHA256_CHAIN: launch<VK_T_SHA256_CHAIN>(p, grid, s); return true;
+    default: return false;
+    }
+}
+#elif VK_SWEEP_GROUP == 4
+template <u32 KIND>
+static void launch_tree(const vk_sweep_params &p, u32 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(vk_sweep_tree_kernel<KIND>, dim3(grid), dim3(VK_BLOCK), 0, s, p);
+}
+bool vk_launch_sweep_tree(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s)
+{
+    switch (kind) {
+    case VK_T_MILKSAD: launch_tree<VK_T_MILKSAD>(p, grid, s); return true;
+    case VK_T_RAWKEYS: launch_tree<VK_T_RAWKEYS>(p, grid, s); return true;
+    case VK_T_LCG: launch_tree<VK_T_LCG>(p, grid, s); return true;
     default: return false;
     }
 }
