@@ -218,7 +218,7 @@ def main():
                 "keys_per_launch": per_launch_keys,
                 **extra,
                 "table_gathers_per_s": eng.info()["windows"] * per_launch_keys / per_launch_s,
-                "table_gather_ceiling_per_s": 19.5e9,  # random 64-B reads, profiles/r01_gather_ceiling.txt (tools/gather_bench.hip)
+                "table_gather_ceiling_per_s": 48.5e9,  # random 64-B entries, quad-cooperative reads landing in LDS (tools/lds_gather_test.hip, profiles/r01_table_read_experiments.txt)
                 **({"executed_tops": extra["valu_insts_per_key"] * per_launch_keys / per_launch_s / 1e12,
                     "executed_frac": extra["valu_insts_per_key"] * per_launch_keys / per_launch_s / PEAK_INT32}
                    if "valu_insts_per_key" in extra else {}),

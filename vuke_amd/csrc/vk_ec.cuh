@@ -199,6 +199,59 @@ VK_DEV void quad_gather_commit(fe &x, fe &y, const quad_regs &v, uint4 *tile)
     y.v[4] = d.x; y.v[5] = d.y; y.v[6] = d.z; y.v[7] = d.w;
 }
 
+// ---- the same reads landing in LDS directly (global_load_lds_dwordx4) ------------------------------------------------
+// No staging registers: the load unit writes lane i's 16 bytes to slot + 16 i.  Round r of a whole-entry read fetches,
+// in lane L, quarter L & 3 of the entry owned by quad lane r; the owner then finds its 64 bytes contiguous in round
+// (lane & 3) at lanes (lane & ~3) .. +3.  The x-only read does the same with lane pairs and halves of x.  A round is 65
+// uint4 (64 lanes + one of padding, so that the owners' 16-byte reads of sixteen consecutive lanes hit distinct banks).
+// slot must be wave-uniform; every lane of the wave takes part.  The data is in LDS once the wave's vmcnt has drained
+// past the reads (the compiler tracks that); before re-using a slot the previous ds_reads must have returned
+// (lds_gather_reuse_fence).
+#define VK_LTILE_ROUND 65
+#define VK_LTILE_FULL (4 * VK_LTILE_ROUND) /* uint4 per whole-entry slot */
+#define VK_LTILE_X (2 * VK_LTILE_ROUND)    /* uint4 per x-only slot */
+typedef const void __attribute__((address_space(1))) *vk_gptr;
+typedef void __attribute__((address_space(3))) *vk_lptr;
+VK_DEV void lds_gather_reuse_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+VK_DEV void lds_gather_issue(uint4 *slot, const uint4 *__restrict__ table, u32 entry)
+{
+    const u32 q = threadIdx.x & 3u;
+    const u32 e0 = __builtin_amdgcn_update_dpp(0u, entry, 0x00, 0xF, 0xF, false);
+    const u32 e1 = __builtin_amdgcn_update_dpp(0u, entry, 0x55, 0xF, 0xF, false);
+    const u32 e2 = __builtin_amdgcn_update_dpp(0u, entry, 0xAA, 0xF, 0xF, false);
+    const u32 e3 = __builtin_amdgcn_update_dpp(0u, entry, 0xFF, 0xF, 0xF, false);
+    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e0 << 2) + q), (vk_lptr)(slot + 0 * VK_LTILE_ROUND), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e1 << 2) + q), (vk_lptr)(slot + 1 * VK_LTILE_ROUND), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e2 << 2) + q), (vk_lptr)(slot + 2 * VK_LTILE_ROUND), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e3 << 2) + q), (vk_lptr)(slot + 3 * VK_LTILE_ROUND), 16, 0, 0);
+}
+VK_DEV void lds_gather_read(fe &x, fe &y, const uint4 *slot)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const uint4 *m = slot + (lane & 3u) * VK_LTILE_ROUND + (lane & ~3u);
+    const uint4 a = m[0], b = m[1], c = m[2], d = m[3];
+    x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
+    x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+    y.v[0] = c.x; y.v[1] = c.y; y.v[2] = c.z; y.v[3] = c.w;
+    y.v[4] = d.x; y.v[5] = d.y; y.v[6] = d.z; y.v[7] = d.w;
+}
+VK_DEV void lds_gather_issue_x(uint4 *slot, const uint4 *__restrict__ table, u32 entry)
+{
+    const u32 h = threadIdx.x & 1u;
+    const u32 e0 = __builtin_amdgcn_update_dpp(0u, entry, 0xA0, 0xF, 0xF, false); // quad_perm [0, 0, 2, 2]
+    const u32 e1 = __builtin_amdgcn_update_dpp(0u, entry, 0xF5, 0xF, 0xF, false); // quad_perm [1, 1, 3, 3]
+    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e0 << 2) + h), (vk_lptr)(slot + 0 * VK_LTILE_ROUND), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e1 << 2) + h), (vk_lptr)(slot + 1 * VK_LTILE_ROUND), 16, 0, 0);
+}
+VK_DEV void lds_gather_read_x(fe &x, const uint4 *slot)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const uint4 *m = slot + (lane & 1u) * VK_LTILE_ROUND + (lane & ~1u);
+    const uint4 a = m[0], b = m[1];
+    x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
+    x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+}
+
 // ecmult_table with cooperative reads: the whole wave calls it (lanes without a key pass k = 1)
 VK_DEV void ecmult_table_coop(jac &acc, const u32 k[8], const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin, uint4 *tile)
 {
@@ -315,4 +368,58 @@ VK_DEV void jac_to_affine(fe &x, fe &y, const jac &p, const fe &zinv)
     fe_mul(y, p.y, zi3);
     fe_canon(x);
     fe_canon(y);
+}
+
+// ecmult_table with the reads landing in LDS directly (the whole wave calls it; lanes without a key pass k = 1).
+// VK_LDS_DEPTH reads are in flight per lane: slots = this wave's VK_LDS_DEPTH x VK_LTILE_FULL uint4, used as a ring.
+#ifndef VK_LDS_DEPTH
+#define VK_LDS_DEPTH 1 /* power of two; 2 and 4 measured 0.4 % slower than 1: the latency is covered, the gain is the cheaper miss path */
+#endif
+VK_DEV void ecmult_table_lds(jac &acc, const u32 k[8], const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin, uint4 *slots)
+{
+    bool inf = true, zone = false;
+    fe_set_zero(acc.x);
+    fe_set_zero(acc.y);
+    fe_set_one(acc.z);
+    u32 carry = 0;
+    u32 dq[VK_LDS_DEPTH];
+    bool nq[VK_LDS_DEPTH];
+    lds_gather_reuse_fence();
+#pragma unroll
+    for (u32 i = 0; i < VK_LDS_DEPTH; i++) { // nwin >= VK_LDS_DEPTH for every layout
+        dq[i] = window_digit(k, wins[i], carry, nq[i]);
+        lds_gather_issue(slots + i * VK_LTILE_FULL, table, (u32)(wins[i].base + dq[i]));
+    }
+#pragma unroll 1
+    for (u32 w = 0; w < nwin; w++) {
+        uint4 *slot = slots + (w & (VK_LDS_DEPTH - 1)) * VK_LTILE_FULL;
+        fe cx, cy;
+        lds_gather_read(cx, cy, slot);
+        const u32 cd = dq[0];
+        const bool cneg = nq[0];
+#pragma unroll
+        for (u32 i = 0; i + 1 < VK_LDS_DEPTH; i++) {
+            dq[i] = dq[i + 1];
+            nq[i] = nq[i + 1];
+        }
+        if (w + VK_LDS_DEPTH < nwin) {
+            dq[VK_LDS_DEPTH - 1] = window_digit(k, wins[w + VK_LDS_DEPTH], carry, nq[VK_LDS_DEPTH - 1]);
+            lds_gather_reuse_fence();
+            lds_gather_issue(slot, table, (u32)(wins[w + VK_LDS_DEPTH].base + dq[VK_LDS_DEPTH - 1]));
+        }
+        if (cd != 0) {
+            fe_cond_negate(cy, cneg);
+            if (inf) {
+                acc.x = cx;
+                acc.y = cy;
+                inf = false;
+                zone = true;
+            } else if (zone) {
+                jac_aadd(acc, acc.x, acc.y, cx, cy);
+                zone = false;
+            } else {
+                jac_madd(acc, acc, cx, cy);
+            }
+        }
+    }
 }

@@ -25,6 +25,12 @@
 #define VK_F_EMIT 0x10000u /* internal: generate-mode records */
 
 #define VK_BLOCK 256
+// How the sweep reads its table entries: 0 = every lane loads its own 64 bytes, 1 = quad-cooperative loads handed over
+// through an LDS tile, 2 = quad-cooperative loads landing in LDS directly (global_load_lds_dwordx4).  Same-box A/B on the
+// Milksad sweep: 2 is 1.4 % faster than 0, 1 is slower than 0 (tools/README.md).
+#ifndef VK_COOP_GATHER
+#define VK_COOP_GATHER 2
+#endif
 #ifndef VK_SWEEP_WAVES
 #define VK_SWEEP_WAVES 2 /* minimum waves per SIMD the sweep kernel is register-budgeted for */
 #endif
@@ -142,7 +148,10 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
     const u64 nth = VK_BLOCK;
     uint4 *wk = p.work + (u64)blockIdx.x * ((u64)B * 8 * VK_BLOCK) + tid;
     __shared__ u64 s_tile;
-#ifdef VK_COOP_GATHER
+#if VK_COOP_GATHER == 2
+    __shared__ uint4 s_gather[(VK_BLOCK / 64) * VK_LDS_DEPTH * VK_LTILE_FULL]; // whole-entry slots per wave (lds_gather_issue)
+    uint4 *gtile = s_gather + (tid >> 6) * (VK_LDS_DEPTH * VK_LTILE_FULL);
+#elif VK_COOP_GATHER == 1
     __shared__ uint4 s_gather[VK_BLOCK * VK_GTILE_STRIDE]; // one 64-entry tile per wave (quad_gather_commit)
     uint4 *gtile = s_gather + (tid & ~63u) * VK_GTILE_STRIDE;
 #endif
@@ -164,14 +173,18 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
             const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
             u32 kw[8];
             jac P;
-#ifdef VK_COOP_GATHER
+#if VK_COOP_GATHER
             {
                 const bool have = item_key<KIND>(kw, p, off, sub);
                 u32 k[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) k[i] = have ? kw[7 - i] : (i == 0 ? 1u : 0u); // lanes without a key walk the table with k = 1
                 scalar_normalize(k);
+#if VK_COOP_GATHER == 2
+                ecmult_table_lds(P, k, p.table, p.wins, p.nwin, gtile);
+#else
                 ecmult_table_coop(P, k, p.table, p.wins, p.nwin, gtile);
+#endif
                 if (!have) {
                     fe_set_zero(P.x);
                     fe_set_zero(P.y);
