@@ -197,6 +197,22 @@ int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words /* 16384 bytes */);
  * analyzer takes one (src/analyze/multibit.rs:47-52).  At most 96 bytes; stays set until changed. */
 int vk_multibit_passphrase_set(vk_engine *e, const uint8_t *passphrase, size_t len);
 
+/* BitimageTransform::apply_batch once the caller has reduced every file to its entropy = SHA-256(base64(file bytes))
+ * (src/bitimage.rs:38-44; file-size-bound host work).  Per (file, passphrase): entropy -> 24-word BIP-39 mnemonic ->
+ * PBKDF2-HMAC-SHA512(mnemonic, "mnemonic" || passphrase, 2048) -> HMAC-SHA512("Bitcoin seed") -> CKDpriv along `path`
+ * (src/bitimage.rs:45-74,119-275), then `count` keys whose last path index is index, index + 1, ... as
+ * BitimageTransform::derive_keys_for_passphrase walks increment_path_index (src/transform/bitimage.rs:71-97,
+ * src/bitimage.rs:277-293).  path[i] = index | 0x80000000 for hardened components; depth = 0 is "m" (count copies of
+ * the master key); depth <= 16.  Passphrases: n_pass >= 1 strings in pass_data[pass_offsets[j] .. pass_offsets[j+1]),
+ * each at most 256 bytes (the single --bitimage-passphrase, possibly empty, or the lines of the passphrase wordlist).
+ * keys_out = n_files * n_pass * count * 32 bytes in (file, passphrase, index) order; valid = one byte per key, 0 where
+ * the reference emits nothing: any error of derive_path (parent key 0 or >= n, IL >= n, child key 0, last index
+ * reaching 2^31) -- and every later index of that (file, passphrase), because the reference does not advance the path
+ * after a failure.  Needs vk_bip39_wordlist_set. */
+int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy /* n_files*32 */, size_t n_files, const uint8_t *pass_data,
+                     const uint32_t *pass_offsets /* n_pass+1 */, size_t n_pass, const uint32_t *path, uint32_t depth,
+                     uint32_t count, uint8_t *keys_out, uint8_t *valid);
+
 /* Transform::apply_batch for string inputs (Input::from_string; wordlist / stdin sources).  String i is
  * data[offsets[i] .. offsets[i+1]).  slots = vk_slots_per_string(t): the hash transforms (sha256, double_sha256, md5,
  * direct) and armory emit one key per string of any length, sha256_chain variants x depth, VK_T_ELECTRUM (strings up to 64

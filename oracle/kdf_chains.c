@@ -4,6 +4,7 @@
  */
 #include "vko.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 static int is_hex_string(const uint8_t *s, size_t n)
@@ -191,4 +192,180 @@ int vko_multibit_label(const char *mnemonic, uint32_t index, char *out, size_t c
     if (n <= 4) return snprintf(out, cap, "%s[m/0'/0/%u]", mnemonic, index);
     return snprintf(out, cap, "%.*s %.*s...%.*s %.*s[m/0'/0/%u]", (int)wl_[0], w[0], (int)wl_[1], w[1], (int)wl_[n - 2], w[n - 2],
                     (int)wl_[n - 1], w[n - 1], index);
+}
+
+/* ==============================================================================================
+ * Bitimage: file -> base64 -> SHA-256 -> BIP-39 mnemonic -> BIP-32 path (reference src/bitimage.rs:38-293,
+ * src/transform/bitimage.rs:71-128).  The word list is an input, as above.
+ * ============================================================================================ */
+/* base64 STANDARD engine: RFC 4648 alphabet with '=' padding.  out needs 4 * ceil(n / 3) bytes. */
+size_t vko_base64(const uint8_t *data, size_t n, char *out)
+{
+    static const char A[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    size_t o = 0, i = 0;
+    for (; i + 3 <= n; i += 3) {
+        uint32_t v = ((uint32_t)data[i] << 16) | ((uint32_t)data[i + 1] << 8) | data[i + 2];
+        out[o++] = A[v >> 18]; out[o++] = A[(v >> 12) & 63]; out[o++] = A[(v >> 6) & 63]; out[o++] = A[v & 63];
+    }
+    if (n - i == 1) {
+        uint32_t v = (uint32_t)data[i] << 16;
+        out[o++] = A[v >> 18]; out[o++] = A[(v >> 12) & 63]; out[o++] = '='; out[o++] = '=';
+    } else if (n - i == 2) {
+        uint32_t v = ((uint32_t)data[i] << 16) | ((uint32_t)data[i + 1] << 8);
+        out[o++] = A[v >> 18]; out[o++] = A[(v >> 12) & 63]; out[o++] = A[(v >> 6) & 63]; out[o++] = '=';
+    }
+    return o;
+}
+
+/* from_file_bytes, first half (:38-44): entropy = SHA-256 of the base64 text of the file */
+int vko_bitimage_entropy(const uint8_t *data, size_t n, uint8_t out[32])
+{
+    char *b = (char *)malloc(4 * ((n + 2) / 3) + 1);
+    if (!b) return 0;
+    size_t bl = vko_base64(data, n, b);
+    vko_sha256((const uint8_t *)b, bl, out);
+    free(b);
+    return 1;
+}
+
+/* entropy_to_mnemonic (:119-148): elen * 8 bits + elen / 4 checksum bits, 11 per word, words joined by one space */
+size_t vko_bip39_mnemonic(const char *const *wl, const uint8_t *entropy, size_t elen, char *out, size_t cap)
+{
+    uint8_t bits[64 + 4], h[32];
+    if (elen > 64 || elen % 4) return 0;
+    vko_sha256(entropy, elen, h);
+    memcpy(bits, entropy, elen);
+    memcpy(bits + elen, h, 4);
+    size_t nbits = elen * 8 + elen * 8 / 32, o = 0;
+    for (size_t i = 0; i < nbits / 11; i++) {
+        uint32_t idx = 0;
+        for (int j = 0; j < 11; j++) {
+            size_t b = i * 11 + j;
+            idx = (idx << 1) | ((bits[b / 8] >> (7 - b % 8)) & 1u);
+        }
+        size_t wlen = strlen(wl[idx]);
+        if (o + wlen + 2 > cap) return 0;
+        if (i) out[o++] = ' ';
+        memcpy(out + o, wl[idx], wlen);
+        o += wlen;
+    }
+    out[o] = 0;
+    return o;
+}
+
+/* parse_derivation_path (:77-117).  comps[i] = index | 0x80000000 when hardened.  Returns the depth, -1 for
+ * "Path must start with 'm/' or be 'm'", -2 for "Invalid index", -3 for "exceeds BIP32 limit", -4 if cap is too small. */
+int vko_bip32_parse_path(const char *path, uint32_t *comps, int cap)
+{
+    /* str::trim: Unicode White_Space; the ASCII members are enough for a command-line argument */
+    size_t b = 0, e = strlen(path);
+    while (b < e && (path[b] == ' ' || (path[b] >= 9 && path[b] <= 13))) b++;
+    while (e > b && (path[e - 1] == ' ' || (path[e - 1] >= 9 && path[e - 1] <= 13))) e--;
+    size_t n = e - b;
+    const char *p = path + b;
+    if (n == 1 && p[0] == 'm') return 0;
+    if (n < 2 || p[0] != 'm' || p[1] != '/') return -1;
+    int depth = 0;
+    size_t i = 2;
+    while (i <= n) { /* split('/') over p[2..n): a trailing '/' yields one empty component */
+        size_t s = i;
+        while (i < n && p[i] != '/') i++;
+        size_t len = i - s;
+        i++;
+        if (len == 0) continue;
+        int hardened = p[s + len - 1] == '\'' || p[s + len - 1] == 'h';
+        if (hardened) len--;
+        /* u32::from_str: optional '+', then at least one ASCII digit, no overflow */
+        size_t d = s;
+        if (d < s + len && p[d] == '+') d++;
+        if (d == s + len) return -2;
+        uint64_t v = 0;
+        for (; d < s + len; d++) {
+            if (p[d] < '0' || p[d] > '9') return -2;
+            v = v * 10 + (uint64_t)(p[d] - '0');
+            if (v > 0xFFFFFFFFull) return -2;
+        }
+        if (v >= 0x80000000ull) return -3;
+        if (depth >= cap) return -4;
+        comps[depth++] = (uint32_t)v | (hardened ? 0x80000000u : 0u);
+    }
+    return depth;
+}
+
+/* increment_path_index (:277-293): text in, text out (the label carries it) */
+size_t vko_bip32_increment_path(const char *path, char *out, size_t cap)
+{
+    size_t n = strlen(path);
+    const char *slash = strrchr(path, '/');
+    if (slash) {
+        size_t pre = (size_t)(slash - path) + 1, sl = n - pre;
+        const char *suf = path + pre;
+        const char *marker = "";
+        char mk[2] = {0, 0};
+        if (sl && (suf[sl - 1] == '\'' || suf[sl - 1] == 'h')) {
+            mk[0] = suf[sl - 1];
+            marker = mk;
+            sl--;
+        }
+        size_t d = 0;
+        if (d < sl && suf[d] == '+') d++;
+        int ok = d < sl;
+        uint64_t v = 0;
+        for (; ok && d < sl; d++) {
+            if (suf[d] < '0' || suf[d] > '9') ok = 0;
+            else {
+                v = v * 10 + (uint64_t)(suf[d] - '0');
+                if (v > 0xFFFFFFFFull) ok = 0;
+            }
+        }
+        if (ok) return (size_t)snprintf(out, cap, "%.*s%u%s", (int)pre, path, (uint32_t)(v + 1), marker); /* wraps like release-mode u32 */
+    }
+    return (size_t)snprintf(out, cap, "%s", path);
+}
+
+/* seed_to_master_key + derive_path (:50-74, 180-275): 1 and key = the private key, 0 on any error of the walk */
+int vko_bip32_derive(const uint8_t seed[64], const uint32_t *comps, int depth, uint8_t key[32])
+{
+    uint8_t I[64], k[32], c[32], ck[32], cc[32];
+    vko_hmac_sha512((const uint8_t *)"Bitcoin seed", 12, seed, 64, I);
+    memcpy(k, I, 32);
+    memcpy(c, I + 32, 32);
+    for (int i = 0; i < depth; i++) {
+        if (!ckd(k, c, comps[i] & 0x7FFFFFFFu, (comps[i] >> 31) != 0, ck, cc)) return 0;
+        memcpy(k, ck, 32);
+        memcpy(c, cc, 32);
+    }
+    memcpy(key, k, 32);
+    return 1;
+}
+
+/* BitimageTransform::derive_keys_for_passphrase for one (entropy, passphrase) (src/transform/bitimage.rs:71-97): keys =
+ * count * 32, valid = count.  path = the text form; labels are not built here (vko_bip32_increment_path gives the text).
+ * Returns the number of keys emitted. */
+uint32_t vko_bitimage_keys(const char *const *wl, const uint8_t entropy[32], const uint8_t *pass, size_t passlen, const char *path,
+                           uint32_t count, uint8_t *keys, uint8_t *valid)
+{
+    char mn[512], cur[512], nxt[512];
+    uint8_t salt[8 + 1024], seed[64];
+    uint32_t emitted = 0;
+    memset(valid, 0, count);
+    if (passlen > 1024 || strlen(path) >= sizeof cur - 16) return 0;
+    size_t ml = vko_bip39_mnemonic(wl, entropy, 32, mn, sizeof mn);
+    if (!ml) return 0;
+    memcpy(salt, "mnemonic", 8);
+    memcpy(salt + 8, pass, passlen);
+    vko_pbkdf2_hmac_sha512((const uint8_t *)mn, ml, salt, 8 + passlen, 2048, seed, 64);
+    snprintf(cur, sizeof cur, "%s", path);
+    for (uint32_t i = 0; i < count; i++) {
+        uint32_t comps[64];
+        int depth = vko_bip32_parse_path(cur, comps, 64);
+        if (depth < 0 || !vko_bip32_derive(seed, comps, depth, keys + 32 * i)) continue; /* Err(_) => continue: the path is NOT advanced */
+        valid[i] = 1;
+        emitted++;
+        if (i + 1 < count) {
+            vko_bip32_increment_path(cur, nxt, sizeof nxt);
+            memcpy(cur, nxt, sizeof cur);
+        }
+    }
+    return emitted;
 }

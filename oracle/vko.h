@@ -112,6 +112,16 @@ int vko_multibit_keys_pass(const char *const *wl, const uint8_t *mnemonic, size_
                            uint8_t *keys, uint8_t *valid, uint8_t seed1_out[64], uint8_t seed2_out[64]);
 int vko_multibit_label(const char *mnemonic, uint32_t index, char *out, size_t cap);
 
+/* Bitimage (src/bitimage.rs, src/transform/bitimage.rs): file -> base64 -> SHA-256 -> BIP-39 -> BIP-32 path */
+size_t vko_base64(const uint8_t *data, size_t n, char *out);
+int vko_bitimage_entropy(const uint8_t *data, size_t n, uint8_t out[32]);
+size_t vko_bip39_mnemonic(const char *const *wl, const uint8_t *entropy, size_t elen, char *out, size_t cap);
+int vko_bip32_parse_path(const char *path, uint32_t *comps, int cap);
+size_t vko_bip32_increment_path(const char *path, char *out, size_t cap);
+int vko_bip32_derive(const uint8_t seed[64], const uint32_t *comps, int depth, uint8_t key[32]);
+uint32_t vko_bitimage_keys(const char *const *wl, const uint8_t entropy[32], const uint8_t *pass, size_t passlen, const char *path,
+                           uint32_t count, uint8_t *keys, uint8_t *valid);
+
 /* ------------------------------------------------------- secp256k1/derive */
 /* src/derive.rs:79-93: valid iff 1 <= k < n, else k mod n, 0 -> 1. */
 void vko_normalize_key(const uint8_t in[32], uint8_t out[32]);

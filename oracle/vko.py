@@ -103,6 +103,17 @@ def lib():
         L.vko_multibit_keys.argtypes = [C.POINTER(cp), cp, sz, u32, cp, cp, cp, cp]
         L.vko_multibit_label.argtypes = [cp, u32, cp, sz]
         L.vko_multibit_keys_pass.argtypes = [C.POINTER(cp), cp, sz, cp, sz, u32, cp, cp, cp, cp]
+        L.vko_base64.argtypes = [cp, sz, cp]
+        L.vko_base64.restype = sz
+        L.vko_bitimage_entropy.argtypes = [cp, sz, cp]
+        L.vko_bip39_mnemonic.argtypes = [C.POINTER(cp), cp, sz, cp, sz]
+        L.vko_bip39_mnemonic.restype = sz
+        L.vko_bip32_parse_path.argtypes = [cp, C.POINTER(u32), C.c_int]
+        L.vko_bip32_increment_path.argtypes = [cp, cp, sz]
+        L.vko_bip32_increment_path.restype = sz
+        L.vko_bip32_derive.argtypes = [cp, C.POINTER(u32), C.c_int, cp]
+        L.vko_bitimage_keys.argtypes = [C.POINTER(cp), cp, cp, sz, cp, u32, cp, cp]
+        L.vko_bitimage_keys.restype = u32
         L.vko_milksad_draws.argtypes = [u32, u32, cp]
         L.vko_mt64_draws.argtypes = [u64, u32, cp]
         L.vko_search.argtypes = [C.POINTER(Spec), u64, u64, u32, cp, u32, cp, C.POINTER(u64), C.POINTER(u64), cp, C.POINTER(u32)]
@@ -318,6 +329,59 @@ def multibit_keys(wl, mnemonic, count=20, passphrase=b""):
             lib().vko_multibit_label(m, i, lab, 700)
             out.append((lab.value.decode(), keys.raw[32 * i:32 * i + 32]))
     return s1.raw, s2.raw, out
+
+
+def base64_text(data):
+    o = _out(4 * ((len(data) + 2) // 3) + 1)
+    n = lib().vko_base64(data, len(data), o)
+    return o.raw[:n]
+
+
+def bitimage_entropy(data):
+    """SHA-256 of the base64 text of the file bytes (BitimageDeriver::from_file_bytes, first half)."""
+    o = _out(32)
+    assert lib().vko_bitimage_entropy(data, len(data), o)
+    return o.raw
+
+
+def bip39_mnemonic(wl, entropy):
+    o = _out(1024)
+    n = lib().vko_bip39_mnemonic(wl.arr, entropy, len(entropy), o, 1024)
+    return o.raw[:n].decode()
+
+
+def bip32_parse_path(path):
+    """Component list (index | 0x80000000 when hardened) or a negative error code (-1 prefix, -2 index, -3 limit)."""
+    comps = (C.c_uint32 * 64)()
+    d = lib().vko_bip32_parse_path(path.encode() if isinstance(path, str) else path, comps, 64)
+    return d if d < 0 else [comps[i] for i in range(d)]
+
+
+def bip32_increment_path(path):
+    o = _out(600)
+    n = lib().vko_bip32_increment_path(path.encode(), o, 600)
+    return o.raw[:n].decode()
+
+
+def bip32_derive(seed64, comps):
+    arr = (C.c_uint32 * max(1, len(comps)))(*comps)
+    o = _out(32)
+    return o.raw if lib().vko_bip32_derive(seed64, arr, len(comps), o) else None
+
+
+def bitimage_keys(wl, entropy, passphrase=b"", path="m/84'/0'/0'/0/0", count=1):
+    """BitimageTransform::derive_keys_for_passphrase for one (file entropy, passphrase): [(path text, key)] in order."""
+    pw = passphrase.encode() if isinstance(passphrase, str) else passphrase
+    keys, valid = _out(32 * count), _out(count)
+    lib().vko_bitimage_keys(wl.arr, entropy, pw, len(pw), path.encode(), count, keys, valid)
+    out, cur = [], path
+    for i in range(count):
+        if not valid.raw[i]:
+            continue
+        out.append((cur, keys.raw[32 * i:32 * i + 32]))
+        if i + 1 < count:
+            cur = bip32_increment_path(cur)
+    return out
 
 
 def normalize_key(k): o = _out(32); lib().vko_normalize_key(k, o); return o.raw

@@ -83,3 +83,44 @@ def armory_key(seed: bytes):
             return None
         k = k * s % N
     return k.to_bytes(32, "big")
+
+
+def bip32_ckd(k: bytes, c: bytes, index: int, hardened: bool):
+    """CKDpriv in python ints + hmac (BIP-32): None where a libsecp256k1 caller would see an error."""
+    import hmac
+    ki = int.from_bytes(k, "big")
+    if not 0 < ki < N:
+        return None
+    idx = (index | 0x80000000) if hardened else index
+    data = (b"\0" + k if hardened else pubkeys(ki)[0]) + idx.to_bytes(4, "big")
+    I = hmac.new(c, data, hashlib.sha512).digest()
+    il = int.from_bytes(I[:32], "big")
+    if il >= N or (il + ki) % N == 0:
+        return None
+    return ((il + ki) % N).to_bytes(32, "big"), I[32:]
+
+
+def bip32_path(seed: bytes, comps):
+    """Master key from a BIP-32 seed, then CKDpriv along comps = [(index, hardened)]."""
+    import hmac
+    I = hmac.new(b"Bitcoin seed", seed, hashlib.sha512).digest()
+    k, c = I[:32], I[32:]
+    for index, hardened in comps:
+        r = bip32_ckd(k, c, index, hardened)
+        if r is None:
+            return None
+        k, c = r
+    return k
+
+
+def bip39_mnemonic(words, entropy: bytes):
+    bits = "".join(f"{b:08b}" for b in entropy) + "".join(f"{b:08b}" for b in hashlib.sha256(entropy).digest())[:len(entropy) // 4]
+    return " ".join(words[int(bits[11 * i:11 * i + 11], 2)] for i in range(len(bits) // 11))
+
+
+def bitimage_key(words, data: bytes, passphrase: bytes, comps):
+    """file bytes -> base64 -> SHA-256 -> BIP-39 mnemonic -> PBKDF2 seed -> BIP-32 path, all from the standard library."""
+    import base64
+    entropy = hashlib.sha256(base64.b64encode(data)).digest()
+    seed = hashlib.pbkdf2_hmac("sha512", bip39_mnemonic(words, entropy).encode(), b"mnemonic" + passphrase, 2048)
+    return bip32_path(seed, comps)

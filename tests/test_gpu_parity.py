@@ -647,3 +647,35 @@ def test_tree_summation_algo(vko):
         assert st["matches"] == 4 and [h["seed"] for h in hits] == planted
     finally:
         e.close()
+
+
+def test_bitimage_chain(eng, vko):
+    """SURVEY section 8 f: Bitimage (file -> base64 -> SHA-256 -> BIP-39 -> BIP-32 path) on the device against the oracle:
+    entropies x passphrases x paths (hardened / normal / "m" / deep / last index at the 2^31 limit), derive_count > 1."""
+    from tests.test_oracle_multibit import synthetic_wordlist
+    import vuke_amd
+    words = synthetic_wordlist()
+    wl = vko.Wordlist(words)
+    eng.bip39_wordlist_set(words)
+    rnd = random.Random(61)
+    files = [b"hello world", b"", b"test data"] + [rnd.randbytes(rnd.randrange(1, 400)) for _ in range(5)]
+    ents = [vko.bitimage_entropy(f) for f in files]
+    ents += [bytes(32), b"\xff" * 32]
+    pws = [b"", b"secret", b"p" * 96, b"q" * 97, b"r" * 130, rnd.randbytes(256), b"TREZOR"]
+    H = 0x80000000
+    for path, count in (("m/84'/0'/0'/0/0", 3), ("m/44'/0'/0'/0/7", 1), ("m", 2), ("m/0", 2), ("m/5'", 2), ("m/1/2/3/4/5/6'/7/8", 1),
+                        ("m/0/2147483646", 4), ("m/0/2147483646'", 3)):
+        comps = vko.bip32_parse_path(path)
+        got = eng.bitimage_keys(ents, pws, comps, count)
+        for fi, e in enumerate(ents):
+            for pj, pw in enumerate(pws):
+                want = [k for _, k in vko.bitimage_keys(wl, e, pw, path, count)]
+                assert [k for k in got[fi][pj] if k is not None] == want, (path, fi, pj)
+                nvalid = len(want)
+                assert all(k is not None for k in got[fi][pj][:nvalid]) and all(k is None for k in got[fi][pj][nvalid:])
+    # argument errors: path too deep, passphrase too long
+    with pytest.raises(vuke_amd.VkError):
+        eng.bitimage_keys(ents[:1], [b""], [0] * 17, 1)
+    with pytest.raises(vuke_amd.VkError):
+        eng.bitimage_keys(ents[:1], [b"x" * 257], [0], 1)
+    assert eng.bitimage_keys([], [b""], [0], 1) == []

@@ -61,7 +61,7 @@ SEARCH_EXACT, SEARCH_MASKED, SEARCH_CASCADE = 0, 1, 2
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
     "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
-    "vk_transform_strings", "vk_scan_keys", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
+    "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
     "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field",
 ]
 
@@ -94,6 +94,7 @@ def load():
     L.vk_transform_batch.argtypes = [vp, C.POINTER(TransformSpec), C.POINTER(u64), sz, vp, vp]
     L.vk_transform_strings.argtypes = [vp, C.POINTER(TransformSpec), cp, C.POINTER(u32), sz, vp, vp]
     L.vk_bip39_wordlist_set.argtypes = [vp, cp]
+    L.vk_bitimage_keys.argtypes = [vp, cp, sz, cp, C.POINTER(u32), sz, C.POINTER(u32), u32, u32, cp, cp]
     L.vk_search.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, C.POINTER(SearchTarget), C.POINTER(SearchResult)]
     L.vk_scan_keys.argtypes = [vp, cp, sz, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_slots_per_input.argtypes = [C.POINTER(TransformSpec)]
@@ -210,6 +211,28 @@ class Engine:
         pw = passphrase.encode() if isinstance(passphrase, str) else passphrase
         self._L.vk_multibit_passphrase_set.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         self._chk(self._L.vk_multibit_passphrase_set(self._e, pw, len(pw)))
+
+    def bitimage_keys(self, entropies, passphrases=(b"",), path=(84 | 1 << 31, 1 << 31, 1 << 31, 0, 0), count=1):
+        """BitimageTransform::apply_batch after the files have been reduced to their entropies (SHA-256 of the base64
+        text): result[file][passphrase] = list of `count` keys (None where the reference emits nothing).
+        path = components, index | 0x80000000 when hardened."""
+        nf, npw = len(entropies), len(passphrases)
+        offs = (C.c_uint32 * (npw + 1))()
+        for i, s in enumerate(passphrases):
+            offs[i + 1] = offs[i] + len(s)
+        comps = (C.c_uint32 * max(1, len(path)))(*path)
+        total = nf * npw * count
+        keys, valid = C.create_string_buffer(max(1, total * 32)), C.create_string_buffer(max(1, total))
+        self._chk(self._L.vk_bitimage_keys(self._e, b"".join(entropies), nf, b"".join(passphrases), offs, npw, comps, len(path), count, keys, valid))
+        rk, rv = keys.raw, valid.raw
+        out = []
+        for f in range(nf):
+            row = []
+            for j in range(npw):
+                base = (f * npw + j) * count
+                row.append([rk[32 * (base + c):32 * (base + c) + 32] if rv[base + c] else None for c in range(count)])
+            out.append(row)
+        return out
 
     def transform_strings(self, spec, strings, raw=False):
         """Transform::apply_batch for string inputs: per input a list of keys (None where nothing is emitted).

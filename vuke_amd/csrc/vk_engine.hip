@@ -798,6 +798,56 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
     return VK_OK;
 }
 
+extern "C" int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy, size_t n_files, const uint8_t *pass_data, const uint32_t *pass_offsets,
+                                size_t n_pass, const uint32_t *path, uint32_t depth, uint32_t count, uint8_t *keys_out, uint8_t *valid)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->d_wordlist) return fail(e, VK_E_INVALID_ARG, "bitimage needs the BIP-39 word list: call vk_bip39_wordlist_set first");
+    if (n_files == 0 || count == 0) return VK_OK;
+    if (!entropy || !pass_offsets || !keys_out || !valid || n_pass == 0) return fail(e, VK_E_INVALID_ARG, "entropy / pass_offsets / keys_out / valid is NULL or n_pass is 0");
+    if (depth > VK_BIP32_MAX_DEPTH) return fail(e, VK_E_UNSUPPORTED, "derivation path deeper than 16 levels");
+    if (depth && !path) return fail(e, VK_E_INVALID_ARG, "path is NULL");
+    for (size_t i = 0; i < n_pass; i++) {
+        if (pass_offsets[i + 1] < pass_offsets[i]) return fail(e, VK_E_INVALID_ARG, "pass_offsets must be non-decreasing");
+        if (pass_offsets[i + 1] - pass_offsets[i] > VK_BITIMAGE_MAX_PASS) return fail(e, VK_E_UNSUPPORTED, "passphrase longer than 256 bytes");
+    }
+    const u64 items = (u64)n_files * n_pass;
+    if (items > (1ull << 28) || items * count > (1ull << 28)) return fail(e, VK_E_INVALID_ARG, "too many keys for one vk_bitimage_keys call (max 2^28)");
+    vk_bip32_path pd = {};
+    pd.depth = depth;
+    for (u32 i = 0; i < depth; i++) pd.comp[i] = path[i];
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t pbytes = pass_offsets[n_pass], outs = (size_t)(items * count);
+    SCRATCH(e, d_pass, unsigned char *, 0, pbytes + 1);
+    SCRATCH(e, d_offs, u32 *, 2, (n_pass + 1) * 4);
+    SCRATCH(e, d_ent, unsigned char *, 3, n_files * 32);
+    SCRATCH(e, d_keys, u32 *, 1, outs * 32);
+    SCRATCH(e, d_valid, unsigned char *, 4, outs);
+    hipError_t c = hipSuccess;
+    if (pbytes) {
+        if (!pass_data) return fail(e, VK_E_INVALID_ARG, "pass_data is NULL");
+        c = hipMemcpy(d_pass, pass_data, pbytes, hipMemcpyHostToDevice);
+    }
+    if (c == hipSuccess) c = hipMemcpy(d_offs, pass_offsets, (n_pass + 1) * 4, hipMemcpyHostToDevice);
+    if (c == hipSuccess) c = hipMemcpy(d_ent, entropy, n_files * 32, hipMemcpyHostToDevice);
+    if (c == hipSuccess) c = hipMemsetAsync(d_keys, 0, outs * 32, e->stream);
+    if (c == hipSuccess) c = hipMemsetAsync(d_valid, 0, outs, e->stream);
+    if (c == hipSuccess) {
+        hipLaunchKernelGGL(vk_bitimage_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_ent, items, d_pass, d_offs,
+                           (u32)n_pass, pd, count, e->d_wordlist, e->table, e->d_wins, e->nwin, d_keys, d_valid);
+        c = hipGetLastError();
+    }
+    if (c == hipSuccess) c = hipStreamSynchronize(e->stream);
+    if (c == hipSuccess) c = hipMemcpy(keys_out, d_keys, outs * 32, hipMemcpyDeviceToHost);
+    if (c == hipSuccess) c = hipMemcpy(valid, d_valid, outs, hipMemcpyDeviceToHost);
+    if (c != hipSuccess) {
+        e->err = std::string("vk_bitimage_keys: ") + hipGetErrorString(c);
+        return VK_E_HIP;
+    }
+    return VK_OK;
+}
+
 extern "C" int vk_scan_keys(vk_engine *e, const uint8_t *keys, size_t n, uint32_t flags, vk_hit *hits, size_t hit_cap, vk_sweep_stats *out)
 {
     if (!e) return VK_E_INVALID_ARG;

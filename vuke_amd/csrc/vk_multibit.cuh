@@ -214,8 +214,10 @@ struct vk_mb_pass {
     unsigned char b[VK_MULTIBIT_MAX_PASS];
 };
 
-// PBKDF2-HMAC-SHA512(password, "mnemonic" || passphrase, 2048, 64 bytes); pw may be overwritten (padding)
-__device__ __noinline__ void pbkdf2_mnemonic(u64 seed[8], unsigned char *pw, u32 pwlen, const vk_mb_pass &pass)
+// PBKDF2-HMAC-SHA512(password, "mnemonic" || passphrase, 2048, 64 bytes); pw may be overwritten (padding).
+// plen <= VK_BITIMAGE_MAX_PASS (salt || INT(1) may span three SHA-512 blocks).
+#define VK_BITIMAGE_MAX_PASS 256
+__device__ __noinline__ void pbkdf2_mnemonic_salt(u64 seed[8], unsigned char *pw, u32 pwlen, const unsigned char *pass, u32 pl)
 {
     u64 ist[8], ost[8];
     unsigned char key[128];
@@ -229,15 +231,20 @@ __device__ __noinline__ void pbkdf2_mnemonic(u64 seed[8], unsigned char *pw, u32
         for (u32 i = 0; i < pwlen; i++) key[i] = pw[i];
     }
     hmac512_init(ist, ost, key, klen);
-    unsigned char salt[128];
+    unsigned char salt[384];
     const char s[8] = {'m', 'n', 'e', 'm', 'o', 'n', 'i', 'c'};
     for (int i = 0; i < 8; i++) salt[i] = (unsigned char)s[i];
-    const u32 pl = pass.len;
-    for (u32 i = 0; i < pl; i++) salt[8 + i] = pass.b[i];
+    for (u32 i = 0; i < pl; i++) salt[8 + i] = pass[i];
     salt[8 + pl] = 0; salt[9 + pl] = 0; salt[10 + pl] = 0; salt[11 + pl] = 1;
     u64 u1[8];
     hmac512_final(u1, ist, ost, salt, 12 + pl);
     pbkdf2_tail_2048(seed, ist, ost, u1);
+}
+VK_DEV void pbkdf2_mnemonic(u64 seed[8], unsigned char *pw, u32 pwlen, const vk_mb_pass &pass)
+{
+    unsigned char pb[VK_MULTIBIT_MAX_PASS];
+    for (u32 i = 0; i < pass.len; i++) pb[i] = pass.b[i];
+    pbkdf2_mnemonic_salt(seed, pw, pwlen, pb, pass.len);
 }
 
 // one CKDpriv step in the reference's spelling; data33 = 0x00 || k (hardened) or serP(K) (normal)
@@ -388,6 +395,137 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_multibit_kernel(const unsigned ch
         u32 ck[8];
         unsigned char cc[32];
         if (!ckd_step(ck, cc, k1, c1, d33, j)) continue;
+#pragma unroll
+        for (int q = 0; q < 8; q++) kout[j * 8 + q] = bswap32(ck[7 - q]);
+        vout[j] = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------ bitimage
+// BitimageDeriver::from_file_bytes after the file has been reduced to its 32 bytes of entropy, then derive_path for
+// derive_count paths that differ in the last index (reference src/bitimage.rs:38-74, src/transform/bitimage.rs:71-97):
+// entropy -> 24-word mnemonic (8 checksum bits) -> PBKDF2 seed -> HMAC("Bitcoin seed") -> CKDpriv along the path.
+// One lane per (file, passphrase); the parent of the last level is derived once.
+#define VK_BIP32_MAX_DEPTH 16
+struct vk_bip32_path {
+    u32 depth;
+    u32 comp[VK_BIP32_MAX_DEPTH]; // bit 31 = hardened
+};
+
+VK_DEV void ckd_parent_data(unsigned char d33[33], const u32 k[8], bool hardened, const uint4 *table, const vk_win_desc *wins, u32 nwin)
+{
+    if (hardened) { // 0x00 || k
+        d33[0] = 0;
+        for (int j = 0; j < 8; j++) {
+            const u32 w = k[7 - j];
+            d33[1 + 4 * j] = (unsigned char)(w >> 24); d33[2 + 4 * j] = (unsigned char)(w >> 16);
+            d33[3 + 4 * j] = (unsigned char)(w >> 8);  d33[4 + 4 * j] = (unsigned char)w;
+        }
+    } else { // serP(K)
+        ser_pubkey(d33, k, table, wins, nwin);
+    }
+}
+
+__global__ void __launch_bounds__(VK_BLOCK) vk_bitimage_kernel(const unsigned char *__restrict__ entropy, u64 n_items, const unsigned char *__restrict__ pass_data,
+                                                                 const u32 *__restrict__ pass_offs, u32 n_pass, const vk_bip32_path path, u32 count,
+                                                                 const u64 *__restrict__ wordlist, const uint4 *__restrict__ table,
+                                                                 const vk_win_desc *__restrict__ wins, u32 nwin, u32 *__restrict__ keys_out,
+                                                                 unsigned char *__restrict__ valid_out)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    if (idx >= n_items) return;
+    const u64 file = idx / n_pass;
+    const u32 pj = (u32)(idx % n_pass);
+    // ---- entropy_to_mnemonic: 256 + 8 bits -> 24 words joined by single spaces
+    unsigned char bits[33];
+    for (int j = 0; j < 32; j++) bits[j] = entropy[file * 32 + j];
+    {
+        unsigned char tmp[128];
+        for (int j = 0; j < 32; j++) tmp[j] = bits[j];
+        u32 h[8];
+        sha256_private(h, tmp, 32);
+        bits[32] = (unsigned char)(h[0] >> 24);
+    }
+    unsigned char buf[640];
+    u32 bl = 0;
+#pragma unroll 1
+    for (u32 w = 0; w < 24; w++) {
+        u32 wi = 0;
+        for (u32 j = 0; j < 11; j++) {
+            const u32 b = w * 11 + j;
+            wi = (wi << 1) | ((bits[b >> 3] >> (7 - (b & 7))) & 1u);
+        }
+        if (w) buf[bl++] = ' ';
+        u64 packed = wordlist[wi];
+        while (packed & 0xff) {
+            buf[bl++] = (unsigned char)packed;
+            packed >>= 8;
+        }
+    }
+    // ---- seed = PBKDF2(mnemonic, "mnemonic" || passphrase); (k, c) = HMAC("Bitcoin seed", seed)
+    u64 seed[8];
+    {
+        unsigned char pb[VK_BITIMAGE_MAX_PASS];
+        const u32 po = pass_offs[pj], pl = pass_offs[pj + 1] - po;
+        for (u32 j = 0; j < pl; j++) pb[j] = pass_data[po + j];
+        pbkdf2_mnemonic_salt(seed, buf, bl, pb, pl);
+    }
+    u64 ist[8], ost[8], I[8];
+    {
+        const char bs[12] = {'B', 'i', 't', 'c', 'o', 'i', 'n', ' ', 's', 'e', 'e', 'd'};
+        unsigned char key[12];
+        for (int j = 0; j < 12; j++) key[j] = (unsigned char)bs[j];
+        hmac512_init(ist, ost, key, 12);
+        unsigned char dat[256];
+        for (int j = 0; j < 8; j++) store_be64(dat + 8 * j, seed[j]);
+        hmac512_final(I, ist, ost, dat, 64);
+    }
+    u32 k[8];
+    unsigned char c[32], d33[33];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        k[7 - 2 * j] = (u32)(I[j] >> 32);
+        k[6 - 2 * j] = (u32)I[j];
+    }
+    for (int j = 0; j < 4; j++) store_be64(c + 8 * j, I[4 + j]);
+    u32 *kout = keys_out + idx * count * 8;
+    unsigned char *vout = valid_out + idx * count;
+    if (path.depth == 0) { // "m": the master key as it is, derive_count times (increment_path_index leaves "m" alone)
+#pragma unroll 1
+        for (u32 j = 0; j < count; j++) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) kout[j * 8 + q] = bswap32(k[7 - q]);
+            vout[j] = 1;
+        }
+        return;
+    }
+    // ---- all levels but the last
+#pragma unroll 1
+    for (u32 d = 0; d + 1 < path.depth; d++) {
+        const u32 comp = path.comp[d];
+        const bool hard = (comp >> 31) != 0;
+        if (!scalar_is_key(k)) return; // SecretKey::from_slice(parent) in scalar_add / private_to_public
+        ckd_parent_data(d33, k, hard, table, wins, nwin);
+        u32 ck[8];
+        unsigned char cc[32];
+        if (!ckd_step(ck, cc, k, c, d33, comp)) return;
+#pragma unroll
+        for (int q = 0; q < 8; q++) k[q] = ck[q];
+        for (int q = 0; q < 32; q++) c[q] = cc[q];
+    }
+    // ---- the last level: index, index + 1, ...; the first failure ends the item (the reference does not advance the
+    // path after a failed derivation, so every later attempt repeats it)
+    const u32 last = path.comp[path.depth - 1];
+    const bool hard = (last >> 31) != 0;
+    if (!scalar_is_key(k)) return;
+    ckd_parent_data(d33, k, hard, table, wins, nwin);
+#pragma unroll 1
+    for (u32 j = 0; j < count; j++) {
+        const u64 index = (u64)(last & 0x7FFFFFFFu) + j;
+        if (index >= 0x80000000ull) return; // "exceeds BIP32 limit"
+        u32 ck[8];
+        unsigned char cc[32];
+        if (!ckd_step(ck, cc, k, c, d33, (u32)index | (last & 0x80000000u))) return;
 #pragma unroll
         for (int q = 0; q < 8; q++) kout[j * 8 + q] = bswap32(ck[7 - q]);
         vout[j] = 1;
