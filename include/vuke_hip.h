@@ -64,6 +64,9 @@ extern "C" {
                                 2 = the string zero padded to 32 bytes (strings longer than 32 bytes emit nothing) */
 #define VK_T_ARMORY 11u       /* src/transform/armory.rs:21-101: root seed -> chaincode -> 4 chained key*G multiplications;
                                 slot 0 seed = SHA256(decimal string), slot 1 seed = 24 zero bytes || 8 BE bytes */
+#define VK_T_BITIMAGE 12u     /* src/bitimage.rs, src/transform/bitimage.rs: BLOB inputs only (file contents) -- the device entry
+                                 point is vk_bitimage_keys; vk_slots_per_input / vk_slots_per_string are 0 (the reference emits
+                                 nothing for numeric or string inputs), every other call rejects the kind */
 #define VK_VARIANT_ALL 0xFFFFFFFFu
 
 typedef struct vk_transform_spec {

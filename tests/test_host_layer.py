@@ -65,7 +65,7 @@ def test_transform_grammar_reference_cases(host):
     assert parse(host, "sha256_chain:iterated:le")[1].startswith("Invalid SHA256 chain format")
     assert parse(host, "nothing")[1].startswith("Unknown transform: nothing. Valid: direct, sha256,")
     assert [parse(host, n)[0][0] for n in ("double_sha256", "md5", "direct", "armory")] == [8, 9, 10, 11]
-    assert parse(host, "bitimage")[0] is None and "outside the device hot path" in parse(host, "bitimage")[1]
+    assert parse(host, "bitimage") == ((12, ALL, 0, 10), "bitimage")              # blob inputs only: vk_bitimage_keys
     assert parse(host, "electrum") == ((6, 0, 0, 20), "electrum")                 # src/transform/mod.rs:180-181
     assert parse(host, "electrum:change") == ((6, 1, 0, 20), "electrum:change")
     assert parse(host, "multibit") == ((7, 0, 0, 20), "multibit")                 # src/transform/mod.rs:178
@@ -309,3 +309,55 @@ def test_storage_output_writes_the_19_column_parquet_record(host, vko, tmp_path,
     assert col("private_key_leading_zeros") == [d.leading_zeros for d in ds]
     now = datetime.datetime.now(datetime.timezone.utc)
     assert all(abs((now - ts).total_seconds()) < 600 for ts in col("timestamp")[::250])
+
+
+def test_bitimage_host_pieces(host):
+    """The host half of Bitimage (src/bitimage.rs:38-44, 77-117, 277-293): streamed base64 + SHA-256 of file bytes against
+    hashlib/base64, parse_derivation_path and increment_path_index against the reference's test cases and, on generated
+    path texts, against the oracle's restatement (same accept / reject decision, same components, same error class)."""
+    import base64
+    import hashlib
+    import random
+    from oracle import vko
+    host.vkh_bitimage_entropy.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+    host.vkh_bitimage_entropy.restype = None
+    rnd = random.Random(77)
+    for n in list(range(0, 200)) + [255, 256, 257, 4095, 4096, 4097, 65536, 100003]:
+        data = rnd.randbytes(n)
+        out = C.create_string_buffer(32)
+        host.vkh_bitimage_entropy(data, n, out)
+        assert out.raw == hashlib.sha256(base64.b64encode(data)).digest(), n
+    host.vkh_parse_derivation_path.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.c_int, C.c_char_p, C.c_size_t]
+    host.vkh_increment_path_index.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    host.vkh_increment_path_index.restype = C.c_size_t
+
+    def parse_path(p):
+        comps, err = (C.c_uint32 * 64)(), C.create_string_buffer(256)
+        d = host.vkh_parse_derivation_path(p.encode(), comps, 64, err, 256)
+        return [comps[i] for i in range(d)] if d >= 0 else err.value.decode()
+
+    def inc(p):
+        o = C.create_string_buffer(600)
+        n = host.vkh_increment_path_index(p.encode(), o, 600)
+        return o.raw[:n].decode()
+
+    H = 0x80000000
+    assert parse_path("m/84'/0'/0'/0/0") == [84 | H, H, H, 0, 0]
+    assert parse_path("m") == []
+    assert parse_path("84'/0'/0'/0/0") == "Invalid derivation path: Path must start with 'm/' or be 'm'"
+    assert parse_path("m/abc") == "Invalid derivation path: Invalid index: abc"
+    assert parse_path("m/2147483648'/0'/0'/0/0") == "Invalid derivation path: Index 2147483648 exceeds BIP32 limit (must be < 2^31)"
+    assert parse_path("m/2147483647'/0'/0'/0/0") == [0xFFFFFFFF, H, H, 0, 0]
+    assert inc("m/84'/0'/0'/0/0") == "m/84'/0'/0'/0/1" and inc("m/84'/0'/0'/0/5") == "m/84'/0'/0'/0/6" and inc("m/44'/0'/0'/0'") == "m/44'/0'/0'/1'"
+    pieces = ["m", "M", "", "/", "0", "1", "7", "84", "2147483647", "2147483648", "4294967295", "4294967296", "'", "h", "+", "-", " ", "\t", "x", "00"]
+    for _ in range(3000):
+        p = "".join(rnd.choice(pieces) for _ in range(rnd.randrange(1, 9)))
+        if rnd.random() < 0.6:
+            p = "m/" + p
+        want = vko.bip32_parse_path(p)
+        got = parse_path(p)
+        if isinstance(want, int):
+            assert isinstance(got, str) and {-1: "must start", -2: "Invalid index", -3: "exceeds BIP32"}[want] in got, (p, want, got)
+        else:
+            assert got == want, p
+        assert inc(p) == vko.bip32_increment_path(p), p

@@ -124,6 +124,23 @@ int vkh_timestamp_range(const char *start_date, const char *end_date, uint64_t *
     }
 }
 
+// bitimage host pieces (src/bitimage.rs:38-44, 77-117, 277-293)
+void vkh_bitimage_entropy(const uint8_t *data, size_t n, uint8_t out[32]) { bitimage_entropy(data, n, out); }
+// depth, or -1 with the reference's error text in err
+int vkh_parse_derivation_path(const char *path, uint32_t *comps, int cap, char *err, size_t err_cap)
+{
+    try {
+        std::vector<uint32_t> c = parse_derivation_path(path);
+        if ((int)c.size() > cap) return -2;
+        for (size_t i = 0; i < c.size(); i++) comps[i] = c[i];
+        return (int)c.size();
+    } catch (const std::exception &e) {
+        snprintf(err, err_cap, "%s", e.what());
+        return -1;
+    }
+}
+size_t vkh_increment_path_index(const char *path, char *out, size_t cap) { return (size_t)snprintf(out, cap, "%s", increment_path_index(path).c_str()); }
+
 // StorageOutput without a device: n records (key, hash160s, X || Y, source, optional matched address) -> Parquet chunks
 // under `dir`; returns the number of files written.  matched[i] = "" means a plain key record.
 int vkh_storage_write(const char *dir, const char *transform, uint64_t chunk_records, size_t n, const uint8_t *keys, const uint8_t *hc,

@@ -65,6 +65,61 @@ void sha256(const uint8_t *msg, size_t len, uint8_t out[32])
     }
 }
 
+void bitimage_entropy(const uint8_t *data, size_t len, uint8_t out[32])
+{
+    static const char A[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    Sha256 s;
+    uint8_t blk[128];
+    size_t off = 0;
+    uint64_t text_len = 0;
+    for (; off + 48 <= len; off += 48) { // 48 bytes -> 64 characters = one SHA-256 block
+        for (int g = 0; g < 16; g++) {
+            const uint32_t v = ((uint32_t)data[off + 3 * g] << 16) | ((uint32_t)data[off + 3 * g + 1] << 8) | data[off + 3 * g + 2];
+            blk[4 * g] = (uint8_t)A[v >> 18];
+            blk[4 * g + 1] = (uint8_t)A[(v >> 12) & 63];
+            blk[4 * g + 2] = (uint8_t)A[(v >> 6) & 63];
+            blk[4 * g + 3] = (uint8_t)A[v & 63];
+        }
+        s.block(blk);
+        text_len += 64;
+    }
+    size_t tl = 0; // the tail: fewer than 64 characters, then the SHA-256 padding
+    memset(blk, 0, sizeof blk);
+    for (; off + 3 <= len; off += 3) {
+        const uint32_t v = ((uint32_t)data[off] << 16) | ((uint32_t)data[off + 1] << 8) | data[off + 2];
+        blk[tl++] = (uint8_t)A[v >> 18];
+        blk[tl++] = (uint8_t)A[(v >> 12) & 63];
+        blk[tl++] = (uint8_t)A[(v >> 6) & 63];
+        blk[tl++] = (uint8_t)A[v & 63];
+    }
+    if (len - off == 1) {
+        const uint32_t v = (uint32_t)data[off] << 16;
+        blk[tl++] = (uint8_t)A[v >> 18];
+        blk[tl++] = (uint8_t)A[(v >> 12) & 63];
+        blk[tl++] = '=';
+        blk[tl++] = '=';
+    } else if (len - off == 2) {
+        const uint32_t v = ((uint32_t)data[off] << 16) | ((uint32_t)data[off + 1] << 8);
+        blk[tl++] = (uint8_t)A[v >> 18];
+        blk[tl++] = (uint8_t)A[(v >> 12) & 63];
+        blk[tl++] = (uint8_t)A[(v >> 6) & 63];
+        blk[tl++] = '=';
+    }
+    text_len += tl;
+    blk[tl] = 0x80;
+    const size_t padded = tl < 56 ? 64 : 128;
+    const uint64_t bits = text_len * 8;
+    for (int i = 0; i < 8; i++) blk[padded - 1 - i] = (uint8_t)(bits >> (8 * i));
+    s.block(blk);
+    if (padded == 128) s.block(blk + 64);
+    for (int i = 0; i < 8; i++) {
+        out[4 * i] = (uint8_t)(s.h[i] >> 24);
+        out[4 * i + 1] = (uint8_t)(s.h[i] >> 16);
+        out[4 * i + 2] = (uint8_t)(s.h[i] >> 8);
+        out[4 * i + 3] = (uint8_t)s.h[i];
+    }
+}
+
 std::string hex_encode(const uint8_t *b, size_t n)
 {
     static const char H[] = "0123456789abcdef";

@@ -26,9 +26,12 @@ static int usage(const char *msg)
                     "       vuke-hip bench [--transform <T>] [--json]      transform-only inputs/s (the reference's `vuke bench`)\n"
                     "       vuke-hip analyze <KEY> [--fast] [--json] [--mask BITS] [--cascade b:t,b:t,...] [--analyzer milksad|lcg[:variant][:endian]|mt64|xorshift[:variant]|sha256_chain[:variant]]...\n"
                     "  --transform <T>...   sha256 | double_sha256 | md5 | direct | armory | milksad | mt64 | lcg[:variant][:endian] | xorshift[:variant] |\n"
-                    "                       sha256_chain[:variant] | electrum[:change] | multibit\n"
+                    "                       sha256_chain[:variant] | electrum[:change] | multibit | bitimage\n"
                     "  sources: range --start A --end B | timestamps --start YYYY-MM-DD --end YYYY-MM-DD [--microseconds] |\n"
-                    "           wordlist --file F | stdin   (passphrase sources feed the string form of each transform)\n"
+                    "           wordlist --file F | stdin   (passphrase sources feed the string form of each transform) |\n"
+                    "           files --file F | files --dir D   (file contents feed bitimage; other transforms see the path)\n"
+                    "  --bitimage-path <P>  HD derivation path (default m/84'/0'/0'/0/0); --bitimage-passphrase <S>;\n"
+                    "                       --bitimage-passphrase-wordlist <F> one passphrase per line; --bitimage-derive-count <N> (default 1)\n"
                     "  --targets <FILE>     (scan) one address per line\n"
                     "  -v, --verbose        (generate) all key formats\n"
                     "  -o, --output <FILE>  write to FILE instead of stdout\n"
@@ -61,7 +64,7 @@ static uint64_t parse_u64(const char *s)
 
 static bool is_source_word(const char *a)
 {
-    for (const char *w : {"range", "wordlist", "stdin", "timestamps"})
+    for (const char *w : {"range", "wordlist", "stdin", "timestamps", "files"})
         if (strcmp(a, w) == 0) return true;
     return false;
 }
@@ -256,6 +259,9 @@ int main(int argc, char **argv)
     std::string targets, outpath, single_value;
     bool verbose = false, have_range = false, have_start = false, have_end = false, have_wordlist = false, have_timestamps = false, microseconds = false;
     std::string wordlist_file, bip39_file, start_s, end_s, network = "bitcoin", devices_s, storage_dir;
+    bool have_files = false;
+    std::string files_dir, bitimage_pass_wordlist;
+    BitimageConfig bitimage_cfg; // src/main.rs:174-188
     uint64_t chunk_records = 1000000; // DEFAULT_CHUNK_RECORDS, src/storage/parquet_backend.rs:13
     uint64_t chunk_bytes = 100ull << 20; // 100M, src/main.rs:130-132
     std::string compression = "zstd";   // src/main.rs:134-141
@@ -304,6 +310,16 @@ int main(int argc, char **argv)
             else if (a == "wordlist") have_wordlist = true;
             else if (a == "stdin") { have_wordlist = true; wordlist_file = "-"; }
             else if (a == "timestamps") have_timestamps = true;
+            else if (a == "files") have_files = true;
+            else if (a == "--dir") files_dir = need("--dir");
+            else if (a == "--bitimage-path") bitimage_cfg.path = need("--bitimage-path");
+            else if (a == "--bitimage-passphrase") bitimage_cfg.passphrase = need("--bitimage-passphrase");
+            else if (a == "--bitimage-passphrase-wordlist") bitimage_pass_wordlist = need("--bitimage-passphrase-wordlist");
+            else if (a == "--bitimage-derive-count") {
+                const uint64_t v = parse_u64(need("--bitimage-derive-count"));
+                if (v > 0xFFFFFFFFull) throw std::invalid_argument("--bitimage-derive-count does not fit a u32");
+                bitimage_cfg.derive_count = (uint32_t)v;
+            }
             else if (a == "--microseconds") microseconds = true;
             else if (a == "--file") wordlist_file = need("--file");
             else if (a == "--bip39-wordlist") bip39_file = need("--bip39-wordlist");
@@ -317,11 +333,18 @@ int main(int argc, char **argv)
         if (tnames.empty()) throw std::invalid_argument("the following required arguments were not provided: --transform <TRANSFORM>...");
         std::vector<Transform> transforms;
         for (auto &n : tnames) transforms.push_back(TransformType::from_str(n));
+        if (!bitimage_pass_wordlist.empty()) bitimage_cfg.passphrase_wordlist = BitimageConfig::load_passphrase_wordlist(bitimage_pass_wordlist);
+        for (Transform &t : transforms)
+            if (t.is_bitimage()) t.bitimage = bitimage_cfg; // apply_bitimage_config, src/main.rs:48-70
         if (cmd == "scan" && targets.empty()) throw std::invalid_argument("the following required arguments were not provided: --targets <TARGETS>");
         if (cmd != "single" && have_wordlist && wordlist_file.empty()) throw std::invalid_argument("wordlist needs --file <FILE>");
-        if (cmd != "single" && !have_wordlist && ((!have_range && !have_timestamps) || !have_start || !have_end))
+        if (cmd != "single" && have_files) {
+            if (!wordlist_file.empty() && !files_dir.empty()) throw std::invalid_argument("the argument '--file <FILE>' cannot be used with '--dir <DIR>'");
+            if (wordlist_file.empty() && files_dir.empty()) throw std::invalid_argument("Either --file or --dir must be specified"); // src/main.rs:1361
+        }
+        if (cmd != "single" && !have_wordlist && !have_files && ((!have_range && !have_timestamps) || !have_start || !have_end))
             throw std::invalid_argument("sources on the device path: `range --start A --end B`, `timestamps --start DATE --end DATE [--microseconds]`, "
-                                        "`wordlist --file F`, `stdin`");
+                                        "`wordlist --file F`, `stdin`, `files --file F | --dir D`");
         if (have_range) {
             start = parse_u64(start_s.c_str());
             end = parse_u64(end_s.c_str());
@@ -386,8 +409,8 @@ int main(int argc, char **argv)
             if (timing) fprintf(stderr, "[timing] %s at %.3f s after engine creation\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
         };
         for (const Transform &t : transforms)
-            if (t.spec().kind == VK_T_MULTIBIT) {
-                if (bip39_file.empty()) throw std::invalid_argument("multibit needs --bip39-wordlist <FILE> (the 2048-word BIP-39 English list)");
+            if (t.spec().kind == VK_T_MULTIBIT || (t.is_bitimage() && have_files)) {
+                if (bip39_file.empty()) throw std::invalid_argument(std::string(t.name()) + " needs --bip39-wordlist <FILE> (the 2048-word BIP-39 English list)");
                 load_bip39_wordlist(engine, bip39_file);
                 break;
             }
@@ -430,7 +453,9 @@ int main(int argc, char **argv)
             sink = multi.get();
         }
         std::unique_ptr<Source> source_ptr;
-        if (have_wordlist) source_ptr = std::make_unique<HipWordlistSource>(engine, wordlist_file);
+        if (have_files)
+            source_ptr = std::make_unique<HipFilesSource>(files_dir.empty() ? HipFilesSource::from_file(engine, wordlist_file) : HipFilesSource::from_dir(engine, files_dir));
+        else if (have_wordlist) source_ptr = std::make_unique<HipWordlistSource>(engine, wordlist_file);
         else if (have_timestamps) source_ptr = std::make_unique<HipTimestampSource>(engine, start_s, end_s, microseconds);
         else if (engines.size() > 1) source_ptr = std::make_unique<HipMultiRangeSource>(engines, start, end);
         else source_ptr = std::make_unique<HipRangeSource>(engine, start, end);

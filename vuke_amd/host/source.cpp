@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cerrno>
 #include <exception>
+#include <filesystem>
 #include <fstream>
 #include <iostream>
 #include <thread>
@@ -337,6 +339,7 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
         for (uint64_t lo = start;; lo += block) {
             const uint64_t hi = (end - lo < block - 1) ? end : lo + block - 1;
             for (const Transform &t : transforms) {
+                if (t.is_bitimage()) continue; // nothing for an input without a blob
                 if (t.takes_strings()) { // e.g. electrum over a numeric range: the decimal string is the seed
                     for (uint64_t a = lo;; a += 16384) {
                         const uint64_t b = (hi - a < 16383) ? hi : a + 16383;
@@ -393,6 +396,7 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
                     continue;
                 }
                 const uint32_t k = t.slots();
+                if (k == 0) continue; // bitimage: nothing for an input without a blob
                 const size_t n = (size_t)(hi - lo + 1) * k;
                 std::vector<uint8_t> priv(n * 32), hc(n * 20), hu(n * 20), valid(n);
                 vk_sweep_stats ss;
@@ -418,6 +422,107 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
             if (hi == end) break;
         }
     }
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------------ FilesSource
+HipFilesSource HipFilesSource::from_file(vk_engine *engine, const std::string &path)
+{
+    std::error_code ec;
+    const std::filesystem::path p(path);
+    if (!std::filesystem::exists(p, ec)) throw std::runtime_error("File not found: " + path);
+    if (!std::filesystem::is_regular_file(p, ec)) throw std::runtime_error("Not a file: " + path);
+    HipFilesSource s(engine);
+    s.files.push_back(path);
+    return s;
+}
+
+static void collect_files_inner(const std::filesystem::path &dir, std::vector<std::string> &files)
+{
+    for (const std::filesystem::directory_entry &entry : std::filesystem::directory_iterator(dir)) {
+        if (entry.is_symlink()) continue; // skip symlinks: loops (src/source/files.rs:69-72)
+        if (entry.is_regular_file()) files.push_back(entry.path().string());
+        else if (entry.is_directory()) collect_files_inner(entry.path(), files);
+    }
+}
+
+HipFilesSource HipFilesSource::from_dir(vk_engine *engine, const std::string &path)
+{
+    std::error_code ec;
+    const std::filesystem::path p(path);
+    if (!std::filesystem::exists(p, ec)) throw std::runtime_error("Directory not found: " + path);
+    if (!std::filesystem::is_directory(p, ec)) throw std::runtime_error("Not a directory: " + path);
+    HipFilesSource s(engine);
+    collect_files_inner(p, s.files);
+    if (s.files.empty()) throw std::runtime_error("No files found in directory: " + path);
+    std::sort(s.files.begin(), s.files.end()); // read_dir order is unspecified (and the reference runs files in parallel): a fixed order here
+    return s;
+}
+
+ProcessStats HipFilesSource::process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output)
+{
+    ProcessStats st;
+    if (matcher) {
+        std::vector<uint8_t> h160, kind;
+        matcher->device_targets(h160, kind);
+        check_rc(engine_, vk_targets_set(engine_, h160.data(), kind.data(), kind.size()));
+    }
+    bool any_bitimage = false;
+    for (const Transform &t : transforms) any_bitimage |= t.is_bitimage();
+    // the files in batches: read + base64 + SHA-256 on the host cores (file-size-bound), everything after on the device
+    const size_t batch = 4096;
+    for (size_t f0 = 0; f0 < files.size(); f0 += batch) {
+        const size_t nf = std::min(batch, files.size() - f0);
+        std::vector<std::array<uint8_t, 32>> ent(nf);
+        std::vector<uint8_t> ok(nf, 0);
+        std::vector<std::string> errs(nf);
+        auto work = [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                FILE *fp = fopen(files[f0 + i].c_str(), "rb");
+                if (!fp) {
+                    errs[i] = strerror(errno);
+                    continue;
+                }
+                std::vector<uint8_t> data;
+                uint8_t buf[1 << 16];
+                size_t got;
+                while ((got = fread(buf, 1, sizeof buf, fp)) > 0) data.insert(data.end(), buf, buf + got);
+                const bool bad = ferror(fp) != 0;
+                if (bad) errs[i] = strerror(errno);
+                fclose(fp);
+                if (bad) continue;
+                if (any_bitimage) bitimage_entropy(data.data(), data.size(), ent[i].data());
+                ok[i] = 1;
+            }
+        };
+        if (nf >= 2) {
+            unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), (unsigned)std::min<size_t>(nf, 32));
+            std::vector<std::thread> th;
+            for (unsigned w = 0; w < nt; w++) th.emplace_back(work, nf * w / nt, nf * (w + 1) / nt);
+            for (auto &t : th) t.join();
+        } else {
+            work(0, nf);
+        }
+        std::vector<std::array<uint8_t, 32>> ents;
+        std::vector<std::string> labels;
+        for (size_t i = 0; i < nf; i++) {
+            if (!ok[i]) {
+                fprintf(stderr, "Warning: Failed to read '%s': %s\n", files[f0 + i].c_str(), errs[i].c_str());
+                continue;
+            }
+            ents.push_back(ent[i]);
+            labels.push_back(files[f0 + i]); // path.display().to_string()
+        }
+        st.inputs_processed += labels.size();
+        if (labels.empty()) continue;
+        for (const Transform &t : transforms) {
+            std::vector<std::pair<std::string, Key>> out;
+            if (t.is_bitimage()) t.apply_batch_blobs(engine_, ents, labels, out);
+            else t.apply_batch(engine_, labels, out); // Input::string_val = the label
+            emit_keys(engine_, t, out, matcher, output, st);
+        }
+    }
+    if (matcher) check_rc(engine_, vk_targets_set(engine_, nullptr, nullptr, 0));
     return st;
 }
 

@@ -58,9 +58,6 @@ Transform TransformType::from_str(const std::string &raw)
 {
     const std::string s = lower(raw);
     vk_transform_spec sp{0, VK_VARIANT_ALL, 0, 10};
-    auto unsupported = [&](const char *name) -> Transform {
-        throw std::invalid_argument(std::string("transform '") + name + "' is outside the device hot path of this build (see DESIGN.md)");
-    };
     if (s == "sha256") { sp.kind = VK_T_SHA256; return Transform(sp); }
     if (s == "milksad") { sp.kind = VK_T_MILKSAD; return Transform(sp); }
     if (s == "mt64") { sp.kind = VK_T_MT64; return Transform(sp); }
@@ -80,7 +77,7 @@ Transform TransformType::from_str(const std::string &raw)
     if (s == "md5") { sp.kind = VK_T_MD5; return Transform(sp); }
     if (s == "direct") { sp.kind = VK_T_DIRECT; return Transform(sp); }
     if (s == "armory") { sp.kind = VK_T_ARMORY; return Transform(sp); }
-    if (s == "bitimage") return unsupported("bitimage");
+    if (s == "bitimage") { sp.kind = VK_T_BITIMAGE; return Transform(sp); } // src/transform/mod.rs:204-209: defaults, configured later
     if (s == "lcg" || s.rfind("lcg:", 0) == 0) { // LcgConfig::parse
         auto parts = split_colon(s);
         sp.kind = VK_T_LCG;
@@ -147,6 +144,7 @@ Transform TransformType::from_str(const std::string &raw)
 const char *Transform::name() const
 {
     switch (spec_.kind) {
+    case VK_T_BITIMAGE: return "bitimage";
     case VK_T_SHA256: return "sha256";
     case VK_T_DOUBLE_SHA256: return "double_sha256";
     case VK_T_MD5: return "md5";
@@ -216,6 +214,163 @@ std::string Transform::label(const std::string &input, uint32_t sub) const
         return input + "[" + CH_NAMES[(all ? sub / d : spec_.variant) & 3] + ":" + std::to_string(sub % d) + "]";
     }
     return input;
+}
+
+// ---------------------------------------------------------------------------------------------- bitimage
+static bool rust_ws(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+// u32::from_str: optional '+', at least one ASCII digit, no overflow
+static bool parse_u32(const std::string &t, uint32_t &out)
+{
+    size_t d = 0;
+    if (d < t.size() && t[d] == '+') d++;
+    if (d == t.size()) return false;
+    uint64_t v = 0;
+    for (; d < t.size(); d++) {
+        if (t[d] < '0' || t[d] > '9') return false;
+        v = v * 10 + (uint64_t)(t[d] - '0');
+        if (v > 0xFFFFFFFFull) return false;
+    }
+    out = (uint32_t)v;
+    return true;
+}
+
+std::vector<uint32_t> parse_derivation_path(const std::string &raw)
+{
+    size_t b = 0, e = raw.size();
+    while (b < e && rust_ws((unsigned char)raw[b])) b++;
+    while (e > b && rust_ws((unsigned char)raw[e - 1])) e--;
+    const std::string path = raw.substr(b, e - b);
+    if (path == "m") return {};
+    if (path.rfind("m/", 0) != 0) throw std::invalid_argument("Invalid derivation path: Path must start with 'm/' or be 'm'");
+    std::vector<uint32_t> out;
+    size_t i = 2;
+    while (i <= path.size()) {
+        size_t s0 = i;
+        while (i < path.size() && path[i] != '/') i++;
+        std::string comp = path.substr(s0, i - s0);
+        i++;
+        if (comp.empty()) continue;
+        std::string idx = comp;
+        bool hardened = false;
+        if (comp.back() == '\'' || comp.back() == 'h') {
+            hardened = true;
+            idx.pop_back();
+        }
+        uint32_t v;
+        if (!parse_u32(idx, v)) throw std::invalid_argument("Invalid derivation path: Invalid index: " + comp);
+        if (v >= 0x80000000u) throw std::invalid_argument("Invalid derivation path: Index " + std::to_string(v) + " exceeds BIP32 limit (must be < 2^31)");
+        out.push_back(v | (hardened ? 0x80000000u : 0u));
+    }
+    return out;
+}
+
+std::string increment_path_index(const std::string &path)
+{
+    const size_t slash = path.rfind('/');
+    if (slash != std::string::npos) {
+        const std::string prefix = path.substr(0, slash + 1);
+        std::string suffix = path.substr(slash + 1), marker;
+        if (!suffix.empty() && (suffix.back() == '\'' || suffix.back() == 'h')) {
+            marker = suffix.substr(suffix.size() - 1);
+            suffix.pop_back();
+        }
+        uint32_t v;
+        if (parse_u32(suffix, v)) return prefix + std::to_string((uint32_t)(v + 1)) + marker;
+    }
+    return path;
+}
+
+std::vector<std::string> BitimageConfig::load_passphrase_wordlist(const std::string &file)
+{
+    std::ifstream f(file, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open passphrase wordlist: " + file);
+    std::vector<std::string> words;
+    std::string line;
+    while (std::getline(f, line)) {
+        size_t b = 0, e = line.size();
+        while (b < e && rust_ws((unsigned char)line[b])) b++;
+        while (e > b && rust_ws((unsigned char)line[e - 1])) e--;
+        if (e > b) words.push_back(line.substr(b, e - b));
+    }
+    return words;
+}
+
+void Transform::apply_batch_blobs(vk_engine *e, const std::vector<std::array<uint8_t, 32>> &entropies, const std::vector<std::string> &labels,
+                                  std::vector<std::pair<std::string, Key>> &output) const
+{
+    if (!is_bitimage() || entropies.empty()) return; // every other transform skips Input::blob
+    const BitimageConfig &c = bitimage;
+    // the passphrases one file is tried with, in order (src/transform/bitimage.rs:120-126)
+    std::vector<std::string> pws = c.passphrase_wordlist ? *c.passphrase_wordlist : std::vector<std::string>{c.passphrase};
+    if (pws.empty() || c.derive_count == 0) return;
+    // the path texts derive_keys_for_passphrase walks (src/transform/bitimage.rs:80-96); a text that does not parse ends
+    // the walk (Err => continue without advancing: every later attempt repeats it)
+    std::vector<std::string> texts{c.path};
+    std::vector<std::vector<uint32_t>> comps;
+    for (uint32_t i = 0; i < c.derive_count; i++) {
+        try {
+            comps.push_back(parse_derivation_path(texts[i]));
+        } catch (const std::invalid_argument &) {
+            break;
+        }
+        if (i + 1 < c.derive_count) texts.push_back(increment_path_index(texts[i]));
+    }
+    const uint32_t count = (uint32_t)comps.size();
+    if (count == 0) return;
+    // runs the device walks in one call: same parent, last index going up by one ("m" repeats the master key).  A last
+    // component increment_path_index cannot read ("m/0/", "m/0/1 ") leaves the text as it is: runs of one.
+    struct Run { uint32_t first, len; };
+    std::vector<Run> runs;
+    for (uint32_t i = 0; i < count;) {
+        uint32_t len = 1;
+        while (i + len < count) {
+            const auto &a = comps[i], &n = comps[i + len];
+            bool next = a.size() == n.size();
+            if (next && !a.empty()) {
+                next = std::equal(a.begin(), a.end() - 1, n.begin()) && (a.back() >> 31) == (n.back() >> 31) &&
+                       (uint64_t)(a.back() & 0x7FFFFFFFu) + len == (n.back() & 0x7FFFFFFFu);
+            }
+            if (!next) break;
+            len++;
+        }
+        runs.push_back({i, len});
+        i += len;
+    }
+    std::vector<uint8_t> pdata;
+    std::vector<uint32_t> poffs{0};
+    for (const std::string &pw : pws) {
+        pdata.insert(pdata.end(), pw.begin(), pw.end());
+        poffs.push_back((uint32_t)pdata.size());
+    }
+    const size_t per_call = std::max<size_t>(1, (1u << 22) / (pws.size() * count)); // files per device call
+    std::vector<uint8_t> keys, valid, rk, rv;
+    for (size_t f0 = 0; f0 < entropies.size(); f0 += per_call) {
+        const size_t nf = std::min(per_call, entropies.size() - f0), items = nf * pws.size();
+        keys.assign(items * count * 32, 0);
+        valid.assign(items * count, 0);
+        for (const Run &r : runs) {
+            rk.assign(items * r.len * 32, 0);
+            rv.assign(items * r.len, 0);
+            check_rc(e, vk_bitimage_keys(e, entropies[f0].data(), nf, pdata.data(), poffs.data(), pws.size(), comps[r.first].data(),
+                                         (uint32_t)comps[r.first].size(), r.len, rk.data(), rv.data()));
+            for (size_t it = 0; it < items; it++)
+                for (uint32_t q = 0; q < r.len; q++) {
+                    valid[it * count + r.first + q] = rv[it * r.len + q];
+                    memcpy(&keys[(it * count + r.first + q) * 32], &rk[(it * r.len + q) * 32], 32);
+                }
+        }
+        for (size_t f = 0; f < nf; f++)
+            for (size_t j = 0; j < pws.size(); j++)
+                for (uint32_t i = 0; i < count; i++) {
+                    const size_t idx = (f * pws.size() + j) * count + i;
+                    if (!valid[idx]) break; // a failed derivation is repeated for every later index
+                    Key key;
+                    std::copy(keys.begin() + 32 * idx, keys.begin() + 32 * idx + 32, key.begin());
+                    const std::string &lab = labels[f0 + f];
+                    output.emplace_back(pws[j].empty() ? lab + "[" + texts[i] + "]" : lab + ":" + pws[j] + "[" + texts[i] + "]", key);
+                }
+    }
 }
 
 void load_bip39_wordlist(vk_engine *e, const std::string &path)

@@ -28,6 +28,14 @@ using Key = std::array<uint8_t, 32>;
 
 // ---------------------------------------------------------------- text codecs (codecs.cpp)
 void sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
+// BitimageDeriver::from_file_bytes, first half (src/bitimage.rs:38-44): SHA-256 of the base64 text (STANDARD alphabet, '='
+// padding) of the file bytes; the text is streamed through the hash, never materialised
+void bitimage_entropy(const uint8_t *data, size_t len, uint8_t out[32]);
+// parse_derivation_path (src/bitimage.rs:77-117): components as index | 0x80000000 when hardened; throws
+// std::invalid_argument("Invalid derivation path: ...") with the reference's messages
+std::vector<uint32_t> parse_derivation_path(const std::string &path);
+// increment_path_index (src/bitimage.rs:277-293)
+std::string increment_path_index(const std::string &path);
 std::string hex_encode(const uint8_t *b, size_t n);
 std::string base58check_encode(const uint8_t *payload, size_t len);
 bool base58check_decode(const std::string &s, std::vector<uint8_t> &out); // version byte + payload
@@ -96,9 +104,25 @@ private:
 };
 
 // ---------------------------------------------------------------- transform/mod.rs
+// BitimageTransform's builder state (src/transform/bitimage.rs:9-69)
+struct BitimageConfig {
+    std::string path = "m/84'/0'/0'/0/0";
+    std::string passphrase;
+    std::optional<std::vector<std::string>> passphrase_wordlist; // trimmed non-empty lines of --bitimage-passphrase-wordlist
+    uint32_t derive_count = 1;
+    static std::vector<std::string> load_passphrase_wordlist(const std::string &file); // with_passphrase_wordlist (:36-64)
+};
+
 class Transform {
 public:
     explicit Transform(const vk_transform_spec &s) : spec_(s) {}
+    // ---- bitimage (blob inputs: FilesSource)
+    bool is_bitimage() const { return spec_.kind == VK_T_BITIMAGE; }
+    BitimageConfig bitimage;
+    // apply_batch for Input::from_blob inputs, on the device: entropies[i] = bitimage_entropy(file i), labels[i] = its
+    // Input::string_val; appends ("{label}[{path}]" or "{label}:{passphrase}[{path}]", key) in the reference's order
+    void apply_batch_blobs(vk_engine *e, const std::vector<std::array<uint8_t, 32>> &entropies, const std::vector<std::string> &labels,
+                           std::vector<std::pair<std::string, Key>> &output) const;
     const char *name() const;                              // Transform::name()
     const vk_transform_spec &spec() const { return spec_; }
     uint32_t slots() const { return vk_slots_per_input(&spec_); }
@@ -119,8 +143,8 @@ private:
 
 struct TransformType {
     // TransformType::from_str (src/transform/mod.rs:170-215): throws std::invalid_argument with the
-    // reference's message for unknown names; the one transform outside the device path (bitimage) is
-    // recognised and rejected as unsupported.
+    // reference's message for unknown names.  "bitimage" comes back with the default BitimageConfig
+    // (apply_bitimage_config in src/main.rs:48-70 = assigning Transform::bitimage afterwards).
     static Transform from_str(const std::string &s);
 };
 
@@ -269,6 +293,22 @@ public:
     bool microseconds;
 
 private:
+    vk_engine *engine_;
+};
+
+// FilesSource on the GPU (src/source/files.rs): one file, or every regular file under a directory (recursive, symlinks
+// skipped).  Each file is one Input::from_blob(contents, path): bitimage consumes the contents, every other transform
+// sees the path as Input::string_val.  Unreadable files are reported on stderr and skipped.
+class HipFilesSource : public Source {
+public:
+    static HipFilesSource from_file(vk_engine *engine, const std::string &path); // throws: "File not found: ..", "Not a file: .."
+    static HipFilesSource from_dir(vk_engine *engine, const std::string &path);  // throws: "Directory not found", "Not a directory", "No files found in directory"
+    ProcessStats process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output) override;
+    size_t file_count() const { return files.size(); }
+    std::vector<std::string> files;
+
+private:
+    explicit HipFilesSource(vk_engine *engine) : engine_(engine) {}
     vk_engine *engine_;
 };
 
