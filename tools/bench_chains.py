@@ -28,3 +28,15 @@ keys = sum(valid)
 ops = 200000 * 2168 + 21 * 213000
 print(json.dumps({"chain": "electrum", "inputs": n, "seconds": dt, "inputs_per_s": n / dt, "keys_per_s": keys / dt,
                   "canonical_tops": n / dt * ops / 1e12}))
+# Bitimage with a passphrase wordlist: 64 files x n/64 passphrases, default path, one key each (one PBKDF2 per item)
+import time
+ents = [rnd.randbytes(32) for _ in range(64)]
+pws = [("pw%07d" % i).encode() for i in range(n // 64)]
+e.bitimage_keys(ents[:4], pws[:256])
+t0 = time.perf_counter()
+res = e.bitimage_keys(ents, pws)
+dt = time.perf_counter() - t0   # includes the python-side unpacking of the result
+items = len(ents) * len(pws)
+ops = 2048 * 2 * 5520 + 3 * 213000
+print(json.dumps({"chain": "bitimage", "items": items, "seconds_incl_python_unpack": dt, "items_per_s": items / dt,
+                  "canonical_tops": items / dt * ops / 1e12}))
