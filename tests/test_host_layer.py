@@ -256,7 +256,7 @@ def test_timestamp_source_dates(host):
         assert host.vkh_timestamp_range(bad[0].encode(), bad[1].encode(), C.byref(lo), C.byref(hi)) == -1, bad
 
 
-@pytest.mark.parametrize("compression", ["zstd", "gzip", "none"])
+@pytest.mark.parametrize("compression", ["zstd", "gzip", "none", "snappy", "lz4"])
 def test_storage_output_writes_the_19_column_parquet_record(host, vko, tmp_path, compression):
     """StorageOutput: files readable by pyarrow, schema = src/storage/schema.rs:78-111 field for field,
     values = the oracle's DerivedKey, partition layout and rotation = src/storage/parquet_backend.rs:86-131."""
@@ -278,13 +278,18 @@ def test_storage_output_writes_the_19_column_parquet_record(host, vko, tmp_path,
     nfiles = host.vkh_storage_write(str(tmp_path).encode(), b"sha256_chain:iterated", 1000, n, raw, hc, hu, xy, (C.c_char_p * n)(*sources), (C.c_char_p * n)(*matched),
                                     compression.encode())
     assert nfiles == 3                                           # 1000 + 1000 + 500 records
-    assert host.vkh_storage_write(str(tmp_path / "x").encode(), b"t", 0, 0, raw, hc, hu, xy, (C.c_char_p * n)(*sources), (C.c_char_p * n)(*matched), b"snappy") == -1
+    assert host.vkh_storage_write(str(tmp_path / "x").encode(), b"t", 0, 0, raw, hc, hu, xy, (C.c_char_p * n)(*sources), (C.c_char_p * n)(*matched), b"brotli") == -1
     today = datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d")
     files = sorted(glob.glob(str(tmp_path / "transform=sha256_chain:iterated" / f"date={today}" / "chunk_*.parquet")))
     assert [os.path.basename(f) for f in files] == ["chunk_0001.parquet", "chunk_0002.parquet", "chunk_0003.parquet"]
     tables = [pq.read_table(f) for f in files]
     assert [t.num_rows for t in tables] == [1000, 1000, 500]
-    assert pq.read_metadata(files[0]).row_group(0).column(8).compression == {"zstd": "ZSTD", "gzip": "GZIP", "none": "UNCOMPRESSED"}[compression]
+    # codec id 5 (Hadoop-framed LZ4): pyarrow decodes it but its Python metadata wrapper has no name for it
+    assert pq.read_metadata(files[0]).row_group(0).column(8).compression in {"zstd": ["ZSTD"], "gzip": ["GZIP"], "none": ["UNCOMPRESSED"], "snappy": ["SNAPPY"],
+                                                                              "lz4": ["LZ4", "LZ4_HADOOP", "UNKNOWN"]}[compression]
+    if compression in ("snappy", "lz4"):  # the matchers written here do compress: the binary-digit column is 256 characters of '0' / '1' per record
+        m8 = pq.read_metadata(files[0]).row_group(0).column(8)
+        assert m8.total_compressed_size < m8.total_uncompressed_size // 2
     t = pa.concat_tables(tables)
     utf8 = lambda name, nullable: pa.field(name, pa.string(), nullable=nullable)
     want_schema = pa.schema([
@@ -361,3 +366,30 @@ def test_bitimage_host_pieces(host):
         else:
             assert got == want, p
         assert inc(p) == vko.bip32_increment_path(p), p
+
+
+def test_page_compressors_round_trip(host):
+    """The Snappy and LZ4 matchers written for the Parquet writer, decoded by pyarrow's codecs: empty and tiny inputs (the
+    LZ4 end-of-block rules: last 5 bytes literal, last match 12 bytes before the end), long runs, overlapping copies,
+    incompressible data, literals longer than 60 / 15, matches longer than 64 / 19, distances at the 64 KB window edge."""
+    pa = pytest.importorskip("pyarrow")
+    host.vkh_compress_page.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    host.vkh_compress_page.restype = C.c_long
+    rnd = random.Random(91)
+    cases = [bytes(n) for n in range(0, 40)] + [rnd.randbytes(n) for n in list(range(0, 40)) + [59, 60, 61, 255, 256, 257, 65535, 65536, 65537, 200000]]
+    cases += [b"ab" * n for n in (1, 2, 5, 6, 7, 8, 9, 30, 31, 32, 33, 34, 1000, 40000)]
+    cases += [b"x" * 300000, rnd.randbytes(100) * 3000, bytes(rnd.choice(b"01") for _ in range(70000))]
+    blk = rnd.randbytes(64)
+    cases += [blk + rnd.randbytes(65535 - 64) + blk + b"tail-bytes-here", blk + rnd.randbytes(65536 - 64) + blk + b"tail-bytes-here"]
+    cases += [b"".join(rnd.choice([b"0", b"1", b"src", b"[x:", b"]"]) for _ in range(50000))]
+    for data in cases:
+        out = C.create_string_buffer(len(data) * 2 + 64)
+        n = host.vkh_compress_page(1, data, len(data), out, len(out))
+        assert n > 0
+        assert pa.Codec("snappy").decompress(out.raw[:n], decompressed_size=len(data)).to_pybytes() == data, len(data)
+        n = host.vkh_compress_page(5, data, len(data), out, len(out))
+        assert n >= 9 and int.from_bytes(out.raw[:4], "big") == len(data) and int.from_bytes(out.raw[4:8], "big") == n - 8
+        if data:
+            assert pa.Codec("lz4_raw").decompress(out.raw[8:n], decompressed_size=len(data)).to_pybytes() == data, len(data)
+        if len(data) >= 1000 and len(set(data)) <= 8:
+            assert n < len(data) * 2 // 3   # random binary digits: one bit of information per byte, matches of 4 and more only

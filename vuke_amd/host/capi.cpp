@@ -141,6 +141,19 @@ int vkh_parse_derivation_path(const char *path, uint32_t *comps, int cap, char *
 }
 size_t vkh_increment_path_index(const char *path, char *out, size_t cap) { return (size_t)snprintf(out, cap, "%s", increment_path_index(path).c_str()); }
 
+// the page compressors written in parquet.cpp (codec 1 = Snappy raw, 5 = Hadoop-framed LZ4 block): bytes written, or -1
+long vkh_compress_page(int codec, const uint8_t *data, size_t n, uint8_t *out, size_t cap)
+{
+    try {
+        const std::string r = compress_page_for_test(codec, std::string((const char *)data, n));
+        if (r.size() > cap) return -1;
+        memcpy(out, r.data(), r.size());
+        return (long)r.size();
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
+
 // StorageOutput without a device: n records (key, hash160s, X || Y, source, optional matched address) -> Parquet chunks
 // under `dir`; returns the number of files written.  matched[i] = "" means a plain key record.
 int vkh_storage_write(const char *dir, const char *transform, uint64_t chunk_records, size_t n, const uint8_t *keys, const uint8_t *hc,

@@ -37,7 +37,7 @@ static int usage(const char *msg)
                     "  -o, --output <FILE>  write to FILE instead of stdout\n"
                     "  --storage <DIR>      also write the 19-column Parquet record (DIR/transform=T/date=D/chunk_NNNN.parquet,\n"
                     "                       --chunk-records <N> / --chunk-bytes <N[K|M|G]> per file (defaults 1000000 / 100M),\n"
-                    "                       --compression zstd|gzip|none (default zstd),\n"
+                    "                       --compression none|snappy|gzip|lz4|zstd (default zstd),\n"
                     "                       --compression-level <L> (default 3)\n"
                     "  --network <N>        bitcoin | testnet | signet | regtest: used by `single`; parsed and ignored by generate / scan\n"
                     "                       exactly like the reference (src/main.rs:464,499)\n"

@@ -4,11 +4,13 @@
 // Schema and column semantics: src/storage/schema.rs:78-111 (result_schema) and :137-262 (records_to_batch);
 // partition layout `DIR/transform=<first transform>/date=<UTC date>/chunk_NNNN.parquet` and record-count rotation:
 // src/storage/parquet_backend.rs:86-140; console + storage fan-out: src/main.rs:666-672 (MultiOutput).
-// Page compression (src/main.rs:134-141): none, gzip (zlib) and zstd -- the reference's default, level 3 -- through
-// libzstd.so.1 loaded at run time (the image ships the library without its header); snappy and lz4 are not available
-// here.  Cloud upload, Iceberg and the DuckDB query layer are out of scope.
+// Page compression (src/main.rs:70-83, 134-141, 640-649): none, snappy and lz4 (written here: greedy hash-table matchers
+// emitting the raw Snappy format and Hadoop-framed LZ4 blocks, which is what the Parquet codec ids 1 and 5 mean), gzip
+// (zlib) and zstd -- the reference's default, level 3 -- through libzstd.so.1 loaded at run time (the image ships the
+// library without its header).  Cloud upload, Iceberg and the DuckDB query layer are out of scope.
 #include "vuke_host.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <ctime>
@@ -149,10 +151,121 @@ struct ChunkMeta {
     int64_t data_page_offset, size, raw_size, num_values;
 };
 
-// parquet.thrift CompressionCodec: UNCOMPRESSED = 0, GZIP = 2, ZSTD = 6
+static inline uint32_t load32(const uint8_t *p)
+{
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return v;
+}
+
+// Snappy raw format (format_description.txt): varint length, then literals (tag 00) and copies with a 2-byte offset (tag 10)
+std::string snappy_compress(const std::string &in)
+{
+    const uint8_t *p = (const uint8_t *)in.data();
+    const size_t n = in.size();
+    if (n > 0xFFFFFFFFull) throw std::runtime_error("snappy: page larger than 4 GiB");
+    std::string out;
+    out.reserve(n + n / 6 + 32);
+    for (size_t v = n;;) {
+        uint8_t b = v & 0x7F;
+        v >>= 7;
+        out.push_back((char)(b | (v ? 0x80 : 0)));
+        if (!v) break;
+    }
+    auto literal = [&](size_t from, size_t to) {
+        while (from < to) {
+            const size_t len = std::min<size_t>(to - from, 1u << 24), l1 = len - 1;
+            if (l1 < 60) out.push_back((char)(l1 << 2));
+            else if (l1 < 256) { out.push_back((char)(60 << 2)); out.push_back((char)l1); }
+            else if (l1 < 65536) { out.push_back((char)(61 << 2)); out.push_back((char)l1); out.push_back((char)(l1 >> 8)); }
+            else { out.push_back((char)(62 << 2)); out.push_back((char)l1); out.push_back((char)(l1 >> 8)); out.push_back((char)(l1 >> 16)); }
+            out.append((const char *)p + from, len);
+            from += len;
+        }
+    };
+    std::vector<uint32_t> table(1u << 14, 0); // position + 1 of the last occurrence of a 4-byte hash
+    size_t i = 0, lit = 0;
+    while (i + 4 <= n) {
+        const uint32_t v = load32(p + i), h = (v * 0x1e35a7bdu) >> 18;
+        const size_t cand = table[h];
+        table[h] = (uint32_t)(i + 1);
+        if (cand && i - (cand - 1) <= 65535 && load32(p + cand - 1) == v) {
+            const size_t m = cand - 1, off = i - m;
+            size_t len = 4;
+            while (i + len < n && p[m + len] == p[i + len]) len++;
+            literal(lit, i);
+            for (size_t rem = len; rem;) {
+                const size_t l = std::min<size_t>(rem, 64);
+                out.push_back((char)(((l - 1) << 2) | 2));
+                out.push_back((char)off);
+                out.push_back((char)(off >> 8));
+                rem -= l;
+            }
+            i += len;
+            lit = i;
+        } else {
+            i++;
+        }
+    }
+    literal(lit, n);
+    return out;
+}
+
+// One LZ4 block (lz4_Block_format.md) in Hadoop framing: BE32 uncompressed size, BE32 compressed size, block -- the
+// layout behind Parquet's codec id 5 ("LZ4"), which parquet-rs writes for Compression::LZ4
+std::string lz4_hadoop_compress(const std::string &in)
+{
+    const uint8_t *p = (const uint8_t *)in.data();
+    const size_t n = in.size();
+    if (n > 0x7E000000ull) throw std::runtime_error("lz4: page too large for one block");
+    std::string blk;
+    blk.reserve(n + n / 255 + 32);
+    auto lengths = [&](size_t v) { // the 255-run extension of a nibble that said 15
+        for (; v >= 255; v -= 255) blk.push_back((char)255);
+        blk.push_back((char)v);
+    };
+    std::vector<uint32_t> table(1u << 14, 0);
+    size_t i = 0, lit = 0;
+    const size_t mflimit = n >= 12 ? n - 12 : 0, matchend = n >= 5 ? n - 5 : 0; // last match starts 12 before the end, ends 5 before it
+    while (n >= 13 && i <= mflimit) {
+        const uint32_t v = load32(p + i), h = (v * 2654435761u) >> 18;
+        const size_t cand = table[h];
+        table[h] = (uint32_t)(i + 1);
+        if (cand && i - (cand - 1) <= 65535 && load32(p + cand - 1) == v) {
+            const size_t m = cand - 1, off = i - m;
+            size_t len = 4;
+            while (i + len < matchend && p[m + len] == p[i + len]) len++;
+            const size_t L = i - lit, M = len - 4;
+            blk.push_back((char)((std::min<size_t>(L, 15) << 4) | std::min<size_t>(M, 15)));
+            if (L >= 15) lengths(L - 15);
+            blk.append((const char *)p + lit, L);
+            blk.push_back((char)off);
+            blk.push_back((char)(off >> 8));
+            if (M >= 15) lengths(M - 15);
+            i += len;
+            lit = i;
+        } else {
+            i++;
+        }
+    }
+    const size_t L = n - lit;
+    blk.push_back((char)(std::min<size_t>(L, 15) << 4));
+    if (L >= 15) lengths(L - 15);
+    blk.append((const char *)p + lit, L);
+    std::string out;
+    const uint32_t a = (uint32_t)n, b = (uint32_t)blk.size();
+    for (int sh = 24; sh >= 0; sh -= 8) out.push_back((char)(a >> sh));
+    for (int sh = 24; sh >= 0; sh -= 8) out.push_back((char)(b >> sh));
+    out += blk;
+    return out;
+}
+
+// parquet.thrift CompressionCodec: UNCOMPRESSED = 0, SNAPPY = 1, GZIP = 2, LZ4 = 5, ZSTD = 6
 std::string compress_page(int codec, int level, const std::string &in)
 {
     if (codec == 0) return in;
+    if (codec == 1) return snappy_compress(in);
+    if (codec == 5) return lz4_hadoop_compress(in);
     if (codec == 2) {
         z_stream z;
         memset(&z, 0, sizeof z);
@@ -419,6 +532,8 @@ struct StorageOutput::Impl {
     }
 };
 
+std::string compress_page_for_test(int codec, const std::string &in) { return compress_page(codec, codec == 2 ? 6 : 3, in); }
+
 StorageOutput::StorageOutput(const std::string &base_dir, const std::string &transform_name, uint64_t max_chunk_records, const std::string &compression,
                              int level, uint64_t max_chunk_bytes)
     : impl_(new Impl)
@@ -429,11 +544,13 @@ StorageOutput::StorageOutput(const std::string &base_dir, const std::string &tra
     impl_->max_chunk_records = max_chunk_records;
     impl_->level = level;
     if (compression == "none") impl_->codec = 0;
+    else if (compression == "snappy") impl_->codec = 1;
     else if (compression == "gzip") impl_->codec = 2;
+    else if (compression == "lz4") impl_->codec = 5;
     else if (compression == "zstd") impl_->codec = 6;
     else {
         delete impl_;
-        throw std::invalid_argument("compression '" + compression + "' is not available in this build (none, gzip, zstd)");
+        throw std::invalid_argument("invalid value '" + compression + "' for '--compression <COMPRESSION>' [possible values: none, snappy, gzip, lz4, zstd]");
     }
     if (impl_->codec == 2 && (level < 0 || level > 9)) impl_->level = 6;
     if (impl_->codec) (void)compress_page(impl_->codec, impl_->level, std::string("probe")); // fail now, not at the first page

@@ -312,6 +312,9 @@ private:
     vk_engine *engine_;
 };
 
+// parquet.cpp's page compressor by Parquet codec id (0 none, 1 snappy, 2 gzip, 5 lz4, 6 zstd), exposed for the tests
+std::string compress_page_for_test(int codec, const std::string &in);
+
 // Load a BIP-39 word list file (2048 whitespace-separated words of <= 8 bytes) into the engine (multibit transform).
 void load_bip39_wordlist(vk_engine *e, const std::string &path);
 
