@@ -411,7 +411,7 @@ int main(int argc, char **argv)
         for (const Transform &t : transforms)
             if (t.spec().kind == VK_T_MULTIBIT || (t.is_bitimage() && have_files)) {
                 if (bip39_file.empty()) throw std::invalid_argument(std::string(t.name()) + " needs --bip39-wordlist <FILE> (the 2048-word BIP-39 English list)");
-                load_bip39_wordlist(engine, bip39_file);
+                for (vk_engine *e : engines) load_bip39_wordlist(e, bip39_file);
                 break;
             }
 
@@ -455,7 +455,7 @@ int main(int argc, char **argv)
         std::unique_ptr<Source> source_ptr;
         if (have_files)
             source_ptr = std::make_unique<HipFilesSource>(files_dir.empty() ? HipFilesSource::from_file(engine, wordlist_file) : HipFilesSource::from_dir(engine, files_dir));
-        else if (have_wordlist) source_ptr = std::make_unique<HipWordlistSource>(engine, wordlist_file);
+        else if (have_wordlist) source_ptr = std::make_unique<HipWordlistSource>(engines, wordlist_file);
         else if (have_timestamps) source_ptr = std::make_unique<HipTimestampSource>(engine, start_s, end_s, microseconds);
         else if (engines.size() > 1) source_ptr = std::make_unique<HipMultiRangeSource>(engines, start, end);
         else source_ptr = std::make_unique<HipRangeSource>(engine, start, end);

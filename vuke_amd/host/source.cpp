@@ -160,19 +160,24 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
     if (matcher) {
         std::vector<uint8_t> h160, kind;
         matcher->device_targets(h160, kind);
-        check_rc(engine_, vk_targets_set(engine_, h160.data(), kind.data(), kind.size()));
+        for (vk_engine *e : engines_) check_rc(e, vk_targets_set(e, h160.data(), kind.data(), kind.size()));
     }
     const uint32_t flags = VK_F_COMPRESSED | VK_F_UNCOMPRESSED;
     const bool full = output.needs_full_record(), want_pub = output.needs_pubkeys();
     LineReader reader(fp);
     LineBatch b;
-    std::vector<uint8_t> keys, valid, flat;
-    std::vector<uint32_t> slot_of;
-    KeyDeriver deriver(engine_);
+    // what the device side of one slice of a batch produces: the emitted keys in emit order with the slot each came from,
+    // then either the hits (scan) or the derived values of every key (generate)
+    struct SliceOut {
+        std::vector<uint8_t> flat, norm, hc, hu, xy;
+        std::vector<uint32_t> slot_of;
+        std::vector<vk_hit> hits;
+        std::vector<DerivedKey> hit_derived;
+    };
     bool more = true;
     while (more) {
         b.clear();
-        more = reader.fill(b, 1u << 20, 256u << 20); // a million passphrases per device call
+        more = reader.fill(b, 1u << 20, 256u << 20); // a million passphrases per batch
         const size_t n = b.n();
         if (n == 0) continue;
         st.inputs_processed += n;
@@ -181,64 +186,97 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
             if (k == 0) continue; // a transform that needs Input::u64_val pushes nothing for a passphrase
             if (t.takes_strings() && b.max_len() > (t.spec().kind == VK_T_MULTIBIT ? 256u : 64u))
                 throw std::invalid_argument("input string too long for the device path (electrum 64, multibit 256 bytes)");
-            keys.resize(n * k * 32);
-            valid.resize(n * k);
-            check_rc(engine_, vk_transform_strings(engine_, &t.spec(), b.data.data(), b.offs.data(), n, keys.data(), valid.data()));
-            // keys the transform emitted, in emit order, with the slot each came from
-            flat.clear();
-            slot_of.clear();
-            for (size_t s = 0; s < n * k; s++)
-                if (valid[s]) {
-                    flat.insert(flat.end(), keys.begin() + 32 * s, keys.begin() + 32 * s + 32);
-                    slot_of.push_back((uint32_t)s);
+            auto run_slice = [&](vk_engine *eng, size_t first, size_t cnt, SliceOut &o) {
+                std::vector<uint32_t> offs(cnt + 1);
+                for (size_t i = 0; i <= cnt; i++) offs[i] = b.offs[first + i] - b.offs[first];
+                std::vector<uint8_t> keys(cnt * k * 32), valid(cnt * k);
+                check_rc(eng, vk_transform_strings(eng, &t.spec(), b.data.data() + b.offs[first], offs.data(), cnt, keys.data(), valid.data()));
+                for (size_t s = 0; s < cnt * k; s++)
+                    if (valid[s]) {
+                        o.flat.insert(o.flat.end(), keys.begin() + 32 * s, keys.begin() + 32 * s + 32);
+                        o.slot_of.push_back((uint32_t)(first * k + s));
+                    }
+                const size_t m = o.slot_of.size();
+                if (m == 0) return;
+                if (matcher) {
+                    o.hits.resize(4096);
+                    vk_sweep_stats ss;
+                    for (;;) {
+                        check_rc(eng, vk_scan_keys(eng, o.flat.data(), m, flags, o.hits.data(), o.hits.size(), &ss));
+                        if (!ss.hits_dropped) break;
+                        o.hits.resize(o.hits.size() + (size_t)ss.hits_dropped + 1024);
+                    }
+                    o.hits.resize((size_t)ss.matches);
+                    std::sort(o.hits.begin(), o.hits.end(), [](const vk_hit &x, const vk_hit &y) { return x.seed < y.seed; });
+                    std::vector<Key> hk(o.hits.size());
+                    for (size_t i = 0; i < o.hits.size(); i++) memcpy(hk[i].data(), &o.flat[32 * (size_t)o.hits[i].seed], 32);
+                    o.hit_derived = KeyDeriver(eng).derive(hk);
+                } else {
+                    o.norm.resize(m * 32);
+                    o.hc.resize(m * 20);
+                    o.hu.resize(m * 20);
+                    o.xy.resize(want_pub ? m * 64 : 0);
+                    check_rc(eng, vk_derive_batch_pub(eng, o.flat.data(), m, o.norm.data(), o.hc.data(), o.hu.data(), want_pub ? o.xy.data() : nullptr));
                 }
-            const size_t m = slot_of.size();
-            st.keys_generated += m;
-            if (m == 0) continue;
-            auto label_of = [&](size_t j) { return t.label(b.str(slot_of[j] / k), slot_of[j] % k); };
-            if (matcher) {
-                std::vector<vk_hit> hits(4096);
-                vk_sweep_stats ss;
-                for (;;) {
-                    check_rc(engine_, vk_scan_keys(engine_, flat.data(), m, flags, hits.data(), hits.size(), &ss));
-                    if (!ss.hits_dropped) break;
-                    hits.resize(hits.size() + (size_t)ss.hits_dropped + 1024);
-                }
-                hits.resize((size_t)ss.matches);
-                std::sort(hits.begin(), hits.end(), [](const vk_hit &x, const vk_hit &y) { return x.seed < y.seed; });
-                st.matches_found += ss.matches;
-                std::vector<Key> hk(hits.size());
-                for (size_t i = 0; i < hits.size(); i++) memcpy(hk[i].data(), &flat[32 * (size_t)hits[i].seed], 32);
-                std::vector<DerivedKey> derived = deriver.derive(hk);
-                for (size_t i = 0; i < hits.size(); i++) {
-                    MatchInfo mi;
-                    mi.address_type = hits[i].addr_kind == VK_ADDR_P2PKH_C   ? AddressType::P2pkhCompressed
-                                      : hits[i].addr_kind == VK_ADDR_P2PKH_U ? AddressType::P2pkhUncompressed
-                                                                             : AddressType::P2wpkh;
-                    mi.address = *derived[i].addresses()[hits[i].addr_kind];
-                    output.hit(label_of((size_t)hits[i].seed), t.name(), derived[i], mi);
-                }
+            };
+            // one contiguous slice of the batch per engine (independent inputs, no exchange); small batches stay on one
+            const size_t g = n < 4096 ? 1 : std::min(engines_.size(), n);
+            std::vector<SliceOut> outs(g);
+            if (g == 1) {
+                run_slice(engines_[0], 0, n, outs[0]);
             } else {
-                std::vector<uint8_t> norm(m * 32), hc(m * 20), hu(m * 20), xy(want_pub ? m * 64 : 0);
-                check_rc(engine_, vk_derive_batch_pub(engine_, flat.data(), m, norm.data(), hc.data(), hu.data(), want_pub ? xy.data() : nullptr));
-                for (size_t lo = 0; lo < m; lo += 1u << 18) { // bounded text buffers: ~1 KB per key
-                    const size_t cnt = std::min<size_t>(1u << 18, m - lo);
-                    std::vector<DerivedKey> derived(cnt);
-                    std::vector<std::string> labels(cnt);
-                    parallel_for(cnt, [&](size_t a0, size_t a1) {
-                        for (size_t i = a0; i < a1; i++) {
-                            derived[i] = full ? KeyDeriver::from_device(&norm[32 * (lo + i)], &hc[20 * (lo + i)], &hu[20 * (lo + i)])
-                                              : KeyDeriver::from_device_compact(&norm[32 * (lo + i)], &hc[20 * (lo + i)], &hu[20 * (lo + i)]);
-                            if (want_pub) KeyDeriver::set_pubkeys(derived[i], &xy[64 * (lo + i)]);
-                            labels[i] = label_of(lo + i);
+                std::vector<std::exception_ptr> err(g);
+                std::vector<std::thread> th;
+                for (size_t i = 0; i < g; i++)
+                    th.emplace_back([&, i]() {
+                        try {
+                            const size_t first = n * i / g, last = n * (i + 1) / g;
+                            run_slice(engines_[i], first, last - first, outs[i]);
+                        } catch (...) {
+                            err[i] = std::current_exception();
                         }
                     });
-                    for (size_t i = 0; i < cnt; i++) output.key(labels[i], t.name(), derived[i]);
+                for (auto &x : th) x.join();
+                for (auto &x : err)
+                    if (x) std::rethrow_exception(x);
+            }
+            // emission, in input order
+            for (SliceOut &o : outs) {
+                const size_t m = o.slot_of.size();
+                st.keys_generated += m;
+                if (m == 0) continue;
+                auto label_of = [&](size_t j) { return t.label(b.str(o.slot_of[j] / k), o.slot_of[j] % k); };
+                if (matcher) {
+                    st.matches_found += o.hits.size();
+                    for (size_t i = 0; i < o.hits.size(); i++) {
+                        MatchInfo mi;
+                        mi.address_type = o.hits[i].addr_kind == VK_ADDR_P2PKH_C   ? AddressType::P2pkhCompressed
+                                          : o.hits[i].addr_kind == VK_ADDR_P2PKH_U ? AddressType::P2pkhUncompressed
+                                                                                   : AddressType::P2wpkh;
+                        mi.address = *o.hit_derived[i].addresses()[o.hits[i].addr_kind];
+                        output.hit(label_of((size_t)o.hits[i].seed), t.name(), o.hit_derived[i], mi);
+                    }
+                } else {
+                    for (size_t lo = 0; lo < m; lo += 1u << 18) { // bounded text buffers: ~1 KB per key
+                        const size_t cnt = std::min<size_t>(1u << 18, m - lo);
+                        std::vector<DerivedKey> derived(cnt);
+                        std::vector<std::string> labels(cnt);
+                        parallel_for(cnt, [&](size_t a0, size_t a1) {
+                            for (size_t i = a0; i < a1; i++) {
+                                derived[i] = full ? KeyDeriver::from_device(&o.norm[32 * (lo + i)], &o.hc[20 * (lo + i)], &o.hu[20 * (lo + i)])
+                                                  : KeyDeriver::from_device_compact(&o.norm[32 * (lo + i)], &o.hc[20 * (lo + i)], &o.hu[20 * (lo + i)]);
+                                if (want_pub) KeyDeriver::set_pubkeys(derived[i], &o.xy[64 * (lo + i)]);
+                                labels[i] = label_of(lo + i);
+                            }
+                        });
+                        for (size_t i = 0; i < cnt; i++) output.key(labels[i], t.name(), derived[i]);
+                    }
                 }
             }
         }
     }
-    if (matcher) check_rc(engine_, vk_targets_set(engine_, nullptr, nullptr, 0));
+    if (matcher)
+        for (vk_engine *e : engines_) check_rc(e, vk_targets_set(e, nullptr, nullptr, 0));
     return st;
 }
 

@@ -272,15 +272,17 @@ private:
 
 // WordlistSource / StdinSource on the GPU (src/source/wordlist.rs, src/source/stdin.rs): one passphrase per line,
 // trimmed, empty lines skipped, Input::from_string.  path "-" reads stdin.  Transforms that need a numeric seed
-// emit nothing for these inputs, exactly like the reference.
+// emit nothing for these inputs, exactly like the reference.  With several engines every batch of lines is cut into one
+// contiguous slice per GPU (the inputs are independent, nothing is exchanged); records come out in input order.
 class HipWordlistSource : public Source {
 public:
-    HipWordlistSource(vk_engine *engine, std::string path) : path(std::move(path)), engine_(engine) {}
+    HipWordlistSource(vk_engine *engine, std::string path) : path(std::move(path)), engines_{engine} {}
+    HipWordlistSource(std::vector<vk_engine *> engines, std::string path) : path(std::move(path)), engines_(std::move(engines)) {}
     ProcessStats process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output) override;
     std::string path;
 
 private:
-    vk_engine *engine_;
+    std::vector<vk_engine *> engines_;
 };
 
 // TimestampSource on the GPU (src/source/timestamps.rs): every second of [start_date 00:00:00, end_date 23:59:59] UTC
