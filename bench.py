@@ -224,6 +224,17 @@ def main():
                    if "valu_insts_per_key" in extra else {}),
             },
         }
+        # the same launch priced against the memory system, in the contract's own form (the kernel is not HBM-bound: see frac)
+        algo_bytes_per_key = eng.info()["windows"] * 64 + 128 + 160 + 32  # table entries + workspace write + workspace read + target probe
+        out["roofline_hbm"] = {
+            "bound": "hbm",
+            "achieved": algo_bytes_per_key * per_launch_keys / per_launch_s / 1e9,
+            "peak": 8000.0,
+            "unit": "GB/s",
+            "frac": algo_bytes_per_key * per_launch_keys / per_launch_s / 8e12,
+            "traffic": traffic,
+            "algorithmic_bytes_per_key": algo_bytes_per_key,
+        }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
