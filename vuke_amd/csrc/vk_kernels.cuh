@@ -31,6 +31,10 @@
 #ifndef VK_COOP_GATHER
 #define VK_COOP_GATHER 2
 #endif
+// 1: the sweep's accumulator in XYZZ coordinates (vk_ec.cuh; needs VK_COOP_GATHER 2), 0: Jacobian
+#ifndef VK_XYZZ
+#define VK_XYZZ (VK_COOP_GATHER == 2)
+#endif
 #ifndef VK_SWEEP_WAVES
 #define VK_SWEEP_WAVES 2 /* minimum waves per SIMD the sweep kernel is register-budgeted for */
 #endif
@@ -172,6 +176,35 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
         for (u32 b = 0; b < B; b++) {
             const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
             u32 kw[8];
+#if VK_XYZZ
+            // parked per item: X*ZZZ, Y*ZZ, e = ZZ*ZZZ and the running product of e: x = (X*ZZZ) / e, y = (Y*ZZ) / e
+            uint4 *it = wk + (u64)b * 8 * nth;
+            {
+                const bool have = item_key<KIND>(kw, p, off, sub);
+                u32 k[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) k[i] = have ? kw[7 - i] : (i == 0 ? 1u : 0u); // lanes without a key walk the table with k = 1
+                scalar_normalize(k);
+                xyzz Q;
+                ecmult_table_lds_xyzz(Q, k, p.table, p.wins, p.nwin, gtile);
+                fe e;
+                if (have) {
+                    fe_mul(Q.x, Q.x, Q.zzz);
+                    fe_mul(Q.y, Q.y, Q.zz);
+                    fe_mul(e, Q.zz, Q.zzz);
+                } else { // (0, 0) with e = 1 marks "no key here"; (0,0) is not on the curve
+                    fe_set_zero(Q.x);
+                    fe_set_zero(Q.y);
+                    fe_set_one(e);
+                }
+                if (b == 0) c = e;
+                else fe_mul(c, c, e);
+                work_store(it, nth, Q.x);
+                work_store(it + 2 * nth, nth, Q.y);
+                work_store(it + 4 * nth, nth, e);
+                work_store(it + 6 * nth, nth, c);
+            }
+#else
             jac P;
 #if VK_COOP_GATHER
             {
@@ -211,6 +244,7 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
             work_store(it + 2 * nth, nth, P.y);
             work_store(it + 4 * nth, nth, P.z);
             work_store(it + 6 * nth, nth, c);
+#endif
             if (++sub == p.slots) {
                 sub = 0;
                 r++;
@@ -248,7 +282,14 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
             for (int i = 0; i < 8; i++) nz |= P.x.v[i] | P.y.v[i];
             if (nz == 0) continue;
             fe x, y;
+#if VK_XYZZ
+            fe_mul(x, P.x, zinv); // P.x = X*ZZZ, P.y = Y*ZZ, zinv = 1 / (ZZ*ZZZ)
+            fe_mul(y, P.y, zinv);
+            fe_canon(x);
+            fe_canon(y);
+#else
             jac_to_affine(x, y, P, zinv);
+#endif
             n_keys++;
             const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
             u32 hc[5], hu[5];
