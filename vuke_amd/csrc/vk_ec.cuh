@@ -426,9 +426,9 @@ VK_DEV void ecmult_table_lds(jac &acc, const u32 k[8], const uint4 *__restrict__
 
 // ---- the sweep's accumulator in XYZZ coordinates ---------------------------------------------------------------------
 // (X, Y, ZZ, ZZZ) with x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2.  Adding an affine point costs 8M + 2S instead of the
-// 8M + 3S of the Jacobian mixed addition (no Z^2 to recompute: "madd-2008-s"); the price is paid once per key when the
-// point leaves the chain -- X*ZZZ, Y*ZZ and ZZ*ZZZ for the batch inversion instead of one Z -- so a k*G with seven
-// such additions saves 7S and pays 2M - 1S: about 3 % of the sweep's instructions.
+// 8M + 3S of the Jacobian mixed addition (no Z^2 to recompute: "madd-2008-s").  Leaving the chain costs the same as
+// before: ZZZ goes through the batch inversion, y = Y / ZZZ, x = X * ZZ^2 / ZZZ^2 (ZZ^3 = ZZZ^2) -- 2S + 3M per key like
+// the Jacobian 1S + 3M plus one squaring -- so a k*G with seven such additions saves about 6S: 4 % of the sweep.
 struct xyzz {
     fe x, y, zz, zzz;
 };

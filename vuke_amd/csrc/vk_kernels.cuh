@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
             const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
             u32 kw[8];
 #if VK_XYZZ
-            // parked per item: X*ZZZ, Y*ZZ, e = ZZ*ZZZ and the running product of e: x = (X*ZZZ) / e, y = (Y*ZZ) / e
+            // parked per item: X*ZZ^2, Y, e = ZZZ and the running product of e: y = Y / e, x = X*ZZ^2 / e^2 (ZZ^3 = ZZZ^2)
             uint4 *it = wk + (u64)b * 8 * nth;
             {
                 const bool have = item_key<KIND>(kw, p, off, sub);
@@ -189,9 +189,9 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
                 ecmult_table_lds_xyzz(Q, k, p.table, p.wins, p.nwin, gtile);
                 fe e;
                 if (have) {
-                    fe_mul(Q.x, Q.x, Q.zzz);
-                    fe_mul(Q.y, Q.y, Q.zz);
-                    fe_mul(e, Q.zz, Q.zzz);
+                    fe_sqr(e, Q.zz);
+                    fe_mul(Q.x, Q.x, e);
+                    e = Q.zzz;
                 } else { // (0, 0) with e = 1 marks "no key here"; (0,0) is not on the curve
                     fe_set_zero(Q.x);
                     fe_set_zero(Q.y);
@@ -283,8 +283,9 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
             if (nz == 0) continue;
             fe x, y;
 #if VK_XYZZ
-            fe_mul(x, P.x, zinv); // P.x = X*ZZZ, P.y = Y*ZZ, zinv = 1 / (ZZ*ZZZ)
-            fe_mul(y, P.y, zinv);
+            fe_mul(y, P.y, zinv); // P.x = X*ZZ^2, P.y = Y, zinv = 1 / ZZZ
+            fe_sqr(zinv, zinv);
+            fe_mul(x, P.x, zinv);
             fe_canon(x);
             fe_canon(y);
 #else
