@@ -39,7 +39,8 @@ def test_field_ops(eng):
     a = [rnd.choice(vals) for _ in range(2000)] + vals
     b = [rnd.choice(vals) for _ in range(2000)] + vals[::-1]
     ab, bb = [be(x) for x in a], [be(x) for x in b]
-    for op, f in ((0, lambda x, y: x * y % P), (3, lambda x, y: (x + y) % P), (4, lambda x, y: (x - y) % P)):
+    for op, f in ((0, lambda x, y: x * y % P), (3, lambda x, y: (x + y) % P), (4, lambda x, y: (x - y) % P),
+                  (5, lambda x, y: (x - 3 * y) % P), (6, lambda x, y: (-x - y) % P), (7, lambda x, y: (-x - 3 * y) % P)):  # fe_sub3 = a - b - 2c
         got = eng.field_op(op, ab, bb)
         for x, y, g in zip(a, b, got):
             assert int.from_bytes(g, "big") == f(x, y), (op, hex(x), hex(y))

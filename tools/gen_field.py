@@ -289,10 +289,45 @@ def gen_addsub():
     return "".join(L)
 
 
+def gen_sub3():
+    """r = a - b - 2c: three borrow chains, the borrows counted, one fix-up of count * (2^32 + 977)."""
+    L = ["// r = a - b - 2c (mod p), weakly reduced: the x-coordinate of every point addition.  r may alias a, b or c.\n"]
+    L.append("VK_DEV void fe_sub3(fe &r, const fe &a, const fe &b, const fe &c)\n{\n    u32 d[8], e[8], f[8];\n    vk_carry c1, c2, c3;\n")
+    A, B, C = ([f"{n}.v[{j}]" for j in range(8)] for n in "abc")
+    D, E, F = ([f"{n}[{j}]" for j in range(8)] for n in "def")
+    L.append(chain(D, A, B, carry_out="c1", sub=True))
+    L.append(chain(E, D, C, carry_out="c2", sub=True))
+    L.append(chain(F, E, C, carry_out="c3", sub=True))
+    L.append("    u32 k, k0;\n    vk_carry c4;\n")
+    a = Asm()
+    for x in ("k", "k0"):
+        a.out("=&v", x)
+    for j in range(8):
+        a.out("=&v", f"r.v[{j}]")
+    a.out("=&s", "c4")
+    for j in range(8):
+        a.inp("v", F[j])
+    for x in ("c1", "c2", "c3"):
+        a.inp("s", x)
+    a.inp("v", "VK_PC0")
+    a.ins_("v_cndmask_b32 {}, 0, 1, {}", "k", "c1")
+    a.ins_("v_addc_co_u32 {}, vcc, {}, 0, {}", "k", "k", "c2")
+    a.ins_("v_addc_co_u32 {}, vcc, {}, 0, {}", "k", "k", "c3")
+    a.ins_("v_mul_u32_u24 {}, {}, {}", "k0", "k", "VK_PC0")
+    a.ins_("v_sub_co_u32 {}, vcc, {}, {}", "r.v[0]", F[0], "k0")
+    a.ins_("v_subb_co_u32 {}, vcc, {}, {}, vcc", "r.v[1]", F[1], "k")
+    for j in range(2, 7):
+        a.ins_("v_subb_co_u32 {}, vcc, {}, 0, vcc", f"r.v[{j}]", F[j])
+    a.ins_("v_subb_co_u32 {}, {}, {}, 0, vcc", "r.v[7]", "c4", F[7])
+    L.append(a.render())
+    L.append("    if (__builtin_expect(c4 != 0, 0)) fe_wrap_sub(r, c4); // the fix-up wrapped: only for results in the sliver next to zero\n}\n\n")
+    return "".join(L)
+
+
 def main():
     hdr = "// GENERATED by tools/gen_field.py -- do not edit.  Column kernels of the 256-bit multiply / square\n"
     hdr += "// on v_mad_u64_u32 (see the scheme in vk_field.cuh).\n#pragma once\n\n"
-    txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_addsub() + gen_reduce()
+    txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_addsub() + gen_sub3() + gen_reduce()
     open(OUT, "w").write(txt)
     print("wrote", OUT, len(txt.splitlines()), "lines")
 

@@ -186,6 +186,9 @@ __global__ void vk_field_kernel(int op, const u32 *a, const u32 *b, u64 n, u32 *
     case 1: fe_sqr(r, x); break;
     case 2: fe_inv(r, x); break;
     case 3: fe_add(r, x, y); break;
+    case 5: fe_sub3(r, x, y, y); break;                      // x - 3y
+    case 6: r = x; fe_sub3(r, r, y, r); break;               // -x - y, result and third operand aliasing the first
+    case 7: fe_add(r, x, y); fe_sub3(r, x, y, r); break;     // -x - 3y, result aliasing the third
     default: fe_sub(r, x, y); break;
     }
     fe_canon(r);

@@ -30,9 +30,7 @@ VK_DEV void jac_madd(jac &r, const jac &p, const fe &qx, const fe &qy)
     fe_mul(v, p.x, h2);
     fe_mul(r.z, p.z, h); // last use of p.z
     fe_sqr(t, rr);
-    fe_sub(t, t, h3);
-    fe_sub(t, t, v);
-    fe_sub(t, t, v);     // x3
+    fe_sub3(t, t, h3, v);     // x3
     fe_mul(h3, h3, p.y); // y1 * h^3 (last use of p.y)
     fe_sub(v, v, t);
     fe_mul(v, v, rr);
@@ -51,9 +49,7 @@ VK_DEV void jac_aadd(jac &r, const fe &px, const fe &py, const fe &qx, const fe 
     fe_mul(h3, h2, h);
     fe_mul(v, px, h2);
     fe_sqr(t, rr);
-    fe_sub(t, t, h3);
-    fe_sub(t, t, v);
-    fe_sub(t, t, v); // x3
+    fe_sub3(t, t, h3, v); // x3
     fe_mul(h3, h3, py);
     fe_sub(v, v, t);
     fe_mul(v, v, rr);
@@ -446,9 +442,7 @@ VK_DEV void xyzz_madd(xyzz &r, const fe &qx, const fe &qy)
     fe_mul(r.zz, r.zz, pp);
     fe_mul(r.zzz, r.zzz, ppp);
     fe_sqr(t, s2);
-    fe_sub(t, t, ppp);
-    fe_sub(t, t, q);
-    fe_sub(t, t, q);           // X3
+    fe_sub3(t, t, ppp, q);           // X3
     fe_mul(ppp, ppp, r.y);     // Y1 * P^3
     fe_sub(q, q, t);
     fe_mul(q, q, s2);
@@ -465,9 +459,7 @@ VK_DEV void xyzz_aadd(xyzz &r, const fe &qx, const fe &qy)
     fe_mul(r.zzz, r.zz, h);
     fe_mul(q, r.x, r.zz);
     fe_sqr(t, rr);
-    fe_sub(t, t, r.zzz);
-    fe_sub(t, t, q);
-    fe_sub(t, t, q);           // x3
+    fe_sub3(t, t, r.zzz, q);           // x3
     fe_mul(yp, r.zzz, r.y);
     fe_sub(q, q, t);
     fe_mul(q, q, rr);
