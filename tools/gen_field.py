@@ -204,30 +204,8 @@ def chain(dst, xs, ys, first_carry_in=None, carry_out=None, sub=False):
     return a.render()
 
 
-def gen_reduce():
+def fold_stage():
     L = []
-    L.append("// r = t_lo + t_hi * (2^32 + 977) folded to 8 limbs, weakly reduced (see vk_field.cuh)\n")
-    L.append("VK_DEV void fe_reduce16(fe &r, const u32 t[16])\n{\n")
-    L.append("    u32 ql[8], qh[8];\n#pragma unroll\n    for (int i = 0; i < 8; i++) {\n        u64 q = mul_wide_s(t[8 + i], VK_PC0);\n        ql[i] = (u32)q;\n        qh[i] = (u32)(q >> 32);\n    }\n")
-    L.append("    u32 a[9], b[9], s[9];\n    vk_carry c1, c3;\n")
-    # chain 1: a_j = t_j + ql_j, a_8 = carry
-    a = Asm()
-    for j in range(9):
-        a.out("=&v", f"a[{j}]")
-    for j in range(8):
-        a.inp("v", f"t[{j}]")
-    for j in range(8):
-        a.inp("v", f"ql[{j}]")
-    a.ins_("v_add_co_u32 {}, vcc, {}, {}", "a[0]", "t[0]", "ql[0]")
-    for j in range(1, 8):
-        a.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", f"a[{j}]", f"t[{j}]", f"ql[{j}]")
-    a.ins_("v_addc_co_u32 {}, vcc, 0, 0, vcc", "a[8]")
-    L.append(a.render())
-    # chain 2: b_j = a_j + qh_{j-1}, j = 1..8 (no carry out of limb 8)
-    L.append(chain([f"b[{j}]" for j in range(1, 9)], [f"a[{j}]" for j in range(1, 9)], [f"qh[{j - 1}]" for j in range(1, 9)]))
-    # chain 3: s_j = b_j + t[8+j-1], j = 1..8, carry out c3 = bit 32 of limb 8
-    L.append(chain([f"s[{j}]" for j in range(1, 9)], [f"b[{j}]" for j in range(1, 9)], [f"t[{7 + j}]" for j in range(1, 9)], carry_out="c3"))
-    L.append("    s[0] = a[0];\n")
     # stage 3: fold o = s[8] + 2^32*c3:  o*C = s8*977 + (s8 << 32) + c3*(977 << 32) + c3 << 64
     L.append("    u64 m = mul_wide_s(s[8], VK_PC0);\n    u32 ml = (u32)m, mh = (u32)(m >> 32);\n")
     L.append("    u32 w1, w2;\n    vk_carry c4;\n")
@@ -253,6 +231,35 @@ def gen_reduce():
         a.ins_("v_addc_co_u32 {}, vcc, 0, {}, vcc", f"r.v[{j}]", f"s[{j}]")
     a.ins_("v_addc_co_u32 {}, {}, 0, {}, vcc", "r.v[7]", "c4", "s[7]")
     L.append(a.render())
+    return "".join(L)
+
+
+def gen_reduce():
+    L = []
+    L.append("// r = t_lo + t_hi * (2^32 + 977) folded to 8 limbs, weakly reduced (see vk_field.cuh): the form without any\n")
+    L.append("// precondition on t_hi -- three carry chains; fe_reduce16 falls back to it\n")
+    L.append("VK_DEV void fe_reduce16_slow(fe &r, const u32 t[16])\n{\n")
+    L.append("    u32 ql[8], qh[8];\n#pragma unroll\n    for (int i = 0; i < 8; i++) {\n        u64 q = mul_wide_s(t[8 + i], VK_PC0);\n        ql[i] = (u32)q;\n        qh[i] = (u32)(q >> 32);\n    }\n")
+    L.append("    u32 a[9], b[9], s[9];\n    vk_carry c1, c3;\n")
+    # chain 1: a_j = t_j + ql_j, a_8 = carry
+    a = Asm()
+    for j in range(9):
+        a.out("=&v", f"a[{j}]")
+    for j in range(8):
+        a.inp("v", f"t[{j}]")
+    for j in range(8):
+        a.inp("v", f"ql[{j}]")
+    a.ins_("v_add_co_u32 {}, vcc, {}, {}", "a[0]", "t[0]", "ql[0]")
+    for j in range(1, 8):
+        a.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", f"a[{j}]", f"t[{j}]", f"ql[{j}]")
+    a.ins_("v_addc_co_u32 {}, vcc, 0, 0, vcc", "a[8]")
+    L.append(a.render())
+    # chain 2: b_j = a_j + qh_{j-1}, j = 1..8 (no carry out of limb 8)
+    L.append(chain([f"b[{j}]" for j in range(1, 9)], [f"a[{j}]" for j in range(1, 9)], [f"qh[{j - 1}]" for j in range(1, 9)]))
+    # chain 3: s_j = b_j + t[8+j-1], j = 1..8, carry out c3 = bit 32 of limb 8
+    L.append(chain([f"s[{j}]" for j in range(1, 9)], [f"b[{j}]" for j in range(1, 9)], [f"t[{7 + j}]" for j in range(1, 9)], carry_out="c3"))
+    L.append("    s[0] = a[0];\n")
+    L.append(fold_stage())
     L.append("    if (__builtin_expect(c4 != 0, 0)) fe_wrap_add(r, c4); // value was 2^256 + small: add C (cannot carry again)\n}\n\n")
     return "".join(L)
 
@@ -286,6 +293,48 @@ def gen_addsub():
         L.append(a.render())
         fn = "fe_wrap_sub" if sub else "fe_wrap_add"
         L.append(f"    if (__builtin_expect(c2 != 0, 0)) {fn}(r, c2); // second wrap: only for operands in the 2^32-wide sliver next to 2^256\n}}\n\n")
+    return "".join(L)
+
+
+def gen_reduce_fast():
+    """r = t_lo + t_hi * C with one multiply-add per high limb: t[8+i] * 977 + (t[8+i] : t[i]) is the whole contribution of
+    limb pair i at position i; it fits 64 bits unless t[8+i] >= 2^32 - 977 - 1 (one multiply in 2^22), which the
+    multiplier's carry-out reports: any lane of the wave -> the three-chain form.  Otherwise one chain sums the overlapping
+    halves."""
+    L = []
+    L.append("// r = t_lo + t_hi * (2^32 + 977), weakly reduced: 8 multiply-adds that also add t_lo and t_hi << 32, one carry chain, fold\n")
+    L.append("VK_DEV void fe_reduce16(fe &r, const u32 t[16])\n{\n")
+    L.append("    // no multiply-add below can overflow 64 bits when t[8 + i] <= 2^32 - 978: (2^32 - 978)(2^32 + 977) + 2^32 - 1 < 2^64\n")
+    L.append("    u32 mx = t[8];\n#pragma unroll\n    for (int i = 9; i < 16; i++) mx = mx > t[i] ? mx : t[i]; // v_max3_u32 x 3 + v_max_u32\n")
+    L.append("    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > 0xFFFFFC2Eu) != 0, 0)) {\n        fe_reduce16_slow(r, t);\n    } else {\n")
+    L.append("    u64 v[8];\n#pragma unroll\n    for (int i = 0; i < 8; i++) v[i] = ((u64)t[8 + i] << 32) | t[i];\n")
+    for half in range(2):
+        a = Asm()
+        for i in range(4 * half, 4 * half + 4):
+            a.out("+v", f"v[{i}]")
+        for i in range(4 * half, 4 * half + 4):
+            a.inp("v", f"t[{8 + i}]")
+        a.inp("s", "VK_PC0")
+        for i in range(4 * half, 4 * half + 4):
+            a.ins_("v_mad_u64_u32 {}, vcc, {}, {}, {}", f"v[{i}]", f"t[{8 + i}]", "VK_PC0", f"v[{i}]")
+        L.append(a.render())
+    L.append("    u32 lo[8], hi[8], s[9];\n#pragma unroll\n    for (int i = 0; i < 8; i++) {\n        lo[i] = (u32)v[i];\n        hi[i] = (u32)(v[i] >> 32);\n    }\n    vk_carry c3;\n")
+    a = Asm()
+    for j in range(1, 9):
+        a.out("=&v", f"s[{j}]")
+    a.out("=&s", "c3")
+    for j in range(1, 8):
+        a.inp("v", f"lo[{j}]")
+    for j in range(8):
+        a.inp("v", f"hi[{j}]")
+    a.ins_("v_add_co_u32 {}, vcc, {}, {}", "s[1]", "lo[1]", "hi[0]")
+    for j in range(2, 8):
+        a.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", f"s[{j}]", f"lo[{j}]", f"hi[{j - 1}]")
+    a.ins_("v_addc_co_u32 {}, {}, 0, {}, vcc", "s[8]", "c3", "hi[7]")
+    L.append(a.render())
+    L.append("    s[0] = lo[0];\n")
+    L.append(fold_stage())
+    L.append("    if (__builtin_expect(c4 != 0, 0)) fe_wrap_add(r, c4); // value was 2^256 + small: add C (cannot carry again)\n    }\n}\n\n")
     return "".join(L)
 
 
@@ -327,7 +376,7 @@ def gen_sub3():
 def main():
     hdr = "// GENERATED by tools/gen_field.py -- do not edit.  Column kernels of the 256-bit multiply / square\n"
     hdr += "// on v_mad_u64_u32 (see the scheme in vk_field.cuh).\n#pragma once\n\n"
-    txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_addsub() + gen_sub3() + gen_reduce()
+    txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_addsub() + gen_sub3() + gen_reduce() + gen_reduce_fast()
     open(OUT, "w").write(txt)
     print("wrote", OUT, len(txt.splitlines()), "lines")
 
