@@ -270,15 +270,15 @@ def gen_addsub():
         L.append(f"// r = a {'-' if sub else '+'} b (mod p), weakly reduced; operands may alias\n")
         L.append(f"VK_DEV void {name}(fe &r, const fe &a, const fe &b)\n{{\n    u32 d[8];\n    vk_carry c1;\n")
         L.append(chain([f"d[{j}]" for j in range(8)], [f"a.v[{j}]" for j in range(8)], [f"b.v[{j}]" for j in range(8)], carry_out="c1", sub=sub))
-        # fix-up: +/- C under mask c1
+        # fix-up: +/- C under mask c1, limbs 0 and 1 only; a carry beyond goes through fe_ripple_*
         L.append("    u32 k0, k1;\n    vk_carry c2;\n")
         a = Asm()
         for e in ("k0", "k1"):
             a.out("=&v", e)
-        for j in range(8):
+        for j in range(2):
             a.out("=&v", f"r.v[{j}]")
         a.out("=&s", "c2")
-        for j in range(8):
+        for j in range(2):
             a.inp("v", f"d[{j}]")
         a.inp("s", "c1")
         a.inp("v", "VK_PC0")
@@ -286,13 +286,11 @@ def gen_addsub():
         a.ins_("v_cndmask_b32 {}, 0, 1, {}", "k1", "c1")
         o0, oc = ("v_sub_co_u32", "v_subb_co_u32") if sub else ("v_add_co_u32", "v_addc_co_u32")
         a.ins_(o0 + " {}, vcc, {}, {}", "r.v[0]", "d[0]", "k0")
-        a.ins_(oc + " {}, vcc, {}, {}, vcc", "r.v[1]", "d[1]", "k1")
-        for j in range(2, 7):
-            a.ins_(oc + " {}, vcc, {}, 0, vcc", f"r.v[{j}]", f"d[{j}]")
-        a.ins_(oc + " {}, {}, {}, 0, vcc", "r.v[7]", "c2", "d[7]")
+        a.ins_(oc + " {}, {}, {}, {}, vcc", "r.v[1]", "c2", "d[1]", "k1")
         L.append(a.render())
-        fn = "fe_wrap_sub" if sub else "fe_wrap_add"
-        L.append(f"    if (__builtin_expect(c2 != 0, 0)) {fn}(r, c2); // second wrap: only for operands in the 2^32-wide sliver next to 2^256\n}}\n\n")
+        L.append("#pragma unroll\n    for (int i = 2; i < 8; i++) r.v[i] = d[i];\n")
+        fn = "fe_ripple_sub" if sub else "fe_ripple_add"
+        L.append(f"    if (__builtin_expect(c2 != 0, 0)) {fn}(r, 2, c2);\n}}\n\n")
     return "".join(L)
 
 
@@ -351,10 +349,10 @@ def gen_sub3():
     a = Asm()
     for x in ("k", "k0"):
         a.out("=&v", x)
-    for j in range(8):
+    for j in range(2):
         a.out("=&v", f"r.v[{j}]")
     a.out("=&s", "c4")
-    for j in range(8):
+    for j in range(2):
         a.inp("v", F[j])
     for x in ("c1", "c2", "c3"):
         a.inp("s", x)
@@ -364,12 +362,10 @@ def gen_sub3():
     a.ins_("v_addc_co_u32 {}, vcc, {}, 0, {}", "k", "k", "c3")
     a.ins_("v_mul_u32_u24 {}, {}, {}", "k0", "k", "VK_PC0")
     a.ins_("v_sub_co_u32 {}, vcc, {}, {}", "r.v[0]", F[0], "k0")
-    a.ins_("v_subb_co_u32 {}, vcc, {}, {}, vcc", "r.v[1]", F[1], "k")
-    for j in range(2, 7):
-        a.ins_("v_subb_co_u32 {}, vcc, {}, 0, vcc", f"r.v[{j}]", F[j])
-    a.ins_("v_subb_co_u32 {}, {}, {}, 0, vcc", "r.v[7]", "c4", F[7])
+    a.ins_("v_subb_co_u32 {}, {}, {}, {}, vcc", "r.v[1]", "c4", F[1], "k")
     L.append(a.render())
-    L.append("    if (__builtin_expect(c4 != 0, 0)) fe_wrap_sub(r, c4); // the fix-up wrapped: only for results in the sliver next to zero\n}\n\n")
+    L.append("#pragma unroll\n    for (int i = 2; i < 8; i++) r.v[i] = f[i];\n")
+    L.append("    if (__builtin_expect(c4 != 0, 0)) fe_ripple_sub(r, 2, c4); // the fix-up borrowed past limb 1\n}\n\n")
     return "".join(L)
 
 

@@ -117,6 +117,56 @@ VK_DEV void fe_wrap_sub(fe &r, vk_carry mask)
     }
 }
 
+// The fix-ups of the generated add / sub / reduce touch limbs 0..1 (0..2 in the reduction) and almost never carry further
+// (one operation in 2^31), so their carry chains stop there and the lanes that do carry come here: +-1 from limb `from`
+// upwards; a carry out of limb 7 is one more wrap of 2^256, i.e. one more +-C (the value is tiny then: no third wrap).
+VK_DEV void fe_ripple_add(fe &r, int from, vk_carry mask)
+{
+    if (!lane_in_mask(mask)) return;
+    u32 c = 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i < from) continue;
+        const u32 v = r.v[i] + c;
+        c = (v < c) ? 1u : 0u;
+        r.v[i] = v;
+    }
+    if (c) {
+        u64 t = (u64)r.v[0] + VK_PC0;
+        r.v[0] = (u32)t;
+        t = (t >> 32) + r.v[1] + 1u;
+        r.v[1] = (u32)t;
+#pragma unroll
+        for (int i = 2; i < 8; i++) {
+            t = (t >> 32) + r.v[i];
+            r.v[i] = (u32)t;
+        }
+    }
+}
+VK_DEV void fe_ripple_sub(fe &r, int from, vk_carry mask)
+{
+    if (!lane_in_mask(mask)) return;
+    u32 b = 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i < from) continue;
+        const u32 v = r.v[i] - b;
+        b = (r.v[i] < b) ? 1u : 0u;
+        r.v[i] = v;
+    }
+    if (b) {
+        u64 d = (u64)r.v[0] - VK_PC0;
+        r.v[0] = (u32)d;
+        d = (u64)r.v[1] - 1u - ((d >> 32) & 1);
+        r.v[1] = (u32)d;
+#pragma unroll
+        for (int i = 2; i < 8; i++) {
+            d = (u64)r.v[i] - ((d >> 32) & 1);
+            r.v[i] = (u32)d;
+        }
+    }
+}
+
 #include "vk_field_gen.cuh" // fe_mul_cols, fe_sqr_cols, merge_eo (generated by tools/gen_field.py)
 
 VK_DEV void fe_mul(fe &r, const fe &a, const fe &b)
