@@ -41,7 +41,7 @@ def test_field_ops(eng):
     # every pair of edge values: the rare paths of the short fix-up chains (a borrow / carry past limb 1 or 2, down to a
     # second wrap of 2^256) need operands like 3 - (2^256 - 1), (2^256 - 1) + (2^256 - 1), 10 - (2^64 + 10)
     edge = [0, 1, 2, 3, 10, 976, 977, 978, 2**32 - 1, 2**32, 2**32 + 976, 2**32 + 977, 2**32 + 978, 2**64 - 1, 2**64, 2**64 + 10, 2**96 - 1, 2**96,
-            2**224 - 1, 2**255, P - 2, P - 1, P, P + 1, 2**256 - 2**64, 2**256 - 2**32 - 978, 2**256 - 2**32 - 977, 2**256 - 978, 2**256 - 977, 2**256 - 2, 2**256 - 1]
+            2**224 - 1, 2**255, (2**32 - 491) << 224, (2**32 - 490) << 224, (2**32 - 489) << 224, (2**32 - 979) << 224, (2**32 - 978) << 224, P - 2, P - 1, P, P + 1, 2**256 - 2**64, 2**256 - 2**32 - 978, 2**256 - 2**32 - 977, 2**256 - 978, 2**256 - 977, 2**256 - 2, 2**256 - 1]
     a += [x for x in edge for _ in edge]
     b += [y for _ in edge for y in edge]
     ab, bb = [be(x) for x in a], [be(x) for x in b]

@@ -302,9 +302,9 @@ def gen_reduce_fast():
     L = []
     L.append("// r = t_lo + t_hi * (2^32 + 977), weakly reduced: 8 multiply-adds that also add t_lo and t_hi << 32, one carry chain, fold\n")
     L.append("VK_DEV void fe_reduce16(fe &r, const u32 t[16])\n{\n")
-    L.append("    // no multiply-add below can overflow 64 bits when t[8 + i] <= 2^32 - 978: (2^32 - 978)(2^32 + 977) + 2^32 - 1 < 2^64\n")
+    L.append("    // with every t[8 + i] <= 2^32 - 979 no multiply-add below overflows 64 bits ((2^32 - 979)(2^32 + 977) + 2^32 - 1 < 2^64)\n    // and limb 8 of the sum stays below 2^32 (hi[7] <= t[15] + 977 <= 2^32 - 2, plus one carry)\n")
     L.append("    u32 mx = t[8];\n#pragma unroll\n    for (int i = 9; i < 16; i++) mx = mx > t[i] ? mx : t[i]; // v_max3_u32 x 3 + v_max_u32\n")
-    L.append("    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > 0xFFFFFC2Eu) != 0, 0)) {\n        fe_reduce16_slow(r, t);\n    } else {\n")
+    L.append("    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > 0xFFFFFC2Du) != 0, 0)) {\n        fe_reduce16_slow(r, t);\n    } else {\n")
     L.append("    u64 v[8];\n#pragma unroll\n    for (int i = 0; i < 8; i++) v[i] = ((u64)t[8 + i] << 32) | t[i];\n")
     for half in range(2):
         a = Asm()
@@ -316,11 +316,10 @@ def gen_reduce_fast():
         for i in range(4 * half, 4 * half + 4):
             a.ins_("v_mad_u64_u32 {}, vcc, {}, {}, {}", f"v[{i}]", f"t[{8 + i}]", "VK_PC0", f"v[{i}]")
         L.append(a.render())
-    L.append("    u32 lo[8], hi[8], s[9];\n#pragma unroll\n    for (int i = 0; i < 8; i++) {\n        lo[i] = (u32)v[i];\n        hi[i] = (u32)(v[i] >> 32);\n    }\n    vk_carry c3;\n")
+    L.append("    u32 lo[8], hi[8], s[9];\n#pragma unroll\n    for (int i = 0; i < 8; i++) {\n        lo[i] = (u32)v[i];\n        hi[i] = (u32)(v[i] >> 32);\n    }\n")
     a = Asm()
     for j in range(1, 9):
         a.out("=&v", f"s[{j}]")
-    a.out("=&s", "c3")
     for j in range(1, 8):
         a.inp("v", f"lo[{j}]")
     for j in range(8):
@@ -328,10 +327,29 @@ def gen_reduce_fast():
     a.ins_("v_add_co_u32 {}, vcc, {}, {}", "s[1]", "lo[1]", "hi[0]")
     for j in range(2, 8):
         a.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", f"s[{j}]", f"lo[{j}]", f"hi[{j - 1}]")
-    a.ins_("v_addc_co_u32 {}, {}, 0, {}, vcc", "s[8]", "c3", "hi[7]")
+    a.ins_("v_addc_co_u32 {}, vcc, 0, {}, vcc", "s[8]", "hi[7]")
     L.append(a.render())
     L.append("    s[0] = lo[0];\n")
-    L.append(fold_stage())
+    # fold limb 8 (< 2^32): s8 * C = s8 * 977 + (s8 << 32)
+    L.append("    u64 m = mul_wide_s(s[8], VK_PC0);\n    u32 ml = (u32)m, mh = (u32)(m >> 32);\n")
+    L.append("    u32 w1, w2;\n    vk_carry c4;\n")
+    a = Asm()
+    for e in ("w1", "w2"):
+        a.out("=&v", e)
+    for j in range(8):
+        a.out("=&v", f"r.v[{j}]")
+    a.out("=&s", "c4")
+    for e in ("mh", "ml") + tuple(f"s[{j}]" for j in range(9)):
+        a.inp("v", e)
+    a.ins_("v_add_co_u32 {}, vcc, {}, {}", "w1", "mh", "s[8]")          # limb 1 addend, carry k
+    a.ins_("v_addc_co_u32 {}, vcc, 0, 0, vcc", "w2")                    # k: limb 2 addend
+    a.ins_("v_add_co_u32 {}, vcc, {}, {}", "r.v[0]", "s[0]", "ml")
+    a.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", "r.v[1]", "s[1]", "w1")
+    a.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", "r.v[2]", "s[2]", "w2")
+    for j in range(3, 7):
+        a.ins_("v_addc_co_u32 {}, vcc, 0, {}, vcc", f"r.v[{j}]", f"s[{j}]")
+    a.ins_("v_addc_co_u32 {}, {}, 0, {}, vcc", "r.v[7]", "c4", "s[7]")
+    L.append(a.render())
     L.append("    if (__builtin_expect(c4 != 0, 0)) fe_wrap_add(r, c4); // value was 2^256 + small: add C (cannot carry again)\n    }\n}\n\n")
     return "".join(L)
 
