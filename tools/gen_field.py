@@ -354,6 +354,56 @@ def gen_reduce_fast():
     return "".join(L)
 
 
+def gen_sqr_tail():
+    """t = 2 * od + sum a_i^2 2^(64 i): the eight diagonal products take the literal 0 as addend (no register to clear),
+    the doubling and the addition run as two carry chains of eight limbs in one asm statement each."""
+    L = ["// t = 2 * od + diag(a): od = the off-diagonal sum (< 2^511), see fe_sqr\n"]
+    L.append("VK_DEV void fe_sqr_tail(u32 t[16], const u32 od[16], const fe &a)\n{\n    u64 d[8];\n")
+    for half in range(2):
+        x = Asm()
+        for i in range(4 * half, 4 * half + 4):
+            x.out("=&v", f"d[{i}]")
+        for i in range(4 * half, 4 * half + 4):
+            x.inp("v", f"a.v[{i}]")
+        for i in range(4 * half, 4 * half + 4):
+            x.ins_("v_mad_u64_u32 {}, vcc, {}, {}, 0", f"d[{i}]", f"a.v[{i}]", f"a.v[{i}]")
+        L.append(x.render())
+    L.append("    u32 dl[8], dh[8];\n#pragma unroll\n    for (int i = 0; i < 8; i++) {\n        dl[i] = (u32)d[i];\n        dh[i] = (u32)(d[i] >> 32);\n    }\n    vk_carry c;\n")
+    for half in range(2):
+        x = Asm()
+        lo, hi = 8 * half, 8 * half + 8
+        for j in range(lo, hi):
+            x.out("=&v", f"t[{j}]")
+        if half == 0:
+            x.out("=&s", "c")
+        for j in range(max(lo - 1, 0), hi):
+            x.inp("v", f"od[{j}]")
+        for i in range(4 * half, 4 * half + 4):
+            x.inp("v", f"dl[{i}]")
+            x.inp("v", f"dh[{i}]")
+        if half == 1:
+            x.inp("s", "c")
+        # doubled limbs first (into t), then the chain adds the diagonal
+        for j in range(lo, hi):
+            if j == 0:
+                x.ins_("v_lshlrev_b32 {}, 1, {}", "t[0]", "od[0]")
+            else:
+                x.ins_("v_alignbit_b32 {}, {}, {}, 31", f"t[{j}]", f"od[{j}]", f"od[{j - 1}]")
+        for j in range(lo, hi):
+            dsrc = f"dl[{j // 2}]" if j % 2 == 0 else f"dh[{j // 2}]"
+            if j == 0:
+                x.ins_("v_add_co_u32 {}, vcc, {}, {}", "t[0]", "t[0]", dsrc)
+            elif j == 8:
+                x.ins_("v_addc_co_u32 {}, vcc, {}, {}, {}", f"t[{j}]", f"t[{j}]", dsrc, "c")
+            elif j == 7:
+                x.ins_("v_addc_co_u32 {}, {}, {}, {}, vcc", f"t[{j}]", "c", f"t[{j}]", dsrc)
+            else:
+                x.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", f"t[{j}]", f"t[{j}]", dsrc)
+        L.append(x.render())
+    L.append("}\n\n")
+    return "".join(L)
+
+
 def gen_sub3():
     """r = a - b - 2c: three borrow chains, the borrows counted, one fix-up of count * (2^32 + 977)."""
     L = ["// r = a - b - 2c (mod p), weakly reduced: the x-coordinate of every point addition.  r may alias a, b or c.\n"]
@@ -390,7 +440,7 @@ def gen_sub3():
 def main():
     hdr = "// GENERATED by tools/gen_field.py -- do not edit.  Column kernels of the 256-bit multiply / square\n"
     hdr += "// on v_mad_u64_u32 (see the scheme in vk_field.cuh).\n#pragma once\n\n"
-    txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_addsub() + gen_sub3() + gen_reduce() + gen_reduce_fast()
+    txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_sqr_tail() + gen_addsub() + gen_sub3() + gen_reduce() + gen_reduce_fast()
     open(OUT, "w").write(txt)
     print("wrote", OUT, len(txt.splitlines()), "lines")
 

@@ -185,20 +185,8 @@ VK_DEV void fe_sqr(fe &r, const fe &a)
     u32 top = fe_sqr_cols(acc, a);
     u32 od[16];
     merge_eo(od, acc, top); // off-diagonal sum < 2^511
-    // t = 2 * od + sum a_i^2 2^(64 i)
     u32 t[16];
-    vk_carry c;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 d = 0;
-        mad_nc(d, a.v[i], a.v[i]);
-        u32 lo2 = (i == 0) ? (od[0] << 1) : __builtin_amdgcn_alignbit(od[2 * i], od[2 * i - 1], 31);
-        u32 hi2 = __builtin_amdgcn_alignbit(od[2 * i + 1], od[2 * i], 31);
-        if (i == 0) t[0] = add_co(c, lo2, (u32)d);
-        else t[2 * i] = addc_co(c, lo2, (u32)d, c);
-        if (i == 7) t[15] = addc(hi2, (u32)(d >> 32), c);
-        else t[2 * i + 1] = addc_co(c, hi2, (u32)(d >> 32), c);
-    }
+    fe_sqr_tail(t, od, a); // t = 2 * od + sum a_i^2 2^(64 i)
     fe_reduce16(r, t);
 }
 
