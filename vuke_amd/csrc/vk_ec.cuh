@@ -223,6 +223,9 @@ VK_DEV void lds_gather_issue(uint4 *slot, const uint4 *__restrict__ table, u32 e
 }
 VK_DEV void lds_gather_read(fe &x, fe &y, const uint4 *slot)
 {
+    // the loads that fill the slot count in vmcnt like any other; the compiler tracks LDS-direct loads and places this
+    // wait itself in the shipped kernels, but a read of stale LDS is silent, so it is spelled out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const u32 lane = threadIdx.x & 63u;
     const uint4 *m = slot + (lane & 3u) * VK_LTILE_ROUND + (lane & ~3u);
     const uint4 a = m[0], b = m[1], c = m[2], d = m[3];
@@ -241,6 +244,7 @@ VK_DEV void lds_gather_issue_x(uint4 *slot, const uint4 *__restrict__ table, u32
 }
 VK_DEV void lds_gather_read_x(fe &x, const uint4 *slot)
 {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const u32 lane = threadIdx.x & 63u;
     const uint4 *m = slot + (lane & 1u) * VK_LTILE_ROUND + (lane & ~1u);
     const uint4 a = m[0], b = m[1];
