@@ -219,8 +219,11 @@ int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy /* n_files*32 */, size
 /* Transform::apply_batch for string inputs (Input::from_string; wordlist / stdin sources).  String i is
  * data[offsets[i] .. offsets[i+1]).  slots = vk_slots_per_string(t): the hash transforms (sha256, double_sha256, md5,
  * direct) and armory emit one key per string of any length, sha256_chain variants x depth, VK_T_ELECTRUM (strings up to 64
- * bytes) and VK_T_MULTIBIT (up to 256 bytes; longer strings return VK_E_UNSUPPORTED) chain_depth keys; the PRNG
- * transforms need a numeric seed and return VK_E_UNSUPPORTED.  keys_out = n*slots*32, valid = n*slots, slot order = emit order. */
+ * bytes) and VK_T_MULTIBIT (up to 256 bytes) chain_depth keys; the PRNG transforms need a numeric seed and return
+ * VK_E_UNSUPPORTED.  keys_out = n*slots*32, valid = n*slots, slot order = emit order.  A string over the device limit of
+ * the two KDF chains never aborts the batch (the reference skips bad inputs silently, src/transform/electrum.rs:49-52): its
+ * slots stay invalid, the call returns VK_OK, and when the reference would have produced keys for it (a multibit line, an
+ * all-hex electrum line) vk_last_error() holds a one-line "warning: N input string(s) ..." until the next call. */
 int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
                          uint8_t *keys_out, uint8_t *valid);
 
@@ -228,6 +231,14 @@ int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t
  * vk_sweep, with hit.seed = index of the key in `keys` and hit.sub_index = 0. */
 int vk_scan_keys(vk_engine *e, const uint8_t *keys /* n*32 */, size_t n, uint32_t flags, vk_hit *hits, size_t hit_cap,
                  vk_sweep_stats *out);
+
+/* Source::process of the string-input sources in scan mode (src/source/wordlist.rs:24-77, src/source/stdin.rs): the
+ * fused form of vk_transform_strings + vk_scan_keys -- strings in, transform on the device, the keys stay in HBM and go
+ * straight through k*G -> hash160 -> probe.  hit.seed = index of the input string, hit.sub_index = its slot;
+ * stats.inputs = n, stats.keys = keys the transform emitted, kernel_seconds = transform kernel + sweep kernel.
+ * Same length rule and warning as vk_transform_strings. */
+int vk_scan_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n, uint32_t flags,
+                    vk_hit *hits, size_t hit_cap, vk_sweep_stats *out);
 
 /* ---- analyzer brute force (reference src/analyze/{milksad,lcg,mt64,xorshift,sha256_chain}.rs)
  * Smallest seed in [seed_lo, seed_hi] whose generated key(s) satisfy the target.  Kinds: VK_T_MILKSAD, VK_T_MT64,

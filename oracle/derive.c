@@ -205,6 +205,9 @@ static void *sweep_worker(void *arg)
     uint32_t slots = vko_slots_per_input(j->spec);
     vko_stats loc;
     memset(&loc, 0, sizeof loc);
+    uint8_t *bk = NULL;
+    uint64_t *bseed = NULL;
+    uint32_t *bsub = NULL;
     for (;;) {
         pthread_mutex_lock(&j->mu);
         uint64_t c = j->next_chunk++;
@@ -214,6 +217,47 @@ static void *sweep_worker(void *arg)
         if (c > span / 1000) break;
         uint64_t s0 = j->lo + c * 1000, s1 = s0 + 999;
         if (s1 > j->hi || s1 < s0) s1 = j->hi;
+        if ((j->flags & VKO_F_BATCHED) && !(j->flags & VKO_F_FAITHFUL)) {
+            /* same chunk, same order, same counters; only the k*G of the chunk's keys is shared work */
+            size_t cap = (size_t)1000 * slots, n = 0;
+            if (!bk) {
+                bk = (uint8_t *)malloc(cap * (32 + 33 + 65));
+                bseed = (uint64_t *)malloc(cap * sizeof *bseed);
+                bsub = (uint32_t *)malloc(cap * sizeof *bsub);
+            }
+            uint8_t *b33 = bk + cap * 32, *b65 = b33 + cap * 33;
+            for (uint64_t seed = s0;; seed++) {
+                for (uint32_t sub = 0; sub < slots; sub++) {
+                    uint8_t key[32];
+                    if (!vko_transform_key(j->spec, seed, sub, key)) continue;
+                    vko_normalize_key(key, bk + 32 * n);
+                    bseed[n] = seed; bsub[n] = sub; n++;
+                }
+                if (seed == s1) break;
+            }
+            vko_pubkey_batch(bk, n, b33, b65);
+            loc.keys += n;
+            for (size_t i = 0; i < n; i++) {
+                uint8_t hc[20], hu[20];
+                const uint8_t *pc = NULL, *pu = NULL;
+                if (j->flags & VKO_F_COMPRESSED) { vko_hash160(b33 + 33 * i, 33, hc); vko_digest_fold(loc.digest, hc); pc = hc; }
+                if (j->flags & VKO_F_UNCOMPRESSED) { vko_hash160(b65 + 65 * i, 65, hu); vko_digest_fold(loc.digest, hu); pu = hu; }
+                int kind = j->m ? vko_matcher_check_h160(j->m, pc, pu) : -1;
+                if (kind >= 0) {
+                    loc.matches++;
+                    pthread_mutex_lock(&j->mu);
+                    if (j->nhits < j->hit_cap) {
+                        vko_hit *h = &j->hits[j->nhits];
+                        h->seed = bseed[i]; h->sub_index = bsub[i]; h->addr_kind = (uint32_t)kind;
+                        memcpy(h->privkey, bk + 32 * i, 32);
+                        memcpy(h->h160, kind == 1 ? hu : hc, 20);
+                    }
+                    j->nhits++;
+                    pthread_mutex_unlock(&j->mu);
+                }
+            }
+            continue;
+        }
         for (uint64_t seed = s0;; seed++) {
             for (uint32_t sub = 0; sub < slots; sub++) {
                 uint8_t key[32];
@@ -257,6 +301,7 @@ static void *sweep_worker(void *arg)
             if (seed == s1) break;
         }
     }
+    free(bk); free(bseed); free(bsub);
     pthread_mutex_lock(&j->mu);
     j->st.keys += loc.keys; j->st.matches += loc.matches;
     j->st.digest[0] ^= loc.digest[0]; j->st.digest[1] ^= loc.digest[1];
@@ -279,7 +324,7 @@ int vko_sweep(const vko_spec *spec, uint64_t lo, uint64_t hi, uint32_t flags, co
     if (hi < lo || !out) return -1;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
-    { uint8_t k[32] = {0}, p[33]; k[31] = 1; vko_pubkey(k, p, NULL); } /* build the table before threads start */
+    { uint8_t k[32] = {0}, p[33]; k[31] = 1; vko_pubkey(k, p, NULL); if (flags & VKO_F_BATCHED) vko_pubkey_batch(k, 1, p, NULL); } /* build the tables before threads start */
     sweep_job j;
     memset(&j, 0, sizeof j);
     j.spec = spec; j.lo = lo; j.hi = hi; j.flags = flags; j.m = m; j.hits = hits; j.hit_cap = hits ? hit_cap : 0;

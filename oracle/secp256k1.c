@@ -298,6 +298,86 @@ void vko_pubkey(const uint8_t key[32], uint8_t pub33[33], uint8_t pub65[65])
     serialize(&a, pub33, pub65);
 }
 
+/* Third k*G path, for whole chunks of keys (the "lean" CPU baseline and the generator of the
+ * full-size golden digests, tests/golden/make_milksad_2p32.py): 16-bit fixed windows (16 x 65536
+ * affine points, 64 MB) and one field inversion per chunk (Montgomery's simultaneous inversion).
+ * Same generic adder as the other two paths, so every special case is still handled; checked
+ * against vko_pubkey_slow / vko_pubkey in tests/test_oracle_derive.py. */
+static aff *g_table16; /* [16][65536]: (d * 65536^w) * G, entry d = 0 unused */
+static pthread_once_t g_once16 = PTHREAD_ONCE_INIT;
+
+/* z[i] <- 1/z[i] for i < n (none zero); scratch holds n field elements */
+static void fe_batch_inv(fe *z, size_t n, fe *scratch)
+{
+    if (!n) return;
+    scratch[0] = z[0];
+    for (size_t i = 1; i < n; i++) fe_mul(&scratch[i], &scratch[i - 1], &z[i]);
+    fe inv;
+    fe_inv(&inv, &scratch[n - 1]);
+    for (size_t i = n - 1; i > 0; i--) {
+        fe t;
+        fe_mul(&t, &inv, &scratch[i - 1]);
+        fe_mul(&inv, &inv, &z[i]);
+        z[i] = t;
+    }
+    z[0] = inv;
+}
+
+static void build_table16(void)
+{
+    const size_t N = 65536;
+    g_table16 = (aff *)calloc(16 * N, sizeof(aff));
+    jac *row = (jac *)malloc(N * sizeof(jac));
+    fe *zs = (fe *)malloc(N * sizeof(fe)), *scr = (fe *)malloc(N * sizeof(fe));
+    aff base = {GX, GY};
+    for (int w = 0; w < 16; w++) {
+        jac acc; acc.inf = 1;
+        for (size_t d = 1; d < N; d++) {
+            jac_add_aff(&acc, &acc, &base);
+            row[d] = acc;
+            zs[d] = acc.z;
+        }
+        fe_batch_inv(zs + 1, N - 1, scr);
+        for (size_t d = 1; d < N; d++) {
+            fe zi2, zi3;
+            fe_sqr(&zi2, &zs[d]); fe_mul(&zi3, &zi2, &zs[d]);
+            fe_mul(&g_table16[(size_t)w * N + d].x, &row[d].x, &zi2);
+            fe_mul(&g_table16[(size_t)w * N + d].y, &row[d].y, &zi3);
+        }
+        jac_add_aff(&acc, &acc, &base); /* 65536 * base */
+        jac_to_aff(&base, &acc);
+    }
+    free(row); free(zs); free(scr);
+}
+
+/* keys: n x 32 B normalised scalars; pub33s / pub65s: n x 33 / n x 65 B (either may be NULL) */
+void vko_pubkey_batch(const uint8_t *keys, size_t n, uint8_t *pub33s, uint8_t *pub65s)
+{
+    pthread_once(&g_once16, build_table16);
+    if (!n) return;
+    jac *acc = (jac *)malloc(n * sizeof(jac));
+    fe *zs = (fe *)malloc(n * sizeof(fe)), *scr = (fe *)malloc(n * sizeof(fe));
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *k = keys + 32 * i;
+        acc[i].inf = 1;
+        for (int w = 0; w < 16; w++) {
+            unsigned d = (unsigned)k[31 - 2 * w] | (unsigned)k[30 - 2 * w] << 8;
+            if (d) jac_add_aff(&acc[i], &acc[i], &g_table16[(size_t)w * 65536 + d]);
+        }
+        zs[i] = acc[i].z; /* k in [1, n) => never the point at infinity */
+    }
+    fe_batch_inv(zs, n, scr);
+    for (size_t i = 0; i < n; i++) {
+        fe zi2, zi3;
+        aff a;
+        fe_sqr(&zi2, &zs[i]); fe_mul(&zi3, &zi2, &zs[i]);
+        fe_mul(&a.x, &acc[i].x, &zi2);
+        fe_mul(&a.y, &acc[i].y, &zi3);
+        serialize(&a, pub33s ? pub33s + 33 * i : NULL, pub65s ? pub65s + 65 * i : NULL);
+    }
+    free(acc); free(zs); free(scr);
+}
+
 void vko_derive_h160(const uint8_t key[32], uint8_t h160_c[20], uint8_t h160_u[20])
 {
     uint8_t k[32], p33[33], p65[65];

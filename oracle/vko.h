@@ -129,6 +129,8 @@ void vko_normalize_key(const uint8_t in[32], uint8_t out[32]);
 void vko_pubkey_slow(const uint8_t key[32], uint8_t pub33[33], uint8_t pub65[65]);
 /* k*G by an 8-bit fixed-window table (checked against vko_pubkey_slow in tests). */
 void vko_pubkey(const uint8_t key[32], uint8_t pub33[33], uint8_t pub65[65]);
+/* k*G for n normalised keys at once: 16-bit windows + one shared field inversion (checked against the two above). */
+void vko_pubkey_batch(const uint8_t *keys, size_t n, uint8_t *pub33s, uint8_t *pub65s);
 /* master + tweak mod n (BIP32 / Electrum child keys); returns 0 if result is 0. */
 int vko_scalar_add(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
 int vko_scalar_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]); /* a * b mod n; 0 if the product is zero */
@@ -200,6 +202,7 @@ typedef struct {
 #define VKO_F_COMPRESSED 1u
 #define VKO_F_UNCOMPRESSED 2u
 #define VKO_F_FAITHFUL 0x100u /* do everything KeyDeriver::derive does per key (CPU baseline) */
+#define VKO_F_BATCHED 0x200u  /* k*G of a whole 1000-input chunk through vko_pubkey_batch (same results, ~4x faster) */
 
 /* RangeSource::process over inclusive [lo, hi] (src/source/range.rs:26-79), nthreads
  * worker threads pulling chunks of 1000 inputs.  hits are sorted by (seed, sub_index). */

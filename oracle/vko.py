@@ -12,7 +12,7 @@ _LIB = os.path.join(_HERE, "build", "libvko.so")
 
 T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM, T_MULTIBIT, T_DOUBLE_SHA256, T_MD5, T_DIRECT, T_ARMORY = range(12)
 VARIANT_ALL = 0xFFFFFFFF
-F_COMPRESSED, F_UNCOMPRESSED, F_FAITHFUL = 1, 2, 0x100
+F_COMPRESSED, F_UNCOMPRESSED, F_FAITHFUL, F_BATCHED = 1, 2, 0x100, 0x200
 
 
 def build(force=False):

@@ -46,7 +46,11 @@ def test_field_ops(eng):
     b += [y for _ in edge for y in edge]
     ab, bb = [be(x) for x in a], [be(x) for x in b]
     for op, f in ((0, lambda x, y: x * y % P), (3, lambda x, y: (x + y) % P), (4, lambda x, y: (x - y) % P),
-                  (5, lambda x, y: (x - 3 * y) % P), (6, lambda x, y: (-x - y) % P), (7, lambda x, y: (-x - 3 * y) % P)):  # fe_sub3 = a - b - 2c
+                  (5, lambda x, y: (x - 3 * y) % P), (6, lambda x, y: (-x - y) % P), (7, lambda x, y: (-x - 3 * y) % P),  # fe_sub3 = a - b - 2c
+                  # one case per aliasing form of the generated statements (result = first / second / both operands)
+                  (8, lambda x, y: x * y % P), (9, lambda x, y: x * y % P), (10, lambda x, y: x * x % P), (11, lambda x, y: x * x % P),
+                  (12, lambda x, y: 2 * x % P), (13, lambda x, y: (y - x) % P), (14, lambda x, y: -2 * x % P),
+                  (15, lambda x, y: pow(x, 32, P) * y % P)):
         got = eng.field_op(op, ab, bb)
         for x, y, g in zip(a, b, got):
             assert int.from_bytes(g, "big") == f(x, y), (op, hex(x), hex(y))

@@ -7,6 +7,14 @@ Scheme (see vk_field.cuh): product scanning; column k = i + j accumulates into t
 the next column of the same parity starts.  Each asm statement handles one even column and the
 following odd column, interleaved, so dependent multiplies are always 3 issue slots apart; the
 even column carries through vcc, the odd one through a scratch SGPR pair.
+
+Operand discipline of every statement emitted here (audited in round 2, profiles/r02_short_fold_root_cause.txt): a
+statement of more than one instruction either early-clobbers its outputs ("=&v" / "=&s") or, where an operand is
+read-write ("+v"), every plain input is read only by the instruction that overwrites the register it could share (the
+reduction's t[8+i] is the high half of its own accumulator pair); carries never leave a statement in vcc, only in a
+declared SGPR pair; nothing inside a statement needs a software wait state (VALU carry-out -> VALU carry-in and VALU ->
+SALU reads of an SGPR are interlocked on gfx9-family parts; no DPP, readlane or VMEM use of a freshly written register).
+The C++ callers may alias result and operands freely: results are written only by the last statement, from temporaries.
 """
 import os
 

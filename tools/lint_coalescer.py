@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Build-time lint for an LLVM register-coalescer miscompile that hit the generated field code (round 1, "short fold").
+
+Root cause found in round 2 (profiles/r02_short_fold_root_cause.txt): when outputs of two inline-asm statements are copied
+into the halves of one wide register tuple (e.g. r.v[0..2] from the fold statement, r.v[3] from the carry chain before
+it), the coalescer may join the 32-bit values into sub-registers of different tuples and then mark the asm output that fed
+the dropped lane `dead` -- the lane of the surviving tuple keeps a stale value.  No hazard, no missing clobber: the MIR is
+right before `register-coalescer` and wrong after it.
+
+The signature is mechanical: an INLINEASM def that is live before the pass and `dead` after it.  This script compiles a
+translation unit with -print-before/-print-after=register-coalescer and reports every such def.
+
+    python tools/lint_coalescer.py [--group N ...]        # default: all sweep groups + the engine TU
+Exit status 1 if anything is flagged.
+"""
+import argparse
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "vuke_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-unused-variable",
+         "-mllvm", "-pragma-unroll-threshold=200000", "--cuda-device-only", "-S"]
+DEF = re.compile(r"def (dead )?(undef )?(early-clobber )?(%\d+|\$\w+)")
+HDR = re.compile(r"^# \*\*\* IR Dump (Before|After) Register Coalescer")
+FN = re.compile(r"^# Machine code for function (\S+):")
+SLOT = re.compile(r"^(\d+B)\s+INLINEASM ")
+
+
+def parse(path):
+    """{(function, when): {slot: [dead?, ...]}}"""
+    out = {}
+    when = fn = None
+    with open(path, errors="replace") as f:
+        for line in f:
+            m = HDR.match(line)
+            if m:
+                when = m.group(1)
+                continue
+            m = FN.match(line)
+            if m:
+                fn = m.group(1)
+                continue
+            m = SLOT.match(line)
+            if m and when and fn:
+                ops = line.split("[attdialect]", 1)[-1]
+                out.setdefault((fn, when), {})[m.group(1)] = [bool(d[0]) for d in DEF.findall(ops)]
+    return out
+
+
+def lint(src, extra, tag):
+    with tempfile.TemporaryDirectory() as td:
+        mir = os.path.join(td, "mir.txt")
+        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + FLAGS + extra + ["-o", os.path.join(td, "dev.s"), src,
+               "-mllvm", "-print-before=register-coalescer", "-mllvm", "-print-after=register-coalescer"]
+        with open(mir, "w") as f:
+            subprocess.run(cmd, check=True, stderr=f, stdout=subprocess.DEVNULL)
+        d = parse(mir)
+    bad = 0
+    nasm = 0
+    for (fn, when), slots in sorted(d.items()):
+        if when != "Before":
+            continue
+        after = d.get((fn, "After"), {})
+        for slot, flags in slots.items():
+            nasm += 1
+            fa = after.get(slot)
+            if fa is None or len(fa) != len(flags):
+                continue
+            for i, (b, a) in enumerate(zip(flags, fa)):
+                if a and not b:
+                    bad += 1
+                    print(f"{tag}: {fn} INLINEASM@{slot}: output ${i} live before register-coalescer, dead after")
+    print(f"{tag}: {nasm} asm statements checked, {bad} dropped outputs")
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--group", type=int, action="append")
+    ap.add_argument("--no-engine", action="store_true")
+    ap.add_argument("--csrc", default=CSRC)
+    args = ap.parse_args()
+    bad = 0
+    for g in (args.group if args.group is not None else [0, 1, 2, 3, 4]):
+        bad += lint(os.path.join(args.csrc, "vk_sweep_tu.hip"), [f"-DVK_SWEEP_GROUP={g}"], f"sweep_g{g}")
+    if not args.no_engine and args.group is None:
+        bad += lint(os.path.join(args.csrc, "vk_engine.hip"), [], "engine")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -61,7 +61,7 @@ SEARCH_EXACT, SEARCH_MASKED, SEARCH_CASCADE = 0, 1, 2
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
     "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
-    "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
+    "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_scan_strings", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
     "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field",
 ]
 
@@ -97,6 +97,7 @@ def load():
     L.vk_bitimage_keys.argtypes = [vp, cp, sz, cp, C.POINTER(u32), sz, C.POINTER(u32), u32, u32, cp, cp]
     L.vk_search.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, C.POINTER(SearchTarget), C.POINTER(SearchResult)]
     L.vk_scan_keys.argtypes = [vp, cp, sz, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
+    L.vk_scan_strings.argtypes = [vp, C.POINTER(TransformSpec), cp, C.POINTER(u32), sz, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_slots_per_input.argtypes = [C.POINTER(TransformSpec)]
     L.vk_slots_per_input.restype = u32
     L.vk_slots_per_string.argtypes = [C.POINTER(TransformSpec)]
@@ -263,6 +264,25 @@ class Engine:
                     key=lambda h: h["index"])
         return dict(inputs=st.inputs, keys=st.keys, matches=st.matches, digest=tuple(st.digest)), hl
 
+    def scan_strings(self, spec, strings, flags=F_COMPRESSED | F_UNCOMPRESSED, hit_cap=4096, packed=None):
+        """Wordlist / stdin source in scan mode: strings -> transform -> derive -> probe without leaving the device.
+        packed = (blob, offsets ctypes array, n) skips the per-call packing (bench)."""
+        if packed is None:
+            packed = pack_strings(strings)
+        blob, offs, n = packed
+        hits = (Hit * max(hit_cap, 1))()
+        st = SweepStats()
+        self._chk(self._L.vk_scan_strings(self._e, C.byref(spec), blob, offs, n, flags, hits, hit_cap, C.byref(st)))
+        m = min(st.matches, hit_cap)
+        hl = sorted((dict(index=h.seed, sub_index=h.sub_index, addr_kind=h.addr_kind, privkey=bytes(h.privkey), h160=bytes(h.h160))
+                     for h in hits[:m]), key=lambda h: (h["index"], h["sub_index"]))
+        warn = (self._L.vk_last_error(self._e) or b"").decode()
+        return dict(inputs=st.inputs, keys=st.keys, matches=st.matches, hits_dropped=st.hits_dropped, digest=tuple(st.digest),
+                    kernel_seconds=st.kernel_seconds, launches=st.launches, warning=warn), hl
+
+    def last_warning(self):
+        return (self._L.vk_last_error(self._e) or b"").decode()
+
     def search(self, spec, lo, hi, key=None, mask_bits=None, cascade=None):
         """Analyzer brute force: smallest matching seed in [lo, hi] (exact key, masked key, or cascade [(bits, target)])."""
         tg = SearchTarget()
@@ -290,6 +310,15 @@ class Engine:
         self._chk(self._L.vk_debug_field(self._e, op, b"".join(a_list), b"".join(b_list) if b_list else None, n, out))
         ro = out.raw
         return [ro[32 * i:32 * i + 32] for i in range(n)]
+
+
+def pack_strings(strings):
+    """(blob, offsets, n) as vk_transform_strings / vk_scan_strings take them."""
+    n = len(strings)
+    offs = (C.c_uint32 * (n + 1))()
+    for i, s in enumerate(strings):
+        offs[i + 1] = offs[i] + len(s)
+    return b"".join(strings), offs, n
 
 
 def spec(kind, variant=VARIANT_ALL, endian=0, chain_depth=10):

@@ -189,6 +189,15 @@ __global__ void vk_field_kernel(int op, const u32 *a, const u32 *b, u64 n, u32 *
     case 5: fe_sub3(r, x, y, y); break;                      // x - 3y
     case 6: r = x; fe_sub3(r, r, y, r); break;               // -x - y, result and third operand aliasing the first
     case 7: fe_add(r, x, y); fe_sub3(r, x, y, r); break;     // -x - 3y, result aliasing the third
+    // aliasing forms of the generated statements (the shapes the sweep uses: inv = inv * e, c = c * e, zinv = zinv^2, ...)
+    case 8: r = x; fe_mul(r, r, y); break;                   // r = r * y
+    case 9: r = y; fe_mul(r, x, r); break;                   // r = x * r
+    case 10: r = x; fe_mul(r, r, r); break;                  // r = r * r through the general multiplier
+    case 11: r = x; fe_sqr(r, r); break;                     // r = r^2
+    case 12: r = x; fe_add(r, r, r); break;                  // r = 2x
+    case 13: r = x; fe_sub(r, y, r); break;                  // r = y - x
+    case 14: r = x; fe_sub3(r, r, r, r); break;              // r = x - x - 2x = -2x
+    case 15: r = x; fe_sqr_n(r, r, 5); fe_mul(r, r, y); break; // x^32 * y: a loop-carried element feeding a multiply
     default: fe_sub(r, x, y); break;
     }
     fe_canon(r);

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <cctype>
 #include <string>
 #include <vector>
 
@@ -385,6 +386,7 @@ struct launch_io {
     vk_hit *hits = nullptr;
     size_t hit_cap = 0;
     const u32 *in_keys = nullptr; // device
+    const unsigned char *in_valid = nullptr; // device, optional
     u32 *out_priv = nullptr;      // device
     u32 *out_h160c = nullptr;
     u32 *out_h160u = nullptr;
@@ -451,6 +453,7 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     p.stats = e->d_stats;
     p.work = e->work;
     p.in_keys = io.in_keys;
+    p.in_valid = io.in_valid;
     p.out_priv = io.out_priv;
     p.out_h160c = io.out_h160c;
     p.out_h160u = io.out_h160u;
@@ -748,22 +751,27 @@ extern "C" int vk_multibit_passphrase_set(vk_engine *e, const uint8_t *passphras
     return VK_OK;
 }
 
-extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
-                                    uint8_t *keys_out, uint8_t *valid)
+// Device half of Transform::apply_batch for string inputs: uploads the strings, runs the transform kernel on the engine's
+// stream and leaves keys (items x 32 B) and validity flags (items) in scratch slots 1 and 4.  Strings longer than the
+// device limit of the two KDF chains get no keys; *overlong counts the ones the reference would not have dropped too.
+static int strings_to_device_keys(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n, u32 slots,
+                                  u32 **d_keys_out, unsigned char **d_valid_out, size_t *overlong, double *kernel_seconds)
 {
-    if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
-    int rc = validate_spec(e, t, true);
-    if (rc) return rc;
-    if (n == 0) return VK_OK;
-    if (!data || !offsets || !keys_out || !valid) return fail(e, VK_E_INVALID_ARG, "data / offsets / keys_out / valid is NULL");
-    const u32 slots = vk_slots_per_string(t);
-    if ((u64)n * slots > (1ull << 28)) return fail(e, VK_E_INVALID_ARG, "too many keys for one vk_transform_strings call (max 2^28)");
     const bool kdf = t->kind == VK_T_ELECTRUM || t->kind == VK_T_MULTIBIT;
     const u32 max_len = t->kind == VK_T_MULTIBIT ? VK_MULTIBIT_MAX_MNEMONIC : kdf ? VK_ELECTRUM_MAX_SEED : 0x7FFFFFFFu;
+    *overlong = 0;
     for (size_t i = 0; i < n; i++) {
         if (offsets[i + 1] < offsets[i]) return fail(e, VK_E_INVALID_ARG, "offsets must be non-decreasing");
-        if (offsets[i + 1] - offsets[i] > max_len) return fail(e, VK_E_UNSUPPORTED, "string too long for this transform on the device (electrum 64, multibit 256 bytes)");
+        const u32 len = offsets[i + 1] - offsets[i];
+        if (len > max_len) {
+            // ElectrumTransform::apply_batch drops every non-hex string itself (src/transform/electrum.rs:49-52): only an
+            // over-long string of hex digits is a key the reference would have produced and this path does not
+            bool counts = true;
+            if (t->kind == VK_T_ELECTRUM) {
+                for (u32 j = 0; j < len && counts; j++) counts = isxdigit(data[offsets[i] + j]) != 0;
+            }
+            if (counts) (*overlong)++;
+        }
     }
     HIPCHK(e, hipSetDevice(e->device));
     const size_t bytes = offsets[n], items = n * slots;
@@ -776,6 +784,7 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
     if (c == hipSuccess) c = hipMemcpy(d_offs, offsets, (n + 1) * 4, hipMemcpyHostToDevice);
     if (c == hipSuccess) c = hipMemsetAsync(d_keys, 0, items * 32, e->stream);
     if (c == hipSuccess) c = hipMemsetAsync(d_valid, 0, items, e->stream);
+    if (c == hipSuccess) c = hipEventRecord(e->ev0, e->stream);
     if (c == hipSuccess) {
         if (!kdf)
             hipLaunchKernelGGL(vk_strings_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, to_dev(t), d_data, d_offs,
@@ -788,13 +797,98 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
                                t->variant, t->chain_depth, 100000u, e->table, e->d_wins, e->nwin, d_keys, d_valid);
         c = hipGetLastError();
     }
+    if (c == hipSuccess) c = hipEventRecord(e->ev1, e->stream);
     if (c == hipSuccess) c = hipStreamSynchronize(e->stream);
-    if (c == hipSuccess) c = hipMemcpy(keys_out, d_keys, items * 32, hipMemcpyDeviceToHost);
+    float ms = 0.f;
+    if (c == hipSuccess) c = hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    if (c != hipSuccess) {
+        e->err = std::string("string transform on the device: ") + hipGetErrorString(c);
+        return VK_E_HIP;
+    }
+    if (kernel_seconds) *kernel_seconds = (double)ms * 1e-3;
+    *d_keys_out = d_keys;
+    *d_valid_out = d_valid;
+    return VK_OK;
+}
+
+static void note_overlong(vk_engine *e, const vk_transform_spec *t, size_t overlong)
+{
+    e->err.clear();
+    if (overlong)
+        e->err = "warning: " + std::to_string(overlong) + " input string(s) longer than the device limit (" +
+                 (t->kind == VK_T_MULTIBIT ? "multibit 256" : "electrum 64") + " bytes) produced no keys";
+}
+
+extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
+                                    uint8_t *keys_out, uint8_t *valid)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int rc = validate_spec(e, t, true);
+    if (rc) return rc;
+    if (n == 0) return VK_OK;
+    if (!data || !offsets || !keys_out || !valid) return fail(e, VK_E_INVALID_ARG, "data / offsets / keys_out / valid is NULL");
+    const u32 slots = vk_slots_per_string(t);
+    if ((u64)n * slots > (1ull << 28)) return fail(e, VK_E_INVALID_ARG, "too many keys for one vk_transform_strings call (max 2^28)");
+    u32 *d_keys = nullptr;
+    unsigned char *d_valid = nullptr;
+    size_t overlong = 0;
+    rc = strings_to_device_keys(e, t, data, offsets, n, slots, &d_keys, &d_valid, &overlong, nullptr);
+    if (rc) return rc;
+    const size_t items = n * slots;
+    hipError_t c = hipMemcpy(keys_out, d_keys, items * 32, hipMemcpyDeviceToHost);
     if (c == hipSuccess) c = hipMemcpy(valid, d_valid, items, hipMemcpyDeviceToHost);
     if (c != hipSuccess) {
         e->err = std::string("vk_transform_strings: ") + hipGetErrorString(c);
         return VK_E_HIP;
     }
+    note_overlong(e, t, overlong);
+    return VK_OK;
+}
+
+// Source::process for the string-input sources in scan mode (reference src/source/wordlist.rs, src/source/stdin.rs:
+// apply_batch -> derive -> Matcher::check per key): the transform's keys never leave HBM -- the sweep kernel reads them
+// back as VK_T_RAWKEYS with the validity flags as its mask.  hit.seed = index of the input string, hit.sub_index = slot.
+extern "C" int vk_scan_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n, uint32_t flags,
+                               vk_hit *hits, size_t hit_cap, vk_sweep_stats *out)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int rc = validate_spec(e, t, true);
+    if (rc) return rc;
+    if (!out) return fail(e, VK_E_INVALID_ARG, "stats out pointer is NULL");
+    if (!(flags & (VK_F_COMPRESSED | VK_F_UNCOMPRESSED)) || (flags & ~(VK_F_COMPRESSED | VK_F_UNCOMPRESSED)))
+        return fail(e, VK_E_INVALID_ARG, "flags must be a non-empty subset of VK_F_COMPRESSED | VK_F_UNCOMPRESSED");
+    memset(out, 0, sizeof *out);
+    if (n == 0) return VK_OK;
+    if (!data || !offsets) return fail(e, VK_E_INVALID_ARG, "data / offsets is NULL");
+    const u32 slots = vk_slots_per_string(t);
+    if ((u64)n * slots > (1ull << 28)) return fail(e, VK_E_INVALID_ARG, "too many keys for one vk_scan_strings call (max 2^28)");
+    u32 *d_keys = nullptr;
+    unsigned char *d_valid = nullptr;
+    size_t overlong = 0;
+    double tsec = 0.0;
+    rc = strings_to_device_keys(e, t, data, offsets, n, slots, &d_keys, &d_valid, &overlong, &tsec);
+    if (rc) return rc;
+    launch_io io;
+    io.in_keys = d_keys;
+    io.in_valid = d_valid;
+    io.hits = hits;
+    io.hit_cap = hits ? hit_cap : 0;
+    vk_spec_dev spec = {VK_T_RAWKEYS, 0, 0, 0};
+    rc = run_range(e, spec, VK_T_RAWKEYS, 1, 0, (u64)n * slots - 1, flags, io, out);
+    if (rc) return rc;
+    out->inputs = n;
+    out->kernel_seconds += tsec;
+    out->launches += 1;
+    out->hits_dropped = out->matches > (hits ? hit_cap : 0) ? out->matches - (hits ? hit_cap : 0) : 0;
+    const size_t got = (size_t)std::min<u64>(out->matches, hits ? hit_cap : 0);
+    for (size_t i = 0; i < got; i++) { // key index -> (input, slot)
+        const u64 idx = hits[i].seed;
+        hits[i].seed = idx / slots;
+        hits[i].sub_index = (u32)(idx % slots);
+    }
+    note_overlong(e, t, overlong);
     return VK_OK;
 }
 

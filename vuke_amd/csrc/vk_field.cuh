@@ -227,9 +227,14 @@ VK_DEV bool fe_is_zero_canon(const fe &a)
     return o == 0;
 }
 
-// r = a^(p-2).  Chain over the run structure of p-2 = 1^223 0 1^22 0000 1 0 1 1 0 1.
-__device__ __noinline__ void fe_inv(fe &r, const fe &a)
+// a^(p-2).  Chain over the run structure of p-2 = 1^223 0 1^22 0000 1 0 1 1 0 1.
+// A real call (one copy per translation unit), operand and result BY VALUE: both travel in VGPRs.  With reference
+// parameters the caller's field elements had their address taken, stayed in scratch (80 bytes per lane in the sweep) and were
+// accessed as 64/128-bit register tuples inside the hot loop -- the shape in which LLVM's register coalescer dropped a lane
+// of the running inverse in the "short fold" experiment (profiles/r02_short_fold_root_cause.txt).
+__device__ __noinline__ fe fe_inv_val(fe a)
 {
+    fe r;
     fe x2, x3, x6, x9, x11, x22, x44, x88, x176, x220, x223, t;
     fe_sqr(x2, a);
     fe_mul(x2, x2, a);
@@ -261,6 +266,12 @@ __device__ __noinline__ void fe_inv(fe &r, const fe &a)
     fe_mul(t, t, x2);
     fe_sqr_n(t, t, 2);
     fe_mul(r, t, a);
+    return r;
+}
+VK_DEV void fe_inv(fe &r, const fe &a)
+{
+    const fe t = a;
+    r = fe_inv_val(t);
 }
 
 // ---------------------------------------------------------------- scalars mod n

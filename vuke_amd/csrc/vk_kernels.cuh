@@ -66,6 +66,7 @@ struct vk_sweep_params {
     u64 *stats;        // [0] keys [1] matches [2] hit cursor [3..6] digest [7] tile counter
     uint4 *work;       // batch-inversion workspace
     const u32 *in_keys;   // VK_T_RAWKEYS: n x 8 words (raw bytes)
+    const unsigned char *in_valid; // VK_T_RAWKEYS: optional n flags, 0 = no key in this slot (vk_scan_strings)
     u32 *out_priv;     // generate mode: n_items x 8 words (raw bytes)
     u32 *out_h160c;    // n_items x 5 words
     u32 *out_h160u;
@@ -127,6 +128,7 @@ VK_DEV bool item_key(u32 kw[8], const vk_sweep_params &p, u64 off, u32 sub)
 {
     if (off > p.span) return false;
     if (KIND == VK_T_RAWKEYS) {
+        if (p.in_valid && !p.in_valid[off]) return false;
         const uint4 *src = reinterpret_cast<const uint4 *>(p.in_keys) + off * 2;
         uint4 a = src[0], b = src[1];
         kw[0] = bswap32(a.x); kw[1] = bswap32(a.y); kw[2] = bswap32(a.z); kw[3] = bswap32(a.w);

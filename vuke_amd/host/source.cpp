@@ -170,7 +170,9 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
     // then either the hits (scan) or the derived values of every key (generate)
     struct SliceOut {
         std::vector<uint8_t> flat, norm, hc, hu, xy;
-        std::vector<uint32_t> slot_of;
+        std::vector<uint32_t> slot_of; // generate: slot of every emitted key; scan: slot of every hit
+        size_t nkeys = 0;              // keys the transform emitted for this slice
+        std::string warning;           // over-long inputs the device skipped (vk_last_error after VK_OK)
         std::vector<vk_hit> hits;
         std::vector<DerivedKey> hit_derived;
     };
@@ -184,34 +186,44 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
         for (const Transform &t : transforms) {
             const uint32_t k = t.string_slots();
             if (k == 0) continue; // a transform that needs Input::u64_val pushes nothing for a passphrase
-            if (t.takes_strings() && b.max_len() > (t.spec().kind == VK_T_MULTIBIT ? 256u : 64u))
-                throw std::invalid_argument("input string too long for the device path (electrum 64, multibit 256 bytes)");
             auto run_slice = [&](vk_engine *eng, size_t first, size_t cnt, SliceOut &o) {
                 std::vector<uint32_t> offs(cnt + 1);
                 for (size_t i = 0; i <= cnt; i++) offs[i] = b.offs[first + i] - b.offs[first];
+                if (matcher) {
+                    // scan: strings in, hits out -- the keys stay on the device (vk_scan_strings)
+                    o.hits.resize(4096);
+                    vk_sweep_stats ss;
+                    for (;;) {
+                        check_rc(eng, vk_scan_strings(eng, &t.spec(), b.data.data() + b.offs[first], offs.data(), cnt, flags, o.hits.data(), o.hits.size(), &ss));
+                        if (!ss.hits_dropped) break;
+                        o.hits.resize(o.hits.size() + (size_t)ss.hits_dropped + 1024);
+                    }
+                    o.warning = vk_last_error(eng);
+                    o.nkeys = (size_t)ss.keys;
+                    o.hits.resize((size_t)ss.matches);
+                    std::sort(o.hits.begin(), o.hits.end(), [](const vk_hit &x, const vk_hit &y) {
+                        return x.seed != y.seed ? x.seed < y.seed : x.sub_index < y.sub_index;
+                    });
+                    std::vector<Key> hk(o.hits.size());
+                    for (size_t i = 0; i < o.hits.size(); i++) {
+                        memcpy(hk[i].data(), o.hits[i].privkey, 32);
+                        o.slot_of.push_back((uint32_t)((first + (size_t)o.hits[i].seed) * k + o.hits[i].sub_index));
+                    }
+                    if (!hk.empty()) o.hit_derived = KeyDeriver(eng).derive(hk);
+                    return;
+                }
                 std::vector<uint8_t> keys(cnt * k * 32), valid(cnt * k);
                 check_rc(eng, vk_transform_strings(eng, &t.spec(), b.data.data() + b.offs[first], offs.data(), cnt, keys.data(), valid.data()));
+                o.warning = vk_last_error(eng);
                 for (size_t s = 0; s < cnt * k; s++)
                     if (valid[s]) {
                         o.flat.insert(o.flat.end(), keys.begin() + 32 * s, keys.begin() + 32 * s + 32);
                         o.slot_of.push_back((uint32_t)(first * k + s));
                     }
                 const size_t m = o.slot_of.size();
+                o.nkeys = m;
                 if (m == 0) return;
-                if (matcher) {
-                    o.hits.resize(4096);
-                    vk_sweep_stats ss;
-                    for (;;) {
-                        check_rc(eng, vk_scan_keys(eng, o.flat.data(), m, flags, o.hits.data(), o.hits.size(), &ss));
-                        if (!ss.hits_dropped) break;
-                        o.hits.resize(o.hits.size() + (size_t)ss.hits_dropped + 1024);
-                    }
-                    o.hits.resize((size_t)ss.matches);
-                    std::sort(o.hits.begin(), o.hits.end(), [](const vk_hit &x, const vk_hit &y) { return x.seed < y.seed; });
-                    std::vector<Key> hk(o.hits.size());
-                    for (size_t i = 0; i < o.hits.size(); i++) memcpy(hk[i].data(), &o.flat[32 * (size_t)o.hits[i].seed], 32);
-                    o.hit_derived = KeyDeriver(eng).derive(hk);
-                } else {
+                {
                     o.norm.resize(m * 32);
                     o.hc.resize(m * 20);
                     o.hu.resize(m * 20);
@@ -243,7 +255,8 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
             // emission, in input order
             for (SliceOut &o : outs) {
                 const size_t m = o.slot_of.size();
-                st.keys_generated += m;
+                st.keys_generated += o.nkeys;
+                if (o.warning.rfind("warning:", 0) == 0) fprintf(stderr, "%s (%s)\n", o.warning.c_str(), t.name());
                 if (m == 0) continue;
                 auto label_of = [&](size_t j) { return t.label(b.str(o.slot_of[j] / k), o.slot_of[j] % k); };
                 if (matcher) {
@@ -254,7 +267,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                                           : o.hits[i].addr_kind == VK_ADDR_P2PKH_U ? AddressType::P2pkhUncompressed
                                                                                    : AddressType::P2wpkh;
                         mi.address = *o.hit_derived[i].addresses()[o.hits[i].addr_kind];
-                        output.hit(label_of((size_t)o.hits[i].seed), t.name(), o.hit_derived[i], mi);
+                        output.hit(label_of(i), t.name(), o.hit_derived[i], mi);
                     }
                 } else {
                     for (size_t lo = 0; lo < m; lo += 1u << 18) { // bounded text buffers: ~1 KB per key
