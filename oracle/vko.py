@@ -393,6 +393,16 @@ def pubkey(k, slow=False):
     return p33.raw, p65.raw
 
 
+def pubkey_batch(keys):
+    """vko_pubkey_batch: [(pub33, pub65)] for normalised keys (16-bit windows + one shared inversion)."""
+    n = len(keys)
+    p33, p65 = _out(33 * n), _out(65 * n)
+    lib().vko_pubkey_batch.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p]
+    lib().vko_pubkey_batch(b"".join(keys), n, p33, p65)
+    a, b = p33.raw, p65.raw
+    return [(a[33 * i:33 * i + 33], b[65 * i:65 * i + 65]) for i in range(n)]
+
+
 def scalar_add(a, b):
     o = _out(32)
     ok = lib().vko_scalar_add(a, b, o)

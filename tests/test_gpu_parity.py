@@ -375,6 +375,64 @@ def test_multibit_chain(eng, vko):
     assert sum(1 for r in got for k in r if k is not None) == 21 * 20
 
 
+def test_multibit_issue_445_vector_through_the_device(eng):
+    """The reference's own MultiBit-HD vector (src/multibit.rs:404-417) on the HIP path: mnemonic -> 20 keys -> address
+    1LQ8XnNK... for index 0.  The word list is the committed sparse fixture (real words at the 58 touched positions)."""
+    from tests.test_oracle_multibit import issue445_fixture
+    from vuke_amd import _ffi as ffi
+    fx, words = issue445_fixture()
+    eng.bip39_wordlist_set(words)
+    spec = ffi.spec(ffi.T_MULTIBIT, 0, 0, 20)
+    row = eng.transform_strings(spec, [fx["mnemonic"].encode()])[0]
+    assert [k.hex() for k in row] == [k for _, k in fx["keys"]]
+    _, hc, hu = eng.derive_batch([row[0]])
+    assert hc[0].hex() == fx["key0_h160_c"] and hu[0].hex() == fx["key0_h160_u"]
+    assert pyref.b58check(b"\0" + hc[0]) == "1LQ8XnNKqC7Vu7atH5k4X8qVCc9ug2q7WE"
+    # the same through the fused scan path: target = that address, one hit at (input 0, slot 0)
+    eng.targets_set([hc[0]], [ffi.TARGET_P2PKH])
+    st, hits = eng.scan_strings(spec, [b"not a mnemonic", fx["mnemonic"].encode()])
+    eng.targets_set([], [])
+    assert (st["inputs"], st["keys"], st["matches"]) == (2, 20, 1)
+    assert (hits[0]["index"], hits[0]["sub_index"], hits[0]["addr_kind"], hits[0]["privkey"].hex()) == (1, 0, 0, fx["keys"][0][1])
+
+
+def test_scan_strings_fused_path(eng, vko):
+    """vk_scan_strings = vk_transform_strings + vk_scan_keys without the host round trip: counters, digest and hits equal
+    the two-call form and the oracle; over-long strings produce no keys, never an error (ElectrumTransform skips what it
+    cannot parse, src/transform/electrum.rs:49-52)."""
+    from vuke_amd import _ffi as ffi
+    rnd = random.Random(77)
+    lines = [("pass%05d" % rnd.randrange(10**5)).encode() for _ in range(3000)] + [b"", b"x" * 300, b"correct horse battery staple"]
+    for spec, ospec in ((ffi.spec(ffi.T_SHA256), vko.spec(vko.T_SHA256)), (ffi.spec(ffi.T_SHA256_CHAIN), vko.spec(vko.T_SHA256_CHAIN))):
+        rows = eng.transform_strings(spec, lines)
+        flat = [(i, s, k) for i, r in enumerate(rows) for s, k in enumerate(r) if k is not None]
+        picks = [flat[7], flat[len(flat) // 2], flat[-1]]
+        tg = [bytes(vko.derive(k).h160_c if j != 1 else vko.derive(k).h160_u) for j, (_, _, k) in enumerate(picks)]
+        eng.targets_set(tg, [ffi.TARGET_P2PKH] * 3)
+        st, hits = eng.scan_strings(spec, lines)
+        st2, hits2 = eng.scan_keys([k for _, _, k in flat])
+        eng.targets_set([], [])
+        assert (st["inputs"], st["keys"], st["matches"]) == (len(lines), len(flat), 3)
+        assert st["digest"] == st2["digest"]
+        assert [(h["index"], h["sub_index"]) for h in hits] == [(i, s) for i, s, _ in picks]
+        assert [h["privkey"] for h in hits] == [vko.normalize_key(k) for _, _, k in picks] == [h["privkey"] for h in hits2]
+        assert [h["addr_kind"] for h in hits] == [0, 1, 0]
+        # the oracle on the same strings
+        for (i, s, k) in picks:
+            assert vko.transform_string(ospec, lines[i], s) == k
+    # electrum: a 65-byte line (hex or not) and a 300-byte line no longer abort the batch
+    es = ffi.spec(ffi.T_ELECTRUM, 0, 0, 2)
+    seeds = [b"acb740e454c3134901d7c8f16497cc1c", b"z" * 65, b"ab" * 33, b"f" * 300, b"0123"]
+    rows = eng.transform_strings(es, seeds)
+    assert "1 input string(s) longer" not in eng.last_warning() and "2 input string(s) longer" in eng.last_warning()  # the two all-hex ones
+    assert [sum(k is not None for k in r) for r in rows] == [2, 0, 0, 0, 2]
+    assert rows[0] == [k for _, k in vko.electrum_keys(seeds[0], count=2)[1]]
+    st, _ = eng.scan_strings(es, seeds)
+    assert (st["inputs"], st["keys"]) == (5, 4) and st["warning"].startswith("warning: 2 ")
+    rows = eng.transform_strings(es, seeds[:1])
+    assert eng.last_warning() == ""
+
+
 def test_multibit_passphrase(eng, vko):
     """vk_multibit_passphrase_set: salt = "mnemonic" || passphrase in both stretches (multibit-hd analyzer)."""
     from tests.test_oracle_multibit import synthetic_wordlist

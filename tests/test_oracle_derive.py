@@ -44,6 +44,33 @@ def test_pubkey_slow_fast_python_agree(vko):
         assert slow == py and fast == py, hex(k)
 
 
+def test_pubkey_batch_agrees_with_double_and_add(vko):
+    """The third k*G path (16-bit windows + Montgomery batch inversion; generator of tests/golden/milksad_2p32.json and the
+    lean CPU baseline) against plain double-and-add and python integers, including every single-window digit shape."""
+    rnd = random.Random(9)
+    ks = [1, 2, 3, 0xFFFF, 0x10000, 0x10001, 2**128, N - 1, N - 2, 2**255, int.from_bytes(CHBS, "big")]
+    ks += [rnd.getrandbits(256) % (N - 1) + 1 for _ in range(60)]
+    ks += [1 << (16 * i) for i in range(16)] + [0xFFFF << (16 * i) for i in range(15)] + [rnd.getrandbits(16 * i + 5) + 1 for i in range(16)]
+    kbs = [k.to_bytes(32, "big") for k in ks]
+    got = vko.pubkey_batch(kbs)
+    for k, kb, g in zip(ks, kbs, got):
+        assert g == vko.pubkey(kb, slow=True) == pyref.pubkeys(k), hex(k)
+    assert vko.pubkey_batch(kbs[:1]) == got[:1] and vko.pubkey_batch([]) == []
+
+
+def test_batched_sweep_equals_plain_sweep(vko):
+    """VKO_F_BATCHED changes only how a chunk's public keys are computed: counters, digest and hits are the plain sweep's."""
+    rnd = random.Random(10)
+    for kind, fl in ((vko.T_MILKSAD, 1), (vko.T_SHA256, 3), (vko.T_LCG, 3), (vko.T_SHA256_CHAIN, 2), (vko.T_XORSHIFT, 1)):
+        sp = vko.spec(kind)
+        for lo in (0, 2**32 - 1500, 2**31 - 700, rnd.randrange(2**32)):
+            d = vko.derive(vko.transform_apply(sp, lo + 5)[0][1])
+            m = vko.Matcher([d.p2pkh_compressed.decode(), d.p2pkh_uncompressed.decode()])
+            a = vko.sweep(sp, lo, lo + 1499, flags=fl, matcher=m, nthreads=2)
+            b = vko.sweep(sp, lo, lo + 1499, flags=fl | vko.F_BATCHED, matcher=m, nthreads=3)
+            assert a == b and a[0]["matches"] >= 1, (kind, lo)
+
+
 def test_derive_reference_known_key(vko):
     d = vko.derive(CHBS)
     # src/derive.rs:190-199

@@ -94,3 +94,30 @@ def test_reference_issue_445_vectors(vko):
     assert vko.multibit_keys(wl, "abandon abandon abandon") is None                                    # :426-433
     assert vko.multibit_keys(wl, "abandon " * 11 + "notaword") is None                                 # :435-443
     assert vko.multibit_keys(wl, "abandon " * 11 + "about") is not None                                # :419-424
+
+
+def issue445_fixture():
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "multibit_issue445.json")))
+    words = []
+    for i in range(2048):  # the fixture's filler rule
+        s, v = "", i
+        for _ in range(3):
+            s = chr(ord("a") + v % 26) + s
+            v //= 26
+        words.append("q" + s)
+    for i, w in fx["words_at"]:
+        words[i] = w
+    return fx, words
+
+
+def test_issue_445_fixture_without_the_reference_tree(vko):
+    """tests/golden/multibit_issue445.json (made from the real list by make_issue445.py) reproduces the reference vector
+    through the oracle with only the ~58 touched positions of the list filled in: this is what the GPU test replays."""
+    fx, words = issue445_fixture()
+    assert len(set(words)) == 2048
+    seed1, seed2, keys = vko.multibit_keys(vko.Wordlist(words), fx["mnemonic"])
+    assert (seed1.hex(), seed2.hex()) == (fx["seed1"], fx["seed2"])
+    assert [[l, k.hex()] for l, k in keys] == fx["keys"] and len(keys) == 20
+    assert keys[0][1].hex() == "9e143561ac6d038bb7d27321dfd56286a21ea4c01c2b1d2fdfb41380beaa5409"
+    assert vko.derive(keys[0][1]).p2pkh_compressed == b"1LQ8XnNKqC7Vu7atH5k4X8qVCc9ug2q7WE" == fx["key0_p2pkh_compressed"].encode()
