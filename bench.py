@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- keys/sec (seed -> P2PKH hash160 -> target probe) for the Milksad sweep on MI355X.
+"""bench.py -- keys/sec of the seed -> key -> k*G -> hash160 -> probe path on MI355X, one JSON line on rank 0.
 
-Workload (BASELINE.json configs[1]): Milksad (MT19937) seeds, compressed P2PKH, 1024 planted
-targets in the on-device probe table.  One *step* = one 2^28-seed block of the 2^32 seed space
-per GPU (16 steps on one GPU = the whole sweep).  With N GPUs, rank r sweeps blocks
-(r*K + step) mod 16: the seed space is range-partitioned, no data-path collective; RCCL is used
-only to all-reduce the counters after the timed region.
+Default workload = BASELINE.json configs[1]: Milksad (MT19937) seed sweep, compressed P2PKH, 1024 (+2) planted targets
+in the on-device probe table; one *step* = one 2^28-seed block of the 2^32 seed space per GPU (16 steps on one GPU =
+the whole sweep).  With N GPUs, rank r sweeps blocks (r*K + step) mod 16: the seed space is range-partitioned, no
+data-path collective; RCCL is used only to all-reduce counters after the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5m|5e] [--strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see README "bench contract").
+Other configs under the same contract (inputs in vuke_amd/workloads.py):
+  --config 3   scan --transform=sha256 vs 1 000 000 targets (both hash160s), step = 2^25 inputs (3 keys each)
+  --config 4   all LCG variants, step = 2^26 seeds (4 keys each) of the 2^31 seed space, range-split over ranks
+  --config 5m  100 000 synthetic MultiBit-HD mnemonics -> 20 keys each -> probe (vk_scan_strings), lines split over ranks
+  --config 5e  the same for Electrum v1 seeds
+--strong (config 2): the N ranks share ONE 2^32 sweep (16/N disjoint blocks each, no wrap) and the line also reports the
+end-to-end wall time from before the engine (table build) exists to after the counters are reduced.
+
+Every expected value comes from the CPU oracle through committed fixtures (tests/golden/): planted hash160s, the
+digest of every 2^28 block of the Milksad space, the digest of each config's warm-up window.  bench.py itself touches
+oracle/ only in the cpu_baseline leg.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,27 +31,268 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BLOCK_LOG2 = 28
-BLOCK = 1 << BLOCK_LOG2
-NBLOCKS = 1 << (32 - BLOCK_LOG2)
-# canonical algorithmic work per Milksad key (32-bit integer ops)
-OPS_PER_KEY = 1736 + 213000 + 2168 + 1455
-# Integer-VALU peak: 256 CUs x 64 lanes/clk x 2.4 GHz = 39.3 T 32-bit ops/s.  Measured on
-# the box (profiles/r01_ubench_valu_rates.txt): v_mad_u64_u32 30-32 T lane-ops/s, mul_lo/hi, addc, alignbit,
-# add3, bfi 35-37.7 T (16 lanes/clk/SIMD), plain v_add_u32 / v_xor_b32 53-55 T -- for this instruction mix the
-# 16-lanes/clk/SIMD figure is the roof.
-PEAK_INT32 = 256 * 64 * 2.4e9
-N_PLANTED = 1024
+# Integer-VALU peak: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s.  This is the
+# 16-lanes-per-clock class that carries this path's arithmetic (v_mad_u64_u32, v_addc_co_u32, v_add3, v_alignbit:
+# 30-38 T measured, profiles/r01_ubench_valu_rates.txt); plain VOP2 adds / logic issue ~1.5x faster (52-58 T) and make
+# up ~15 % of the mix, so a fraction slightly above the naive bound is possible in principle.
+PEAK_INT32 = 256 * 4 * 16 * 2.4e9
+HBM_PEAK = 8.0e12
 
 
-def block_of(rank, step, steps, block_log2=BLOCK_LOG2):
-    """Seed block (inclusive) that `rank` sweeps at `step`: rank-major contiguous blocks, wrapping
-    inside the 2^32 Milksad seed space."""
+def block_of(rank, step, steps, block_log2=28, strong=False, world=1):
+    """Seed block (inclusive lo, hi) of the 2^32 Milksad space that `rank` sweeps at `step`.  Weak scaling (driver default):
+    rank-major blocks (rank*steps + step), wrapping inside the seed space.  --strong: the world shares ONE sweep, rank r owns
+    the contiguous run of nblocks/world blocks starting at r*nblocks/world (disjoint, no wrap, together the whole space)."""
     nblocks = 1 << (32 - block_log2)
-    b = (rank * steps + step) % nblocks
+    b = (rank * (nblocks // world) + step) if strong else (rank * steps + step) % nblocks
     return b << block_log2, ((b + 1) << block_log2) - 1
 
 
+def csrc_hash():
+    """SHA-256 over the kernel sources: PMC-derived numbers are only valid for the exact sources they were taken from."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "vuke_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".cuh", ".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(tag):
+    """profiles/pmc_<tag>.json (tools/pmc_summary.py) if it was taken from the kernel sources in this tree, else a reason."""
+    path = os.path.join(ROOT, "profiles", f"pmc_{tag}.json")
+    if not os.path.exists(path):
+        return None, f"no profiles/pmc_{tag}.json"
+    pj = json.load(open(path))
+    if pj.get("csrc_hash") != csrc_hash():
+        return None, f"profiles/pmc_{tag}.json was taken from other kernel sources ({pj.get('csrc_hash')} != {csrc_hash()}): re-run tools/profile.sh"
+    return pj, None
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+class Workload:
+    """One BASELINE config: targets, warm-up (checked against the oracle's fixture), timed steps."""
+    tag = "?"
+    kernel = "?"
+    unit_name = "keys"
+
+    def __init__(self, args, rank, world):
+        self.args, self.rank, self.world = args, rank, world
+        self.digest_checked = self.digest_bad = 0
+
+    def check_digest(self, got, want):
+        self.digest_checked += 1
+        if tuple(got) != tuple(want):
+            self.digest_bad += 1
+
+    def step_total(self):
+        return self.args.steps
+
+
+class Milksad(Workload):
+    tag, kernel = "c2", "vk_sweep_kernel<1u>"
+    # SURVEY.md 8(d): canonical algorithmic work per Milksad key (32-bit integer ops of a 4-bit-window reference algorithm)
+    canonical_ops_per_key = 1736 + 213000 + 2168 + 1455
+
+    def describe(self, eng):
+        return ("Milksad (MT19937) seed sweep, P2PKH compressed, 1026 planted targets; step = one 2^28-seed block per GPU "
+                "(16 blocks = full 2^32 sweep)" + ("; --strong: the ranks share one 2^32 sweep" if self.args.strong else ""))
+
+    def setup(self, eng, ffi, wl):
+        self.ffi, self.wl = ffi, wl
+        self.spec = ffi.spec(ffi.T_MILKSAD)
+        pl = wl.load_golden("milksad_planted.json")["planted"]
+        self.pseeds = [p["seed"] for p in pl]
+        eng.targets_set([bytes.fromhex(p["h160_c"]) for p in pl], [ffi.TARGET_P2PKH] * len(pl))
+        g = wl.load_golden("milksad_2p32.json")
+        self.block_digest = [wl.unhexd(d) for d in g["block_digests"]] if g else None
+        self.win = {w["lo"]: w for w in (wl.load_golden("digest_windows.json") or [])}
+        self.nblocks = 1 << (32 - wl.C2_BLOCK_LOG2)
+        if self.args.strong:
+            assert self.nblocks % self.world == 0, "--strong needs a GPU count that divides 16"
+            self.per_rank = self.nblocks // self.world
+
+    def step_total(self):
+        return self.per_rank if self.args.strong else self.args.steps
+
+    def block_of(self, step):
+        lo, _ = block_of(self.rank, step, self.args.steps, self.wl.C2_BLOCK_LOG2, self.args.strong, self.world)
+        return lo >> self.wl.C2_BLOCK_LOG2
+
+    def warmup(self, eng):
+        # the first 2^20 seeds: the oracle's digest for that window is a committed fixture (tests/golden/digest_windows.json)
+        st, _ = eng.sweep(self.spec, 0, (1 << 20) - 1, flags=self.ffi.F_COMPRESSED, hit_cap=2048)
+        w = self.win.get(0)
+        if w:
+            self.check_digest(st["digest"], self.wl.unhexd(w["digest"]))
+        lo = self.block_of(0) << self.wl.C2_BLOCK_LOG2
+        eng.sweep(self.spec, lo, lo + (1 << 24) - 1, flags=self.ffi.F_COMPRESSED, hit_cap=2048)  # clocks and caches up
+        return st
+
+    def step(self, eng, s):
+        b = self.block_of(s)
+        lo, hi = b << self.wl.C2_BLOCK_LOG2, ((b + 1) << self.wl.C2_BLOCK_LOG2) - 1
+        st, hits = eng.sweep(self.spec, lo, hi, flags=self.ffi.F_COMPRESSED, hit_cap=2048)
+        if self.block_digest:
+            self.check_digest(st["digest"], self.block_digest[b])
+        st["expected"] = sum(1 for p in self.pseeds if lo <= p <= hi)
+        st["units"] = st["keys"]
+        return st
+
+    def algo_bytes_per_key(self, info):
+        return info["windows"] * 64 + 128 + 160 + 32  # table entries + workspace write + workspace read + probe line (DESIGN 4.1)
+
+
+class Sha256Scan(Workload):
+    tag, kernel = "c3", "vk_sweep_kernel<0u>"
+    canonical_ops_per_key = 2168 + 213000 + 3 * 2168 + 2 * 1455
+
+    def describe(self, eng):
+        return "scan --transform=sha256 vs 1 000 000 targets (1000 planted + 999 000 decoys), both hash160s, 3 keys/input; step = 2^25 inputs per GPU"
+
+    def setup(self, eng, ffi, wl):
+        self.ffi, self.wl = ffi, wl
+        self.spec = ffi.spec(ffi.T_SHA256)
+        self.fx = wl.load_golden("bench_c3.json")
+        h, k = [], []
+        for p in self.fx["planted"]:
+            h.append(bytes.fromhex(p["h160"]))
+            k.append(ffi.TARGET_P2WPKH if p["addr_kind"] == 2 else ffi.TARGET_P2PKH)
+        for d, kind in wl.c3_decoys():
+            h.append(d)
+            k.append(kind)
+        eng.targets_set(h, k)
+        self.pseeds = [p["seed"] for p in self.fx["planted"]]
+
+    def warmup(self, eng):
+        w = self.fx["warmup"]
+        st, _ = eng.sweep(self.spec, w["lo"], w["hi"], flags=3, hit_cap=2048)
+        self.check_digest(st["digest"], self.wl.unhexd(w["digest"]))
+        return st
+
+    def step(self, eng, s):
+        n = self.wl.C3_STEP_INPUTS
+        b = self.rank * self.args.steps + s
+        lo, hi = b * n, (b + 1) * n - 1
+        st, _ = eng.sweep(self.spec, lo, hi, flags=3, hit_cap=2048)
+        st["expected"] = sum(1 for p in self.pseeds if lo <= p <= hi)
+        st["units"] = st["keys"]
+        return st
+
+    def algo_bytes_per_key(self, info):
+        return info["windows"] * 64 + 128 + 160 + 2 * 32
+
+
+class LcgAll(Workload):
+    tag, kernel = "c4", "vk_sweep_kernel<3u>"
+    canonical_ops_per_key = 40 + 213000 + 2168 + 1455
+
+    def describe(self, eng):
+        return "all LCG variants (glibc, minstd, msvc, borland; BE) x 2^31 seeds, compressed; step = one 2^26-seed block (2^28 keys) per GPU, 32 blocks range-split over the ranks"
+
+    def setup(self, eng, ffi, wl):
+        self.ffi, self.wl = ffi, wl
+        self.spec = ffi.spec(ffi.T_LCG)
+        self.fx = wl.load_golden("bench_c4.json")
+        pl = self.fx["planted"]
+        eng.targets_set([bytes.fromhex(p["h160"]) for p in pl], [ffi.TARGET_P2PKH] * len(pl))
+        self.pseeds = [p["seed"] for p in pl]
+        self.nblocks = wl.C4_SEEDS // wl.C4_STEP_SEEDS
+
+    def warmup(self, eng):
+        w = self.fx["warmup"]
+        st, _ = eng.sweep(self.spec, w["lo"], w["hi"], flags=1, hit_cap=2048)
+        self.check_digest(st["digest"], self.wl.unhexd(w["digest"]))
+        return st
+
+    def step(self, eng, s):
+        n = self.wl.C4_STEP_SEEDS
+        b = (self.rank * self.args.steps + s) % self.nblocks
+        lo, hi = b * n, (b + 1) * n - 1
+        st, _ = eng.sweep(self.spec, lo, hi, flags=1, hit_cap=2048)
+        st["expected"] = sum(1 for p in self.pseeds if lo <= p <= hi)
+        st["units"] = st["keys"]
+        return st
+
+    def algo_bytes_per_key(self, info):
+        return info["windows"] * 64 + 128 + 160 + 32
+
+
+class Chains(Workload):
+    """config 5: string inputs -> KDF chain -> 20 keys -> derive -> probe, fused on the device (vk_scan_strings)."""
+    unit_name = "inputs"
+
+    def __init__(self, args, rank, world, which):
+        super().__init__(args, rank, world)
+        self.which = which
+        self.tag = "c5m" if which == "multibit" else "c5e"
+        self.kernel = "vk_multibit_kernel" if which == "multibit" else "vk_electrum_kernel"
+        # SURVEY 8(d): SHA-512 compression 5520 ops; MultiBit = 2 x 2048 x 2 compressions + 40 k*G + 20 derives;
+        # Electrum = 200 000 SHA-256 compressions + 21 k*G (+ 20 derives)
+        self.canonical_ops_per_input = (2 * 2048 * 2 * 5520 + 40 * 213000 + 20 * 220000) if which == "multibit" else (200000 * 2168 + 21 * 213000 + 20 * 220000)
+
+    def describe(self, eng):
+        return (f"{self.wl.C5_INPUTS} synthetic {'12-word MultiBit-HD mnemonics' if self.which == 'multibit' else '32-hex-digit Electrum v1 seeds'} "
+                f"-> 20 keys each -> both hash160s -> probe (100 planted: key 7 of every 1000th input); step = one pass over the rank's slice of the inputs")
+
+    def setup(self, eng, ffi, wl):
+        self.ffi, self.wl = ffi, wl
+        fx = wl.load_golden("bench_c5.json")[self.which]
+        self.fx = fx
+        if self.which == "multibit":
+            eng.bip39_wordlist_set(wl.c5_wordlist())
+            self.spec = ffi.spec(ffi.T_MULTIBIT, 0, 0, 20)
+            lines = wl.c5_mnemonics()
+            nwarm = wl.C5_WARMUP_MULTIBIT
+        else:
+            self.spec = ffi.spec(ffi.T_ELECTRUM, 0, 0, 20)
+            lines = wl.c5_electrum_seeds()
+            nwarm = wl.C5_WARMUP_ELECTRUM
+        assert lines[0].decode() == fx["first_input"]
+        pl = fx["planted"]
+        eng.targets_set([bytes.fromhex(p["h160"]) for p in pl], [ffi.TARGET_P2PKH] * len(pl))
+        # line partition: rank r takes the r-th contiguous slice of the same 100 000 inputs
+        n = len(lines)
+        a, b = n * self.rank // self.world, n * (self.rank + 1) // self.world
+        self.first = a
+        self.packed = ffi.pack_strings(lines[a:b])
+        self.warm_packed = ffi.pack_strings(lines[:nwarm])
+        self.expected = sum(1 for p in pl if a <= p["input"] < b)
+        self.planted_here = [(p["input"] - a, p["sub_index"]) for p in pl if a <= p["input"] < b]
+
+    def warmup(self, eng):
+        st, _ = eng.scan_strings(self.spec, None, flags=3, hit_cap=2048, packed=self.warm_packed)
+        w = self.fx["warmup"]
+        self.check_digest(st["digest"], self.wl.unhexd(w["digest"]))
+        return st
+
+    def step(self, eng, s):
+        st, hits = eng.scan_strings(self.spec, None, flags=3, hit_cap=2048, packed=self.packed)
+        st["expected"] = self.expected
+        if [(h["index"], h["sub_index"]) for h in hits] != self.planted_here:
+            st["matches"] = -1  # wrong hit set: fails the parity check below
+        st["units"] = st["inputs"]
+        return st
+
+    def algo_bytes_per_key(self, info):
+        return None
+
+
+def make_workload(args, rank, world):
+    c = args.config
+    if c == "2":
+        return Milksad(args, rank, world)
+    if c == "3":
+        return Sha256Scan(args, rank, world)
+    if c == "4":
+        return LcgAll(args, rank, world)
+    if c in ("5m", "5e"):
+        return Chains(args, rank, world, "multibit" if c == "5m" else "electrum")
+    raise SystemExit(f"bench.py: unknown --config {c}")
+
+
+# ------------------------------------------------------------------------------------------------ main
 def reduce_counters(dist, dev, counters, elapsed):
     """Sum the integer counters and take the max elapsed time over ranks (one tiny collective each)."""
     import torch
@@ -53,28 +304,31 @@ def reduce_counters(dist, dev, counters, elapsed):
     return [int(x) for x in tot.tolist()], float(tmax.item())
 
 
-def planted_seeds():
-    return [(0x9E3779B1 * j + 12345) & 0xFFFFFFFF for j in range(N_PLANTED)]
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="2", choices=["2", "3", "4", "5m", "5e"])
+    ap.add_argument("--strong", action="store_true", help="config 2: N ranks share one 2^32 sweep; also report end-to-end wall time")
+    ap.add_argument("--emulate-gpus", type=int, default=0, help="--strong on one GPU: sweep only this rank-0 share of an M-GPU run (16/M blocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--algo", type=int, default=0, help="0 = Jacobian chain (default), 1 = VK_ALGO_TREE (experimental, see DESIGN.md section 8)")
+    ap.add_argument("--algo", type=int, default=0, help="0 = XYZZ chain (default), 1 = VK_ALGO_TREE (experimental, see DESIGN.md section 8)")
     # rehearsal knobs (not used by the driver): run the N-rank path on a box with fewer GPUs than ranks
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal)")
     ap.add_argument("--share-device", type=int, default=-1, help="put every rank on this one GPU (rehearsal only)")
-    # table geometry of the flagship run: 9 signed-digit windows (120 GB of the 288 GB HBM, 8 point additions per
-    # key), 128 keys per lane per field inversion, 3 resident workgroups per CU.  --layout 0 --window-bits 24 is the
-    # library default (11.8 GB, 10 additions).
+    # table geometry of the flagship run: 9 signed-digit windows (120 GB of the 288 GB HBM, 8 point additions per key),
+    # 256 keys per lane per field inversion, 2 resident workgroups per CU.  --layout 0 --window-bits 24 is the library
+    # default (11.8 GB, 10 additions).
     ap.add_argument("--layout", type=int, default=1)
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--blocks-per-cu", type=int, default=2)
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"2": 16, "3": 3, "4": 8, "5m": 10, "5e": 3}[args.config]
+    if args.strong and args.config != "2":
+        raise SystemExit("bench.py: --strong is defined for --config 2")
 
     import torch
     import torch.distributed as dist
@@ -101,7 +355,16 @@ def main():
 
     import vuke_amd
     from vuke_amd import _ffi as ffi
+    from vuke_amd import workloads as wl
 
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t_wall0 = time.perf_counter()
     try:
         eng = vuke_amd.Engine(local_rank, window_bits=args.window_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=args.layout, algo=args.algo)
     except vuke_amd.VkError as exc:
@@ -110,133 +373,126 @@ def main():
         # the 120 GB table did not fit (shared or smaller device): fall back to the library's default geometry
         print(f"bench.py: layout {args.layout} unavailable ({exc}); using the default 24-bit uniform table", file=sys.stderr)
         eng = vuke_amd.Engine(local_rank, batch=args.batch, blocks_per_cu=args.blocks_per_cu)
-    spec = ffi.spec(ffi.T_MILKSAD)
+    engine_create_s = time.perf_counter() - t_wall0
+    info = eng.info()
 
-    # synthetic targets: compressed P2PKH hash160 of 1024 known seeds, derived on the device
-    pseeds = planted_seeds()
-    keys = [row[0] for row in eng.transform_batch(spec, pseeds)]
-    _, h160c, _ = eng.derive_batch(keys)
-    eng.targets_set(h160c, [ffi.TARGET_P2PKH] * len(h160c))
+    w = make_workload(args, rank, world)
+    w.setup(eng, ffi, wl)
+    if args.strong and args.emulate_gpus:
+        w.per_rank = w.nblocks // args.emulate_gpus
+    setup_s = time.perf_counter() - t_wall0 - engine_create_s
+    steps = w.step_total()
 
-    def my_block(step):
-        return block_of(rank, step, args.steps)
+    for _ in range(args.warmup):
+        w.warmup(eng)
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for w in range(args.warmup):
-        lo, hi = my_block(w)
-        eng.sweep(spec, lo, lo + (BLOCK >> 4) - 1, flags=ffi.F_COMPRESSED, hit_cap=N_PLANTED)
-
-    keys_done = matches = expected = 0
+    units = keys_done = matches = expected = launches = 0
     kernel_s = 0.0
-    launches = 0
-    digest = [0, 0, 0, 0]
+    digest = (0, 0, 0, 0)
     sync()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        lo, hi = my_block(s)
-        st, hits = eng.sweep(spec, lo, hi, flags=ffi.F_COMPRESSED, hit_cap=N_PLANTED)
+    for s in range(steps):
+        st = w.step(eng, s)
+        units += st["units"]
         keys_done += st["keys"]
         matches += st["matches"]
+        expected += st["expected"]
         kernel_s += st["kernel_seconds"]
         launches += st["launches"]
-        for i in range(3):
-            digest[i] ^= st["digest"][i]
-        digest[3] = (digest[3] + st["digest"][3]) & (2**64 - 1)
-        expected += sum(1 for p in pseeds if lo <= p <= hi)
+        digest = wl.fold_digests([digest, st["digest"]])
     sync()
     elapsed = time.perf_counter() - t0
 
     # counters: one tiny all-reduce over RCCL (the only collective on this path)
     red_dev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")
-    (total_keys, total_matches, total_expected), t = reduce_counters(dist, red_dev, [keys_done, matches, expected], elapsed)
+    (total_units, total_keys, total_matches, total_expected, dg_checked, dg_bad), t = reduce_counters(
+        dist, red_dev, [units, keys_done, matches, expected, w.digest_checked, w.digest_bad], elapsed)
+    wall_s = time.perf_counter() - t_wall0
+    # the digests of all ranks (XOR words and the wrapping sum): gathered, folded on rank 0
+    all_digests = [digest]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [int(x) for x in digest])
+        all_digests = [tuple(g) for g in gathered]
     if total_matches != total_expected:
-        print(f"bench.py: PARITY FAILURE: {total_matches} matches, {total_expected} planted seeds in range", file=sys.stderr)
+        print(f"bench.py: PARITY FAILURE: {total_matches} matches, {total_expected} planted in range", file=sys.stderr)
+        sys.exit(3)
+    if dg_bad:
+        print(f"bench.py: PARITY FAILURE: {dg_bad} of {dg_checked} digests differ from the oracle's (tests/golden)", file=sys.stderr)
         sys.exit(3)
 
     if rank == 0:
         value = total_keys / t
         per_launch_keys = keys_done / max(launches, 1)
         per_launch_s = kernel_s / max(launches, 1)
-        achieved = per_launch_keys * OPS_PER_KEY / per_launch_s
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        extra = {}
-        if os.path.exists(pmc_path):
-            try:
-                pj = json.load(open(pmc_path))
-                traffic = pj.get("hbm_bytes_per_launch")
-                extra = {k: pj[k] for k in ("valu_insts_per_key", "cycles_per_valu_inst_per_simd", "effective_clock_ghz",
-                                            "hbm_gbps_raw", "source") if k in pj}
-                extra["note"] = ("frac > 1: the shipped algorithm (9 signed windows in a 120 GB HBM table = 8 point additions per key, v_mad_u64_u32 field arithmetic) executes "
-                                 "valu_insts_per_key wave-instructions per key, not the canonical 218359 ops; executed_frac = "
-                                 "instructions actually issued (rocprofv3 SQ_INSTS_VALU x this run's key rate) / the same 39.3 Tops/s peak; "
-                                 "the issue-limit check is cycles_per_valu_inst_per_simd vs the ~4.2 cycles a wide integer op holds a SIMD")
-            except Exception:
-                pass
+        rate = keys_done / kernel_s  # this rank's keys per second of kernel time
+        pmc, why = load_pmc(w.tag)
+        roof = {"bound": "valu-int", "peak": PEAK_INT32 / 1e12,
+                "unit": "T lane-ops/s = executed VALU wave-instructions (rocprofv3 SQ_INSTS_VALU) x 64 lanes / s; peak = the 16-lanes-per-clock "
+                        "class (v_mad_u64_u32, carry adds, v_add3, v_alignbit): 256 CU x 4 SIMD x 16 lanes x 2.4 GHz",
+                "kernel": w.kernel, "kernel_ms_per_launch": 1e3 * per_launch_s, "keys_per_launch": per_launch_keys}
+        if pmc:
+            per_key = pmc["valu_insts_per_key"]
+            roof.update({"achieved": per_key * rate / 1e12, "frac": per_key * rate / PEAK_INT32,
+                         "valu_insts_per_key": per_key, "pmc_source": pmc["source"], "pmc_csrc_hash": pmc["csrc_hash"], "pmc_git": pmc.get("git"),
+                         "cycles_per_valu_inst_per_simd": pmc.get("cycles_per_valu_inst_per_simd"),
+                         "effective_clock_ghz_in_profile": pmc.get("effective_clock_ghz"),
+                         "traffic": pmc.get("hbm_bytes_per_launch_calibrated", pmc.get("hbm_bytes_per_launch")),
+                         "vgpr": pmc.get("dispatch", {}).get("VGPR_Count"), "scratch": pmc.get("dispatch", {}).get("Scratch_Size")})
+        else:
+            roof.update({"achieved": None, "frac": None, "traffic": None, "pmc_refused": why})
+        if hasattr(w, "canonical_ops_per_key"):
+            roof["canonical_ops_per_key"] = w.canonical_ops_per_key
+            roof["canonical_frac"] = w.canonical_ops_per_key * rate / PEAK_INT32
+        else:
+            roof["canonical_ops_per_input"] = w.canonical_ops_per_input
+            roof["canonical_frac"] = w.canonical_ops_per_input * (units / kernel_s) / PEAK_INT32
+        roof["canonical_note"] = ("SURVEY 8(d)'s fixed 4-bit-window reference algorithm; the shipped kernel does far fewer operations per key "
+                                  "(9 windows in a 120 GB HBM table), so this ratio exceeds 1 and is NOT a utilisation figure -- frac is")
         out = {
-            "metric": "keys/sec (seed->P2PKH addr), Milksad sweep",
+            "metric": "keys/sec (seed->P2PKH addr)" + (", Milksad sweep" if args.config == "2" else f", BASELINE config {args.config}"),
             "value": value,
             "unit": "keys/s",
             "n_gpus": n_gpus,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * t / args.steps,
+            "ms_per_step": 1e3 * t / steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (args.strong or args.config in ("5m", "5e")) else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": "Milksad (MT19937) seed sweep, P2PKH compressed, 1024 planted targets; "
-                            f"step = one 2^{BLOCK_LOG2}-seed block per GPU (16 blocks = full 2^32 sweep)",
-                "seeds_per_step_per_gpu": BLOCK,
-                "window_bits": eng.info()["window_bits"],
-                "windows": eng.info()["windows"],
-                "layout": eng.info()["layout"],
-                "table_gb": eng.info()["table_bytes"] / 1e9,
-                "table_build_seconds": eng.info()["table_build_seconds"],
-                "batch": eng.info()["batch"],
-                "parallelism": f"range-partition x{n_gpus}",
+                "workload": w.describe(eng),
+                "baseline_config": int(args.config[0]),
+                "window_bits": info["window_bits"], "windows": info["windows"], "layout": info["layout"],
+                "table_gb": info["table_bytes"] / 1e9, "table_build_seconds": info["table_build_seconds"],
+                "batch": info["batch"], "parallelism": f"range-partition x{n_gpus}" if args.config in ("2", "3", "4") else f"line-partition x{n_gpus}",
             },
-            "sweep_2p32_seconds_at_this_rate": (1 << 32) / value,
             "matches": total_matches,
-            "digest": [f"{d:016x}" for d in digest],
-            "roofline": {
-                "bound": "valu-int32",
-                "achieved": achieved / 1e12,
-                "peak": PEAK_INT32 / 1e12,
-                "unit": "Tops/s (canonical 32-bit integer ops, SURVEY 8d: %d per key)" % OPS_PER_KEY,
-                "frac": achieved / PEAK_INT32,
-                "traffic": traffic,
-                "kernel": "vk_sweep_kernel<MILKSAD>",
-                "kernel_ms_per_launch": 1e3 * per_launch_s,
-                "keys_per_launch": per_launch_keys,
-                **extra,
-                "table_gathers_per_s": eng.info()["windows"] * per_launch_keys / per_launch_s,
-                "table_gather_ceiling_per_s": 48.5e9,  # random 64-B entries, quad-cooperative reads landing in LDS (tools/lds_gather_test.hip, profiles/r01_table_read_experiments.txt)
-                **({"executed_tops": extra["valu_insts_per_key"] * per_launch_keys / per_launch_s / 1e12,
-                    "executed_frac": extra["valu_insts_per_key"] * per_launch_keys / per_launch_s / PEAK_INT32}
-                   if "valu_insts_per_key" in extra else {}),
-            },
+            "keys_total": total_keys, "units_total": total_units,
+            "digest": wl.hexd(wl.fold_digests(all_digests)),
+            "digest_ok": (dg_bad == 0) if dg_checked else None,
+            "digests_checked_against_oracle": dg_checked,
+            "roofline": roof,
         }
-        # the same launch priced against the memory system, in the contract's own form (the kernel is not HBM-bound: see frac)
-        algo_bytes_per_key = eng.info()["windows"] * 64 + 128 + 160 + 32  # table entries + workspace write + workspace read + target probe
-        out["roofline_hbm"] = {
-            "bound": "hbm",
-            "achieved": algo_bytes_per_key * per_launch_keys / per_launch_s / 1e9,
-            "peak": 8000.0,
-            "unit": "GB/s",
-            "frac": algo_bytes_per_key * per_launch_keys / per_launch_s / 8e12,
-            "traffic": traffic,
-            "algorithmic_bytes_per_key": algo_bytes_per_key,
-        }
+        if w.unit_name == "inputs":
+            out["inputs_per_s"] = total_units / t
+        if args.config == "2":
+            out["sweep_2p32_seconds_at_this_rate"] = (1 << 32) / value
+            ab = w.algo_bytes_per_key(info)
+            out["roofline_hbm"] = {"bound": "hbm", "achieved": ab * rate / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ab * rate / HBM_PEAK,
+                                   "traffic": roof.get("traffic"), "algorithmic_bytes_per_key": ab,
+                                   "table_gathers_per_s": info["windows"] * rate,
+                                   "table_gather_ceiling_per_s": 48.5e9}  # quad-cooperative 64-B reads landing in LDS, tools/lds_gather_test.hip
+        if args.strong:
+            covered = steps * world == w.nblocks and not args.emulate_gpus
+            out["strong"] = {"blocks_per_rank": steps, "covers_full_2p32": covered, "engine_create_s": engine_create_s,
+                             "table_build_s": info["table_build_seconds"], "targets_and_fixtures_s": setup_s, "sweep_s": t, "wall_s": wall_s,
+                             "emulated_gpus": args.emulate_gpus or None,
+                             "note": "wall_s = from before vk_engine_create (table allocation + build) to after the counter all-reduce, warm-up included"}
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out), flush=True)
 
     eng.close()
@@ -244,34 +500,58 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline():
-    """The CPU oracle ("port": our C restatement, not the Rust binary) on the host cores."""
+def cpu_baseline(config):
+    """The CPU oracle ("port": our C restatement, not the Rust binary) on the host cores, on a bounded sample of the same
+    workload.  value = the leanest form (one k*G per key through 16-bit windows and a shared inversion + only the hash160s
+    the config needs); ref_faithful = everything KeyDeriver::derive does per key."""
     from oracle import vko
+    from vuke_amd import workloads as wl
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("VUKE_CPU_THREADS", "16"))))  # the 1-GPU box's CPU share is 16
-    sp = vko.spec(vko.T_MILKSAD)
-    vko.sweep(sp, 0, 4095, flags=vko.F_COMPRESSED, nthreads=cores)  # builds the table, warms up
-    n = 1 << 23   # about 10 s of CPU work on the 1-GPU box's 16-core share
-    t = time.perf_counter()
-    st, _ = vko.sweep(sp, 0, n - 1, flags=vko.F_COMPRESSED, nthreads=cores)
-    dt = time.perf_counter() - t
-    nf = 1 << 21  # about 7 s
-    t = time.perf_counter()
-    stf, _ = vko.sweep(sp, 0, nf - 1, flags=vko.F_COMPRESSED | vko.F_UNCOMPRESSED | vko.F_FAITHFUL, nthreads=cores)
-    dtf = time.perf_counter() - t
-    return {
-        "value": st["keys"] / dt,
-        "unit": "keys/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"Milksad seeds [0, 2^23), compressed hash160 + probe, oracle/ C restatement, {cores} threads, {dt:.1f} s",
-        "ref_faithful_value": stf["keys"] / dtf,
-        "ref_faithful_sample": f"seeds [0, 2^21), everything KeyDeriver::derive does per key (3 x k*G, both hash160, "
-                               f"base58/bech32/WIF/decimal strings), {dtf:.1f} s",
-    }
+
+    def timed(sp, n, flags):
+        t = time.perf_counter()
+        st, _ = vko.sweep(sp, 0, n - 1, flags=flags, nthreads=cores)
+        return st["keys"] / (time.perf_counter() - t), time.perf_counter() - t
+
+    if config in ("2", "3", "4"):
+        kind, fl, n = {"2": (vko.T_MILKSAD, 1, 1 << 25), "3": (vko.T_SHA256, 3, 1 << 23), "4": (vko.T_LCG, 1, 1 << 23)}[config]
+        sp = vko.spec(kind)
+        vko.sweep(sp, 0, 4095, flags=fl | vko.F_BATCHED, nthreads=cores)  # builds both tables, warms up
+        v, dt = timed(sp, n, fl | vko.F_BATCHED)
+        vu, dtu = timed(sp, n >> 3, fl)
+        vf, dtf = timed(sp, n >> 4, 3 | vko.F_FAITHFUL)
+        return {"value": v, "unit": "keys/s", "cores": cores, "kind": "port",
+                "sample": f"inputs [0, {n}) of the same workload, oracle/ C restatement with batched k*G (16-bit windows, one inversion per 1000-input chunk), {cores} threads, {dt:.1f} s",
+                "unbatched_value": vu, "unbatched_sample": f"inputs [0, {n >> 3}), 8-bit windows + one inversion per key, {dtu:.1f} s",
+                "ref_faithful_value": vf,
+                "ref_faithful_sample": f"inputs [0, {n >> 4}), everything KeyDeriver::derive does per key (3 x k*G, both hash160, base58/bech32/WIF/decimal strings), {dtf:.1f} s"}
+    # config 5: the KDF chain dominates; the oracle's chain functions over a thread pool (ctypes releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    if config == "5m":
+        words = vko.Wordlist(wl.c5_wordlist())
+        lines = wl.c5_mnemonics(6000)
+        fn = lambda m: vko.multibit_keys(words, m)
+    else:
+        lines = wl.c5_electrum_seeds(1000)
+        fn = lambda s: vko.electrum_keys(s)
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(fn, lines[:cores]))
+        t = time.perf_counter()
+        res = list(ex.map(fn, lines))
+        keys = 0
+        for r in res:
+            ks = r[2] if config == "5m" else r[1]
+            keys += len(ks)
+        for r in res[:64]:  # derive share (small next to the chain): timed on a slice, scaled
+            for _, k in (r[2] if config == "5m" else r[1]):
+                vko.derive_h160(k)
+        dt = time.perf_counter() - t
+    return {"value": keys / dt, "unit": "keys/s", "inputs_per_s": len(lines) / dt, "cores": cores, "kind": "port",
+            "sample": f"the first {len(lines)} inputs of the same workload through the oracle's chain (python thread pool over the C functions), {cores} threads, {dt:.1f} s"}
 
 
 if __name__ == "__main__":

@@ -73,3 +73,13 @@ def test_product_does_not_touch_oracle():
                     if re.search(r"\bvko_|libvko|import oracle|from oracle|oracle/vko", txt):
                         bad.append(os.path.join(dp, f))
     assert bad == []
+
+
+def test_coalescer_lint_record_covers_the_kernel_sources_in_the_tree():
+    """tools/lint_coalescer.py (the mechanical check for the LLVM register-coalescer defect behind round 1's short-fold
+    failure, profiles/r02_short_fold_root_cause.txt) was run on exactly these kernel sources and found nothing."""
+    import json
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "lint_coalescer.json")))
+    assert rec["dropped_outputs"] == 0 and rec["asm_statements"] > 20000
+    assert rec["csrc_hash"] == bench.csrc_hash(), "kernel sources changed: re-run tools/lint_coalescer.py (about 4 minutes)"

@@ -1,0 +1,87 @@
+"""bench.py as the driver runs it, on the one GPU of the test box: every config's line, the strong-scaling mode, and the
+N > 1 path with two ranks sharing the device (the launcher starts the ranks before anything touches the GPU)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, nproc=1, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), *args]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def check_contract(o, n_gpus=1):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline"):
+        assert k in o, k
+    assert o["n_gpus"] == n_gpus and o["unit"] == "keys/s" and o["dtype"] == "u32" and o["vs_baseline"] is None
+    assert "workload" in o["config"] and "model" not in o["config"]
+    r = o["roofline"]
+    assert r["peak"] == pytest.approx(39.3216) and "canonical_frac" in r
+    if r["frac"] is not None:  # a PMC profile of exactly these kernel sources is committed
+        assert 0.2 < r["frac"] < 1.3 and r["achieved"] == pytest.approx(r["frac"] * r["peak"])
+    else:
+        assert "pmc_refused" in r
+    assert o["digest_ok"] is True and o["digests_checked_against_oracle"] >= 1
+
+
+def test_default_config_two_steps_digest_checked_against_the_oracle():
+    o = run_bench("--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    check_contract(o)
+    assert o["config"]["baseline_config"] == 2 and o["config"]["layout"] == 1 and o["config"]["batch"] == 256
+    assert o["matches"] == 130 and o["value"] > 1.0e9   # planted seeds in blocks 0 and 1
+    assert o["digests_checked_against_oracle"] == 3       # the warm-up window + two 2^28 blocks of the full-space golden
+    assert o["roofline_hbm"]["frac"] < 1.0
+
+
+@pytest.mark.parametrize("cfg,steps,matches", [("3", 1, 1000), ("4", 2, None), ("5m", 1, 100), ("5e", 1, 100)])
+def test_other_baseline_configs_have_a_bench_line(cfg, steps, matches):
+    o = run_bench("--config", cfg, "--steps", str(steps), "--no-cpu-baseline")
+    check_contract(o)
+    assert o["config"]["baseline_config"] == int(cfg[0])
+    if matches is not None:
+        assert o["matches"] == matches
+    if cfg.startswith("5"):
+        assert o["inputs_per_s"] > 1e4 and o["value"] == pytest.approx(20 * o["inputs_per_s"], rel=1e-3)
+
+
+def test_strong_mode_reports_wall_time():
+    o = run_bench("--strong", "--emulate-gpus", "8", "--layout", "0", "--window-bits", "26", "--no-cpu-baseline")
+    check_contract(o)
+    s = o["strong"]
+    assert o["scaling"] == "strong" and o["steps"] == 2 and s["emulated_gpus"] == 8 and not s["covers_full_2p32"]
+    assert s["wall_s"] > s["sweep_s"] > 0 and s["engine_create_s"] >= s["table_build_s"] > 0
+
+
+def test_two_ranks_share_the_device():
+    """The N > 1 path end to end (RCCL all-reduce of the counters, digest gather, disjoint blocks) with both ranks on GPU 0."""
+    o = run_bench("--share-device", "0", "--layout", "0", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", nproc=2)
+    check_contract(o, n_gpus=2)
+    from vuke_amd import workloads as wl
+    planted = wl.c2_planted_seeds()
+    assert o["matches"] == sum(1 for p in planted if p < 4 << 28)          # ranks 0 and 1 sweep blocks 0,1 and 2,3
+    assert o["digests_checked_against_oracle"] == 6
+    g = wl.load_golden("milksad_2p32.json")
+    assert o["digest"] == wl.hexd(wl.fold_digests([wl.unhexd(d) for d in g["block_digests"][:4]]))
+    o = run_bench("--share-device", "0", "--layout", "0", "--strong", "--emulate-gpus", "8", "--no-cpu-baseline", nproc=2)
+    assert o["strong"]["blocks_per_rank"] == 2 and o["n_gpus"] == 2

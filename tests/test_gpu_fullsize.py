@@ -26,15 +26,21 @@ def fold(parts):
 def test_full_2p32_milksad_sweep_finds_every_planted_seed(eng):
     from vuke_amd import _ffi as ffi
     spec = ffi.spec(ffi.T_MILKSAD)
-    planted = sorted({(0x9E3779B1 * j + 12345) & 0xFFFFFFFF for j in range(1024)} | {0, 2**32 - 1})
-    keys = [row[0] for row in eng.transform_batch(spec, planted)]
-    _, h160c, _ = eng.derive_batch(keys)
+    # planted seeds, private keys and hash160s are the ORACLE's (tests/golden/milksad_planted.json), not the device's own
+    from vuke_amd import workloads as wl
+    pl = wl.load_golden("milksad_planted.json")["planted"]
+    planted = [p["seed"] for p in pl]
+    assert planted == wl.c2_planted_seeds()
+    keys = [bytes.fromhex(p["privkey"]) for p in pl]
+    h160c = [bytes.fromhex(p["h160_c"]) for p in pl]
     eng.targets_set(h160c, [ffi.TARGET_P2PKH] * len(h160c))
     st, hits = eng.sweep(spec, 0, 2**32 - 1, flags=ffi.F_COMPRESSED, hit_cap=4096)
     eng.targets_set([], [])
     assert (st["inputs"], st["keys"], st["matches"], st["hits_dropped"]) == (2**32, 2**32, len(planted), 0)
     assert [h["seed"] for h in hits] == planted
     assert all(h["addr_kind"] == 0 and h["h160"] == c and h["privkey"] == k for h, c, k in zip(hits, h160c, keys))
+    g = wl.load_golden("milksad_2p32.json")  # the oracle's digest of the whole space (default W=24 engine here)
+    assert g is not None and wl.hexd(st["digest"]) == g["digest"]
     # the same space in 16 blocks: counters add up, digest folds to the same value
     parts = [eng.sweep(spec, b << 28, ((b + 1) << 28) - 1, flags=ffi.F_COMPRESSED)[0] for b in range(16)]
     assert sum(p["keys"] for p in parts) == 2**32
@@ -42,6 +48,43 @@ def test_full_2p32_milksad_sweep_finds_every_planted_seed(eng):
     # seeds past u32::MAX are skipped by the transform (src/transform/milksad.rs:21): no keys, empty digest
     st2, _ = eng.sweep(spec, 2**32, 2**32 + 2**24, flags=ffi.F_COMPRESSED)
     assert st2["keys"] == 0 and st2["digest"] == (0, 0, 0, 0)
+
+
+def test_bench_geometry_full_2p32_sweep_against_the_oracles_golden():
+    """BASELINE config 2 end to end on the geometry the headline is quoted on (bench.py: layout 1 = signed9 / 120 GB,
+    batch 256, 2 workgroups per CU): all 16 blocks of 2^28 Milksad seeds, every expected value from the CPU oracle --
+    the planted seeds / keys / hash160s (milksad_planted.json) and the digest of each 2^28 block and of the whole 2^32
+    space (milksad_2p32.json, tests/golden/make_milksad_2p32.py: the oracle over all 2^32 seeds).
+    Reference behaviour: src/transform/milksad.rs:17-29, src/derive.rs:78-118, src/matcher.rs:72-98."""
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+    from vuke_amd import workloads as wl
+    g = wl.load_golden("milksad_2p32.json")
+    assert g is not None, "tests/golden/milksad_2p32.json is missing: run tests/golden/make_milksad_2p32.py"
+    pl = wl.load_golden("milksad_planted.json")["planted"]
+    e = vuke_amd.Engine(0, layout=1, batch=256, blocks_per_cu=2)
+    try:
+        info = e.info()
+        assert (info["layout"], info["windows"], info["batch"]) == (1, 9, 256)
+        spec = ffi.spec(ffi.T_MILKSAD)
+        e.targets_set([bytes.fromhex(p["h160_c"]) for p in pl], [ffi.TARGET_P2PKH] * len(pl))
+        parts, hits = [], []
+        for b in range(16):
+            st, h = e.sweep(spec, b << 28, ((b + 1) << 28) - 1, flags=ffi.F_COMPRESSED, hit_cap=2048)
+            assert (st["inputs"], st["keys"], st["hits_dropped"]) == (2**28, 2**28, 0)
+            assert wl.hexd(st["digest"]) == g["block_digests"][b], f"block {b}"
+            parts.append(st["digest"])
+            hits += h
+        assert wl.hexd(wl.fold_digests(parts)) == g["digest"]
+        assert [(h["seed"], h["privkey"].hex(), h["h160"].hex(), h["addr_kind"]) for h in hits] == [(p["seed"], p["privkey"], p["h160_c"], 0) for p in pl]
+        # a few of the 256 oracle windows of 2^24 seeds on their own, and one full-range call (4 launches of 2^30 inside the library)
+        for w in (0, 37, 255):
+            st, _ = e.sweep(spec, w << 24, ((w + 1) << 24) - 1, flags=ffi.F_COMPRESSED)
+            assert wl.hexd(st["digest"]) == g["window_digests"][w], f"window {w}"
+        st, h = e.sweep(spec, 0, 2**32 - 1, flags=ffi.F_COMPRESSED, hit_cap=2048)
+        assert (st["keys"], st["matches"], wl.hexd(st["digest"])) == (2**32, len(pl), g["digest"])
+    finally:
+        e.close()
 
 
 def test_digest_independent_of_table_geometry_and_batch(eng):

@@ -69,3 +69,63 @@ def test_block_partition_wraps_inside_the_seed_space():
             seen.add(lo)
     assert len(seen) == 16  # 8 ranks x 2 steps = the whole 2^32 space, no overlap
     assert bench.block_of(3, 5, 16, 28) == bench.block_of(0, (3 * 16 + 5) % 16, 16, 28)
+
+
+def test_strong_partition_is_one_disjoint_sweep():
+    """bench.py --strong: N ranks x 16/N blocks, no wrap, together exactly the 2^32 space, for every N the driver uses."""
+    import bench
+    for world in (1, 2, 4, 8, 16):
+        per = 16 // world
+        blocks = [bench.block_of(r, s, per, 28, strong=True, world=world) for r in range(world) for s in range(per)]
+        assert blocks == [(b << 28, ((b + 1) << 28) - 1) for b in range(16)]
+
+
+def test_bench_fixtures_are_consistent_with_the_workload_definitions():
+    """The committed oracle fixtures (tests/golden/bench_c*.json, milksad_planted.json) describe exactly the inputs
+    vuke_amd/workloads.py generates: same planted seeds in the same order, same first synthetic input."""
+    from vuke_amd import workloads as wl
+    assert [p["seed"] for p in wl.load_golden("milksad_planted.json")["planted"]] == wl.c2_planted_seeds()
+    c3 = wl.load_golden("bench_c3.json")
+    assert [(p["seed"], p["sub_index"], p["addr_kind"]) for p in c3["planted"]] == wl.c3_planted()
+    c4 = wl.load_golden("bench_c4.json")
+    assert [(p["seed"], p["sub_index"]) for p in c4["planted"]] == wl.c4_planted() and len(c4["planted"]) == 1024
+    c5 = wl.load_golden("bench_c5.json")
+    assert c5["multibit"]["first_input"].encode() == wl.c5_mnemonics(1)[0] and c5["electrum"]["first_input"].encode() == wl.c5_electrum_seeds(1)[0]
+    assert wl.c5_mnemonics(3, first=5) == wl.c5_mnemonics(8)[5:] and wl.c5_electrum_seeds(3, first=5) == wl.c5_electrum_seeds(8)[5:]
+    assert [p["input"] for p in c5["multibit"]["planted"]] == wl.c5_planted_inputs() == [p["input"] for p in c5["electrum"]["planted"]]
+    assert len(set(wl.c5_wordlist())) == 2048
+
+
+def test_bench_fixture_spot_checks_against_the_oracle(vko):
+    """A few entries of every bench fixture recomputed by the oracle (the generator is tests/golden/make_bench_fixtures.py)."""
+    from vuke_amd import workloads as wl
+    c3 = wl.load_golden("bench_c3.json")
+    for p in c3["planted"][:5] + c3["planted"][-3:]:
+        d = vko.derive(vko.transform_key(vko.spec(vko.T_SHA256), p["seed"], p["sub_index"]))
+        assert (bytes(d.h160_u) if p["addr_kind"] == 1 else bytes(d.h160_c)).hex() == p["h160"]
+    c4 = wl.load_golden("bench_c4.json")
+    for p in c4["planted"][::200]:
+        assert bytes(vko.derive(vko.transform_key(vko.spec(vko.T_LCG), p["seed"], p["sub_index"])).h160_c).hex() == p["h160"]
+    pl = wl.load_golden("milksad_planted.json")["planted"]
+    for p in pl[:3] + pl[-3:]:
+        assert bytes(vko.derive(vko.milksad_key(p["seed"])).h160_c).hex() == p["h160_c"]
+    c5 = wl.load_golden("bench_c5.json")
+    p = c5["multibit"]["planted"][1]
+    keys = vko.multibit_keys(vko.Wordlist(wl.c5_wordlist()), wl.c5_mnemonics(1, first=p["input"])[0])[2]
+    assert bytes(vko.derive(keys[p["sub_index"]][1]).h160_c).hex() == p["h160"]
+    st, _ = vko.sweep(vko.spec(vko.T_LCG), 0, 4095, flags=1 | vko.F_BATCHED, nthreads=2)
+    assert st["keys"] == 4 * 4096
+
+
+def test_golden_2p32_file_is_self_consistent_when_present():
+    """tests/golden/milksad_2p32.json (hours of oracle CPU): windows fold into blocks, blocks into the full digest, and
+    the committed 2^20-window fixture agrees with it where they overlap only through the fold rule."""
+    from vuke_amd import workloads as wl
+    g = wl.load_golden("milksad_2p32.json")
+    if g is None:
+        pytest.skip("full-space golden not generated yet")
+    win = [wl.unhexd(d) for d in g["window_digests"]]
+    assert len(win) == 256 and g["window_log2"] == 24
+    blocks = [wl.fold_digests(win[16 * b:16 * b + 16]) for b in range(16)]
+    assert [wl.hexd(b) for b in blocks] == g["block_digests"]
+    assert wl.hexd(wl.fold_digests(blocks)) == g["digest"]

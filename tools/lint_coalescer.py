@@ -28,6 +28,7 @@ DEF = re.compile(r"def (dead )?(undef )?(early-clobber )?(%\d+|\$\w+)")
 HDR = re.compile(r"^# \*\*\* IR Dump (Before|After) Register Coalescer")
 FN = re.compile(r"^# Machine code for function (\S+):")
 SLOT = re.compile(r"^(\d+B)\s+INLINEASM ")
+TOTAL = [0]
 
 
 def parse(path):
@@ -75,6 +76,7 @@ def lint(src, extra, tag):
                     bad += 1
                     print(f"{tag}: {fn} INLINEASM@{slot}: output ${i} live before register-coalescer, dead after")
     print(f"{tag}: {nasm} asm statements checked, {bad} dropped outputs")
+    TOTAL[0] += nasm
     return bad
 
 
@@ -89,6 +91,15 @@ def main():
         bad += lint(os.path.join(args.csrc, "vk_sweep_tu.hip"), [f"-DVK_SWEEP_GROUP={g}"], f"sweep_g{g}")
     if not args.no_engine and args.group is None:
         bad += lint(os.path.join(args.csrc, "vk_engine.hip"), [], "engine")
+    if args.group is None and not args.no_engine and args.csrc == CSRC:
+        # the record tests/test_abi.py checks against the kernel sources in the tree
+        sys.path.insert(0, ROOT)
+        import bench
+        import json
+        rec = {"tool": "tools/lint_coalescer.py", "csrc_hash": bench.csrc_hash(), "dropped_outputs": bad, "asm_statements": TOTAL[0],
+               "translation_units": ["vk_sweep_tu.hip -DVK_SWEEP_GROUP=0..4", "vk_engine.hip"]}
+        json.dump(rec, open(os.path.join(ROOT, "profiles", "lint_coalescer.json"), "w"), indent=1)
+        print("wrote profiles/lint_coalescer.json")
     sys.exit(1 if bad else 0)
 
 

@@ -1,72 +1,119 @@
 #!/usr/bin/env python3
-"""Turn a tools/profile.sh output directory into profiles/<tag>_* files and profiles/pmc_summary.json.
+"""Turn one config directory of a tools/profile.sh run into profiles/<tag>_c<cfg>_* and profiles/pmc_c<cfg>.json (the
+summary bench.py reads; it carries the hash of the kernel sources it was taken from and bench.py refuses it otherwise).
 
-usage: tools/pmc_summary.py gpurun_out/prof_<tag> <tag> [kernel-substring]
+usage: tools/pmc_summary.py gpurun_out/prof_<tag> <tag> <cfg>          cfg = 2 | 3 | 4 | 5m | 5e
 """
 import collections
 import csv
+import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
-src, tag = sys.argv[1], sys.argv[2]
-kern = sys.argv[3] if len(sys.argv) > 3 else "vk_sweep_kernel<1u>"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dst = os.path.join(ROOT, "profiles")
-os.makedirs(dst, exist_ok=True)
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (csrc_hash only)
 
-shutil.copy(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+src_root, tag, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
+src = os.path.join(src_root, f"c{cfg}")
+KERNELS = {"2": ["vk_sweep_kernel<1u>"], "3": ["vk_sweep_kernel<0u>"], "4": ["vk_sweep_kernel<3u>"],
+           "5m": ["vk_multibit_kernel", "vk_sweep_kernel<100u>"], "5e": ["vk_electrum_kernel", "vk_sweep_kernel<100u>"]}[cfg]
+dst = os.path.join(ROOT, "profiles")
+
+
+def find(pattern):
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+stats_csv = find("stats/**/*kernel_stats.csv")
+if stats_csv:
+    shutil.copy(stats_csv, os.path.join(dst, f"{tag}_c{cfg}_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "bench_stats.json")):
-    shutil.copy(os.path.join(src, "bench_stats.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+    shutil.copy(os.path.join(src, "bench_stats.json"), os.path.join(dst, f"{tag}_c{cfg}_bench_under_rocprof.json"))
+
+
+def bench_line(name):
+    p = os.path.join(src, name)
+    if not os.path.exists(p):
+        return None
+    for line in open(p):
+        if line.startswith("{"):
+            return json.loads(line)
+    return None
+
 
 counters = collections.defaultdict(float)
-launches = collections.defaultdict(set)
 meta = {}
-for d in sorted(os.listdir(src)):
-    f = os.path.join(src, d, "pmc_counter_collection.csv")
-    if not os.path.exists(f):
-        continue
+per_kernel_valu = collections.defaultdict(float)
+for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if kern in r["Kernel_Name"]:
-            counters[r["Counter_Name"]] += float(r["Counter_Value"])
-            launches[r["Counter_Name"]].add(r["Dispatch_Id"])
-            meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
-per_launch = {k: v / max(1, len(launches[k])) for k, v in counters.items()}
+        for k in KERNELS:
+            if k in r["Kernel_Name"]:
+                counters[r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Counter_Name"] == "SQ_INSTS_VALU":
+                    per_kernel_valu[k] += float(r["Counter_Value"])
+                if k == KERNELS[0]:
+                    meta = {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
 
-avg_ns = max_ns = calls = None
-for r in csv.DictReader(open(os.path.join(src, "stats", "stats_kernel_stats.csv"))):
-    if kern in r["Name"]:
-        avg_ns, max_ns, calls = float(r["AverageNs"]), float(r["MaxNs"]), int(r["Calls"])
+kstats = {}
+if stats_csv:
+    for r in csv.DictReader(open(stats_csv)):
+        for k in KERNELS:
+            if k in r["Name"]:
+                kstats[k] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "max_ns": float(r["MaxNs"]), "total_ns": float(r["TotalDurationNs"])}
 
-keys_per_launch = 1 << 28  # the PMC passes run bench.py --steps 1 --warmup 0: one full 2^28-seed launch
+# every --pmc pass ran `bench.py --steps 1 --warmup 0`: the counters of one pass cover exactly the keys of that line
+sq = bench_line("bench_pmc_sq.json")
+keys = sq["roofline"]["keys_per_launch"] * 1 if sq else None
+keys_total = sq["keys_total"] if sq and "keys_total" in sq else None
+units_total = sq.get("units_total") if sq else None
+try:
+    git = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    git = None
 out = {
-    "source": f"profiles/{tag}_* (rocprofv3 --kernel-trace --stats and separate --pmc passes, tools/profile.sh)",
-    "kernel": kern,
-    "keys_per_launch": keys_per_launch,
-    "kernel_stats": {"calls": calls, "avg_ns_incl_short_warmup_launch": avg_ns, "ns_full_2p28_launch": max_ns},
-    "dispatch": meta,
-    "counters_per_launch": per_launch,
+    "source": f"profiles/{tag}_c{cfg}_* (rocprofv3 --kernel-trace --stats and separate --pmc passes of `bench.py --config {cfg}`, tools/profile.sh)",
+    "csrc_hash": bench.csrc_hash(), "git": git, "config": cfg, "kernels": KERNELS,
+    "keys_in_pmc_pass": keys_total, "units_in_pmc_pass": units_total,
+    "kernel_stats": kstats, "dispatch": meta, "counters_per_pass": dict(counters),
 }
-if "SQ_INSTS_VALU" in per_launch:
-    out["valu_insts_per_key"] = per_launch["SQ_INSTS_VALU"] / (keys_per_launch / 64)
-if "GRBM_GUI_ACTIVE" in per_launch and "SQ_INSTS_VALU" in per_launch:
-    cycles = per_launch["GRBM_GUI_ACTIVE"] / 8  # the counter is summed over the 8 XCDs
-    out["gpu_cycles_per_launch"] = cycles
-    out["effective_clock_ghz"] = cycles / (max_ns * 1e-9) / 1e9
-    # issue cost: a VALU wave-instruction holds its SIMD 2 cycles (simple VOP1/VOP2) or 4 (VOP3, carries,
-    # multiplier) -- profiles/r01_ubench_valu_rates.txt; 1024 SIMDs on the chip
-    out["cycles_per_valu_inst_per_simd"] = cycles * 1024 / per_launch["SQ_INSTS_VALU"]
-if "FETCH_SIZE" in per_launch and "WRITE_SIZE" in per_launch:
-    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of the
-    # bytes of a wide (16 B/lane) coalesced stream; the table gathers here are 4 x dwordx4 per lane over one 64-byte
-    # entry (not a contiguous wave-wide stream), so the raw and the x2 figure are both kept.
-    out["hbm_fetch_bytes_raw"] = per_launch["FETCH_SIZE"] * 1024
-    out["hbm_write_bytes"] = per_launch["WRITE_SIZE"] * 1024
-    out["hbm_bytes_per_launch"] = out["hbm_fetch_bytes_raw"] + out["hbm_write_bytes"]
-    out["hbm_bytes_per_launch_fetch_x2"] = 2 * out["hbm_fetch_bytes_raw"] + out["hbm_write_bytes"]
-    out["hbm_bytes_per_key_raw"] = out["hbm_bytes_per_launch"] / keys_per_launch
-    out["hbm_gbps_raw"] = out["hbm_bytes_per_launch"] / (max_ns * 1e-9) / 1e9
-json.dump(out, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
-json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+if "SQ_INSTS_VALU" in counters and keys_total:
+    out["valu_insts_per_key"] = counters["SQ_INSTS_VALU"] / (keys_total / 64)
+    out["valu_insts_per_key_by_kernel"] = {k: v / (keys_total / 64) for k, v in per_kernel_valu.items()}
+    if units_total and units_total != keys_total:
+        out["valu_insts_per_input"] = counters["SQ_INSTS_VALU"] / (units_total / 64)
+if "GRBM_GUI_ACTIVE" in counters and "SQ_INSTS_VALU" in counters and kstats:
+    mem = bench_line("bench_pmc_mem.json")
+    cycles = counters["GRBM_GUI_ACTIVE"] / 8  # the counter is summed over the 8 XCDs
+    kernel_s = (mem["roofline"]["kernel_ms_per_launch"] * 1e-3 * max(1, round(mem["keys_total"] / mem["roofline"]["keys_per_launch"]))) if mem and "keys_total" in mem else None
+    out["gpu_cycles_per_pass"] = cycles
+    if kernel_s:
+        out["effective_clock_ghz"] = cycles / kernel_s / 1e9
+    out["cycles_per_valu_inst_per_simd"] = cycles * 1024 / counters["SQ_INSTS_VALU"]
+if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters and keys_total:
+    fetch, write = counters["FETCH_SIZE"] * 1024, counters["WRITE_SIZE"] * 1024
+    out["hbm_fetch_bytes_raw"] = fetch
+    out["hbm_write_bytes"] = write
+    out["hbm_bytes_per_launch"] = fetch + write
+    out["hbm_bytes_per_key_raw"] = (fetch + write) / keys_total
+    cal_path = os.path.join(dst, "fetch_calibration.json")
+    if os.path.exists(cal_path):
+        cal = json.load(open(cal_path))["patterns"]
+        # FETCH_SIZE tallies requests at 64 B: the coalesced workspace reads (160 B/key, 128-B requests) show up at 1/s of their
+        # bytes, the random table / probe reads at 1/g.  With the workspace stream taken at its algorithmic volume:
+        s, g = cal["calib_stream"]["factor"], cal["calib_gather_lds"]["factor"]
+        stream = 160.0 * keys_total
+        gathers = g * max(0.0, fetch - stream / s)
+        algo_gather = (int(sq["config"]["windows"]) * 64 + 32) * keys_total
+        out["fetch_calibration"] = {"stream_factor": s, "gather_factor": g, "assumed_stream_read_bytes": stream,
+                                    "gather_read_bytes_calibrated": gathers, "algorithmic_gather_bytes": algo_gather,
+                                    "gather_overfetch_ratio": gathers / algo_gather}
+        out["hbm_bytes_per_launch_calibrated"] = gathers + stream + write
+        out["hbm_bytes_per_key_calibrated"] = out["hbm_bytes_per_launch_calibrated"] / keys_total
+json.dump(out, open(os.path.join(dst, f"{tag}_c{cfg}_pmc_summary.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, f"pmc_c{cfg}.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
