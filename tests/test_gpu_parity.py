@@ -347,8 +347,10 @@ def test_electrum_strings_and_scan_keys(eng, vko):
     import vuke_amd
     with pytest.raises(vuke_amd.VkError):
         eng.sweep(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), 0, 10)          # string transform: not a range sweep
-    with pytest.raises(vuke_amd.VkError):
-        eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), [b"a" * 65])
+    # an over-long seed no longer fails the batch (the reference never aborts on an input): no keys, a warning for the all-hex one
+    assert eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), [b"a" * 65]) == [[None] * 20]
+    assert eng.last_warning().startswith("warning: 1 input string(s) longer than the device limit")
+    assert eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), [b"x" * 65]) == [[None] * 20] and eng.last_warning() == ""
 
 
 def test_multibit_chain(eng, vko):
@@ -402,7 +404,7 @@ def test_scan_strings_fused_path(eng, vko):
     cannot parse, src/transform/electrum.rs:49-52)."""
     from vuke_amd import _ffi as ffi
     rnd = random.Random(77)
-    lines = [("pass%05d" % rnd.randrange(10**5)).encode() for _ in range(3000)] + [b"", b"x" * 300, b"correct horse battery staple"]
+    lines = [("pass%05d" % v).encode() for v in rnd.sample(range(10**5), 3000)] + [b"", b"x" * 300, b"correct horse battery staple"]  # distinct lines
     for spec, ospec in ((ffi.spec(ffi.T_SHA256), vko.spec(vko.T_SHA256)), (ffi.spec(ffi.T_SHA256_CHAIN), vko.spec(vko.T_SHA256_CHAIN))):
         rows = eng.transform_strings(spec, lines)
         flat = [(i, s, k) for i, r in enumerate(rows) for s, k in enumerate(r) if k is not None]
