@@ -445,10 +445,102 @@ def gen_sub3():
     return "".join(L)
 
 
+def gen_reduce_flags():
+    """fe_reduce16_flags: the reduction with NO precondition test in the instruction stream.  Every place where the short
+    form can lose a carry -- the eight multiply-adds t[8+i] * 977 + (t[8+i] : t[i]) (overflow of 64 bits: one product in
+    2^22), the carry out of limb 8 of their sum, the multiply-add s8 * 977 + (s8 : s0) that folds limb 8, and the carry out
+    of limb 2 of the fold (one in 2^31) -- writes its carry-out to an SGPR pair; the pairs are OR-ed on the scalar unit
+    (no VALU cycles; each OR sits a statement behind the VALU instruction that produced its operand) and returned.  A
+    non-zero result (any lane of the wave) means: recompute this product exactly (fe_mul_exact / fe_sqr_exact); zero means r
+    is the exact weakly reduced residue.  19 VALU instructions against 32 for fe_reduce16: the v_max3 tree, the separate
+    s8 * 977 product and limbs 3..7 of the fold's carry chain are gone."""
+    L = []
+    L.append("// r = t_lo + t_hi * (2^32 + 977) when the return value is 0; otherwise some lane lost a carry: recompute exactly\n")
+    L.append("VK_DEV vk_carry fe_reduce16_flags(fe &r, const u32 t[16])\n{\n")
+    L.append("    u64 v[8];\n#pragma unroll\n    for (int i = 0; i < 8; i++) v[i] = ((u64)t[8 + i] << 32) | t[i];\n")
+    L.append("    vk_carry k0, k1, k2, k3, k4, k5, k6, k7, ka, kb, kc, kd, ovf;\n")
+    # statement A: mads 0..3, carry-outs k0..k3
+    a = Asm()
+    for i in range(4):
+        a.out("+v", f"v[{i}]")
+    for i in range(4):
+        a.out("=&s", f"k{i}")
+    for i in range(4):
+        a.inp("v", f"t[{8 + i}]")
+    a.inp("s", "VK_PC0")
+    for i in range(4):
+        a.ins_("v_mad_u64_u32 {}, {}, {}, {}, {}", f"v[{i}]", f"k{i}", f"t[{8 + i}]", "VK_PC0", f"v[{i}]")
+    L.append(a.render())
+    # statement B: mads 4..7, carry-outs k4..k7; then the (by now finished) k0..k3 are OR-ed into ka
+    a = Asm()
+    a.clob = ["vcc", "scc"]
+    for i in range(4, 8):
+        a.out("+v", f"v[{i}]")
+    for i in range(4, 8):
+        a.out("=&s", f"k{i}")
+    a.out("=&s", "ka")
+    for i in range(4, 8):
+        a.inp("v", f"t[{8 + i}]")
+    a.inp("s", "VK_PC0")
+    for i in range(4):
+        a.inp("s", f"k{i}")
+    for i in range(4, 8):
+        a.ins_("v_mad_u64_u32 {}, {}, {}, {}, {}", f"v[{i}]", f"k{i}", f"t[{8 + i}]", "VK_PC0", f"v[{i}]")
+    a.ins_("s_or_b64 {}, {}, {}", "ka", "k0", "k1")
+    a.ins_("s_or_b64 {}, {}, {}", "ka", "ka", "k2")
+    a.ins_("s_or_b64 {}, {}, {}", "ka", "ka", "k3")
+    L.append(a.render())
+    L.append("    u32 lo[8], hi[8], s[9];\n#pragma unroll\n    for (int i = 0; i < 8; i++) {\n        lo[i] = (u32)v[i];\n        hi[i] = (u32)(v[i] >> 32);\n    }\n")
+    # chain: s1..s8, carry out of limb 8 -> kb; k4..k7 join ka behind it
+    a = Asm()
+    a.clob = ["vcc", "scc"]
+    for j in range(1, 9):
+        a.out("=&v", f"s[{j}]")
+    a.out("=&s", "kb")
+    a.out("+s", "ka")
+    for j in range(1, 8):
+        a.inp("v", f"lo[{j}]")
+    for j in range(8):
+        a.inp("v", f"hi[{j}]")
+    for i in range(4, 8):
+        a.inp("s", f"k{i}")
+    a.ins_("v_add_co_u32 {}, vcc, {}, {}", "s[1]", "lo[1]", "hi[0]")
+    for j in range(2, 8):
+        a.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", f"s[{j}]", f"lo[{j}]", f"hi[{j - 1}]")
+    a.ins_("v_addc_co_u32 {}, {}, 0, {}, vcc", "s[8]", "kb", "hi[7]")
+    for i in range(4, 8):
+        a.ins_("s_or_b64 {}, {}, {}", "ka", "ka", f"k{i}")
+    L.append(a.render())
+    # fold limb 8 with one multiply-add: f = s8 * 977 + (s8 : s0)
+    L.append("    u64 f = ((u64)s[8] << 32) | lo[0];\n")
+    L.append('    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(f), "=&s"(kc) : "v"(s[8]), "s"(VK_PC0));\n')
+    L.append("    const u32 fl = (u32)f, fh = (u32)(f >> 32);\n")
+    # r1 = s1 + f.hi, r2 = s2 + carry; the carry out of limb 2 is the last flag
+    a = Asm()
+    a.clob = ["vcc", "scc"]
+    a.out("=&v", "r.v[1]")
+    a.out("=&v", "r.v[2]")
+    a.out("=&s", "kd")
+    a.out("=&s", "ovf")
+    a.inp("v", "s[1]")
+    a.inp("v", "s[2]")
+    a.inp("v", "fh")
+    for x in ("ka", "kb", "kc"):
+        a.inp("s", x)
+    a.ins_("v_add_co_u32 {}, vcc, {}, {}", "r.v[1]", "s[1]", "fh")
+    a.ins_("v_addc_co_u32 {}, {}, 0, {}, vcc", "r.v[2]", "kd", "s[2]")
+    a.ins_("s_or_b64 {}, {}, {}", "ovf", "ka", "kb")
+    a.ins_("s_or_b64 {}, {}, {}", "ovf", "ovf", "kc")
+    a.ins_("s_or_b64 {}, {}, {}", "ovf", "ovf", "kd")
+    L.append(a.render())
+    L.append("    r.v[0] = fl;\n#pragma unroll\n    for (int i = 3; i < 8; i++) r.v[i] = s[i];\n    return ovf;\n}\n\n")
+    return "".join(L)
+
+
 def main():
     hdr = "// GENERATED by tools/gen_field.py -- do not edit.  Column kernels of the 256-bit multiply / square\n"
     hdr += "// on v_mad_u64_u32 (see the scheme in vk_field.cuh).\n#pragma once\n\n"
-    txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_sqr_tail() + gen_addsub() + gen_sub3() + gen_reduce() + gen_reduce_fast()
+    txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_sqr_tail() + gen_addsub() + gen_sub3() + gen_reduce() + gen_reduce_fast() + gen_reduce_flags()
     open(OUT, "w").write(txt)
     print("wrote", OUT, len(txt.splitlines()), "lines")
 

@@ -3,8 +3,11 @@
 # translation units next to the engine (six hipcc jobs in parallel), then linked.
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
-out="$here/../lib"
-obj="$here/build"
+# VK_OUT / VK_OBJ: build a variant next to the shipped library (same-box A/B through VUKE_HIP_LIB, tools/ab.sh):
+#   VK_EXTRA_FLAGS="-DVK_REDUCE_FLAGS=0" VK_OUT=vuke_amd/lib/variants/libvuke_hip_base.so VK_OBJ=/tmp/vk_base bash build.sh
+outfile="${VK_OUT:-$here/../lib/libvuke_hip.so}"
+out="$(dirname "$outfile")"
+obj="${VK_OBJ:-$here/build}"
 mkdir -p "$out" "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # -pragma-unroll-threshold: the SHA-512 round loops (2 x 80 rounds in one body) must unroll completely so
@@ -16,5 +19,5 @@ for g in 0 1 2 3 4; do
     "$HIPCC" $FLAGS -DVK_SWEEP_GROUP=$g -c -o "$obj/vk_sweep_g$g.o" "$here/vk_sweep_tu.hip" & pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out/libvuke_hip.so" "$obj/vk_engine.o" "$obj"/vk_sweep_g[0-4].o
-echo "built $out/libvuke_hip.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$outfile" "$obj/vk_engine.o" "$obj"/vk_sweep_g[0-4].o
+echo "built $outfile"

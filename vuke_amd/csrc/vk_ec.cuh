@@ -1,11 +1,13 @@
 // vk_ec.cuh -- secp256k1 group operations for gfx950 lanes.
 //
-// Fixed-base k*G with a precomputed table of (d * 2^(W*w)) * G affine points that lives in
-// HBM and is served from L2 / Infinity Cache (W=16: 16 windows x 65536 entries x 64 B =
-// 64 MiB).  One lane owns one key: ceil(256/W) table gathers and mixed Jacobian+affine
-// additions, no doublings.  Why no special cases are needed in ecmult_table(): with k
-// normalised to [1, n) the accumulator after windows 0..w-1 is s*G with s < 2^(W*w), and the
-// addend is t*G with 2^(W*w) <= t <= k < n, so s != t and s + t = k' <= k < n (s != -t).
+// Fixed-base k*G with a precomputed table of (d * 2^off_w) * G affine points that lives in HBM (vk_win_desc below:
+// uniform W-bit windows -- library default W = 24, 11 windows, 11.8 GB -- or the 9 signed-digit windows of the bench
+// geometry, 4 x 29 + 5 x 28 bits, 120 GB of the 288 GB part).  One lane owns one key: one 64-byte table gather per
+// window and windows - 1 point additions, no doublings.  The sweep uses ecmult_table_lds_xyzz (XYZZ accumulator, entries
+// fetched by lane quads straight into LDS); ecmult_table / ecmult_table_coop / ecmult_table_lds are the Jacobian forms
+// kept for the small kernels and as A/B references.  Why no special cases are needed in any of them: with k normalised
+// to [1, n) the accumulator after windows 0..w-1 is s*G with |s| < 2^off_w, and the addend is t*G with |t| >= 2^off_w,
+// so s != +-t and |s + t| < n.
 //
 // Stands in for libsecp256k1's ecmult_gen reached from src/derive.rs:97 (reference).
 #pragma once

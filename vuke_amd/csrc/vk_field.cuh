@@ -169,18 +169,79 @@ VK_DEV void fe_ripple_sub(fe &r, int from, vk_carry mask)
 
 #include "vk_field_gen.cuh" // fe_mul_cols, fe_sqr_cols, merge_eo (generated by tools/gen_field.py)
 
+// How the 16-limb product is reduced (tools/gen_field.py):
+//   1  fe_reduce16_flags: 19 VALU instructions, no precondition test; every carry the short form can lose is flagged in an
+//      SGPR pair, OR-ed on the scalar unit; a flagged wave (about one multiply in 10^4) recomputes the product exactly
+//   0  fe_reduce16: v_max3 test of the high limbs up front, 32 VALU instructions (round 1)
+#ifndef VK_REDUCE_FLAGS
+#define VK_REDUCE_FLAGS 1
+#endif
+#ifndef VK_TIMING_ONLY_NO_RECOMPUTE
+#define VK_TIMING_ONLY_NO_RECOMPUTE 0 /* 1 = experiment: flags ignored (wrong results one product in 10^4); never shipped */
+#endif
+
+// exact product / square for the flagged case: same columns and merge, the three-chain reduction that has no preconditions.
+// Real calls (one copy per translation unit) so that the rare path costs the hot path a compare and a branch only.
+__device__ __noinline__ fe fe_mul_exact(fe a, fe b)
+{
+    fe r;
+    u64 acc[15];
+    u32 top = fe_mul_cols(acc, a, b);
+    u32 t[16];
+    merge_eo(t, acc, top);
+    fe_reduce16_slow(r, t);
+    return r;
+}
+__device__ __noinline__ fe fe_sqr_exact(fe a)
+{
+    fe r;
+    u64 acc[15];
+    u32 top = fe_sqr_cols(acc, a);
+    u32 od[16];
+    merge_eo(od, acc, top);
+    u32 t[16];
+    fe_sqr_tail(t, od, a);
+    fe_reduce16_slow(r, t);
+    return r;
+}
+
 VK_DEV void fe_mul(fe &r, const fe &a, const fe &b)
 {
+#if VK_REDUCE_FLAGS
+    const fe a0 = a, b0 = b; // r may alias an operand: the recomputation needs the values the product was taken of
+    u64 acc[15];
+    u32 top = fe_mul_cols(acc, a0, b0);
+    u32 t[16];
+    merge_eo(t, acc, top);
+    const vk_carry lost = fe_reduce16_flags(r, t);
+#if !VK_TIMING_ONLY_NO_RECOMPUTE
+    if (__builtin_expect(lost != 0, 0)) r = fe_mul_exact(a0, b0);
+#endif
+#else
     u64 acc[15];
     u32 top = fe_mul_cols(acc, a, b);
     u32 t[16];
     merge_eo(t, acc, top);
     fe_reduce16(r, t);
+#endif
 }
 
 // r = a^2: the 28 off-diagonal products in E/O columns, doubled while merging, plus the diagonal
 VK_DEV void fe_sqr(fe &r, const fe &a)
 {
+#if VK_REDUCE_FLAGS
+    const fe a0 = a;
+    u64 acc[15];
+    u32 top = fe_sqr_cols(acc, a0);
+    u32 od[16];
+    merge_eo(od, acc, top); // off-diagonal sum < 2^511
+    u32 t[16];
+    fe_sqr_tail(t, od, a0); // t = 2 * od + sum a_i^2 2^(64 i)
+    const vk_carry lost = fe_reduce16_flags(r, t);
+#if !VK_TIMING_ONLY_NO_RECOMPUTE
+    if (__builtin_expect(lost != 0, 0)) r = fe_sqr_exact(a0);
+#endif
+#else
     u64 acc[15];
     u32 top = fe_sqr_cols(acc, a);
     u32 od[16];
@@ -188,6 +249,7 @@ VK_DEV void fe_sqr(fe &r, const fe &a)
     u32 t[16];
     fe_sqr_tail(t, od, a); // t = 2 * od + sum a_i^2 2^(64 i)
     fe_reduce16(r, t);
+#endif
 }
 
 VK_DEV void fe_sqr_n(fe &r, const fe &a, int n)

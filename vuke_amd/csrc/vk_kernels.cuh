@@ -1,17 +1,20 @@
 // vk_kernels.cuh -- the fused sweep kernel: seed -> key -> k*G -> hash160 -> probe, on gfx950.
 //
 // Shape of one workgroup tile (256 lanes, B = R * slots items per lane; tiles come from an atomic counter):
-//   pass 1  for each item: transform -> normalise -> ecmult_table -> Jacobian (X, Y, Z);
-//           running product c_b = Z_0..Z_b; (X, Y, Z, c_b) parked in the workgroup's own slice of an HBM
-//           workspace laid out [item][quad][lane] so every access is a 16-byte-per-lane coalesced line.
-//   invert  one field inversion of c_{B-1} per lane (Montgomery's trick: 3 multiplies per key
-//           instead of a 255-squaring inversion per key).
-//   pass 2  walk the items backwards: zinv_b = inv * c_{b-1}; inv *= Z_b; affine (x, y);
-//           SHA-256 + RIPEMD-160 of the SEC1 encoding(s); digest fold; open-address probe of
-//           the target table; hit record / generate-mode record.
-// LDS holds only the tile index, no cross-lane traffic in the loop, no MFMA: the path is integer-VALU bound; the
-// only memory streams are the table gathers (64 B per window, random over the whole HBM table),
-// the workspace (256 B per key) and one 32-byte probe line per hash160.
+//   pass 1  for each item: transform -> normalise -> ecmult_table_lds_xyzz: the first two table entries are added in affine
+//           form (4M + 2S), every later window adds its affine entry to an accumulator in XYZZ coordinates
+//           (X, Y, ZZ, ZZZ: 8M + 2S); the entries arrive through the wave's LDS landing slot (global_load_lds_dwordx4,
+//           four lanes fetch one 64-byte entry).  Parked per item in the workgroup's own slice of an HBM workspace laid out
+//           [item][quad][lane] (every access a 16-byte-per-lane coalesced line): X*ZZ^2, Y, e = ZZZ and the running
+//           product c_b = e_0..e_b.
+//   invert  one field inversion of c_{B-1} per lane (Montgomery's trick: 3 multiplies per key instead of a 255-squaring
+//           inversion per key); fe_inv_val is a real call with its operand and result in registers.
+//   pass 2  walk the items backwards: w_b = inv * c_{b-1} = 1 / e_b; inv *= e_b; y = Y * w, x = (X*ZZ^2) * w^2;
+//           SHA-256 + RIPEMD-160 of the SEC1 encoding(s); digest fold; open-address probe of the target table; hit
+//           record / generate-mode record.  e and c of the next item are requested one item ahead.
+// LDS: the tile index and one 4 160-byte landing slot per wave.  No MFMA: the path is integer-VALU bound; the memory
+// streams are the table gathers (64 B per window, random over the whole HBM table), the workspace (128 B written,
+// 160 B read per key) and one 32-byte probe slot per hash160.  No scratch: every field element lives in VGPRs.
 //
 // Replaces the closure body of RangeSource::process (reference src/source/range.rs:42-70):
 // Transform::apply_batch -> KeyDeriver::derive -> Matcher::check -> counters.
@@ -34,6 +37,9 @@
 // 1: the sweep's accumulator in XYZZ coordinates (vk_ec.cuh; needs VK_COOP_GATHER 2), 0: Jacobian
 #ifndef VK_XYZZ
 #define VK_XYZZ (VK_COOP_GATHER == 2)
+#endif
+#ifndef VK_PASS2_PREFETCH
+#define VK_PASS2_PREFETCH 1 /* 1: pass 2 requests e and c of the next item one iteration ahead */
 #endif
 #ifndef VK_SWEEP_WAVES
 #define VK_SWEEP_WAVES 2 /* minimum waves per SIMD the sweep kernel is register-budgeted for */
@@ -256,6 +262,13 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
         fe inv;
         fe_inv(inv, c);
         // ---------------------------------------------------------------- pass 2
+#if VK_PASS2_PREFETCH
+        // e and the running product of the item before it are what the two multiplies at the top of the body wait for:
+        // they are requested one item ahead (16 registers), X and Y at the top of the body (needed two multiplies later)
+        fe nz, ncp;
+        work_load(nz, wk + (u64)(B - 1) * 8 * nth + 4 * nth, nth);
+        if (B > 1) work_load(ncp, wk + (u64)(B - 2) * 8 * nth + 6 * nth, nth);
+#endif
 #pragma unroll 1
         for (u32 bb = B; bb > 0; bb--) {
             const u32 b = bb - 1;
@@ -270,6 +283,18 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
             fe zinv;
             work_load(P.x, it, nth);
             work_load(P.y, it + 2 * nth, nth);
+#if VK_PASS2_PREFETCH
+            P.z = nz;
+            const fe cp = ncp;
+            if (b > 0) {
+                work_load(nz, it - 4 * nth, nth);                 // e of item b-1
+                if (b > 1) work_load(ncp, it - 10 * nth, nth);    // c of item b-2
+                fe_mul(zinv, inv, cp);
+                fe_mul(inv, inv, P.z);
+            } else {
+                zinv = inv;
+            }
+#else
             work_load(P.z, it + 4 * nth, nth);
             if (b > 0) {
                 fe cp;
@@ -279,6 +304,7 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
             } else {
                 zinv = inv;
             }
+#endif
             u32 nz = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) nz |= P.x.v[i] | P.y.v[i];
