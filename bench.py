@@ -320,8 +320,8 @@ def main():
     # table geometry of the flagship run: 9 signed-digit windows (120 GB of the 288 GB HBM, 8 point additions per key),
     # 256 keys per lane per field inversion, 2 resident workgroups per CU.  --layout 0 --window-bits 24 is the library
     # default (11.8 GB, 10 additions).
-    ap.add_argument("--layout", type=int, default=1)
-    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--layout", type=int, default=None)
+    ap.add_argument("--window-bits", type=int, default=None)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--blocks-per-cu", type=int, default=2)
     args = ap.parse_args()
@@ -329,6 +329,17 @@ def main():
         args.steps = {"2": 16, "3": 3, "4": 8, "5m": 10, "5e": 3}[args.config]
     if args.strong and args.config != "2":
         raise SystemExit("bench.py: --strong is defined for --config 2")
+    world_hint = args.emulate_gpus or int(os.environ.get("WORLD_SIZE", "1"))
+    if args.layout is None and args.window_bits is None:
+        if args.strong:
+            # ONE 2^32 sweep end to end: allocating and building the 120 GB table costs 0.4-5 s (hipMalloc of 120 GB varies
+            # that much between boxes), more than it saves; by measured wall time (profiles/r02_strong_geometry.txt) the
+            # 43 GB W=26 table wins on one GPU and the 11.8 GB W=24 table from two GPUs up
+            args.layout, args.window_bits = 0, (26 if world_hint == 1 else 24)
+        else:
+            args.layout, args.window_bits = 1, 0   # sustained throughput: 9 signed windows, 120 GB
+    args.layout = args.layout or 0
+    args.window_bits = args.window_bits or 0
 
     import torch
     import torch.distributed as dist

@@ -408,7 +408,7 @@ def test_scan_strings_fused_path(eng, vko):
     for spec, ospec in ((ffi.spec(ffi.T_SHA256), vko.spec(vko.T_SHA256)), (ffi.spec(ffi.T_SHA256_CHAIN), vko.spec(vko.T_SHA256_CHAIN))):
         rows = eng.transform_strings(spec, lines)
         flat = [(i, s, k) for i, r in enumerate(rows) for s, k in enumerate(r) if k is not None]
-        picks = [flat[7], flat[len(flat) // 2], flat[-1]]
+        picks = [flat[7], flat[len(flat) // 2 + 3], flat[-1]]  # (not slot 20 of a chain: indexed:le:0 and indexed:be:0 are the same key)
         tg = [bytes(vko.derive(k).h160_c if j != 1 else vko.derive(k).h160_u) for j, (_, _, k) in enumerate(picks)]
         eng.targets_set(tg, [ffi.TARGET_P2PKH] * 3)
         st, hits = eng.scan_strings(spec, lines)
@@ -750,3 +750,15 @@ def test_bitimage_chain(eng, vko):
     with pytest.raises(vuke_amd.VkError):
         eng.bitimage_keys(ents[:1], [b"x" * 257], [0], 1)
     assert eng.bitimage_keys([], [b""], [0], 1) == []
+
+
+def test_large_chain_depth_keeps_the_workspace_bounded(eng, vko):
+    """with sha256_chain the keys per input grow with the depth (8 x depth); the batch-inversion workspace is
+    one slice of that many items per workgroup.  The engine launches fewer workgroups instead of allocating > 16 GiB, and
+    the results do not depend on it."""
+    from vuke_amd import _ffi as ffi
+    depth = 1024
+    sp, osp = ffi.spec(ffi.T_SHA256_CHAIN, ffi.VARIANT_ALL, 0, depth), vko.spec(vko.T_SHA256_CHAIN, vko.VARIANT_ALL, 0, depth)
+    st, _ = eng.sweep(sp, 4000, 4000 + 299, flags=1)
+    ost, _ = vko.sweep(osp, 4000, 4000 + 299, flags=1 | vko.F_BATCHED, nthreads=8)
+    assert st["keys"] == ost["keys"] == 300 * 8 * depth and st["digest"] == ost["digest"]

@@ -393,3 +393,29 @@ def test_page_compressors_round_trip(host):
             assert pa.Codec("lz4_raw").decompress(out.raw[8:n], decompressed_size=len(data)).to_pybytes() == data, len(data)
         if len(data) >= 1000 and len(set(data)) <= 8:
             assert n < len(data) * 2 // 3   # random binary digits: one bit of information per byte, matches of 4 and more only
+
+
+def test_line_reader_follows_rust_lines_and_trim(host, tmp_path):
+    """ADVICE r1: BufRead::lines() + filter_map(Result::ok) drops a line that is not UTF-8, str::trim() strips Unicode
+    White_Space (src/source/wordlist.rs:24-30); Matcher::load propagates the UTF-8 error (src/matcher.rs:50-56)."""
+    out = C.create_string_buffer(256)
+
+    def f(raw):
+        n = host.vkh_line_filter(raw, len(raw), out, 256)
+        return None if n == -2 else out.raw[:n]
+
+    assert f(b"  hello \t\r") == b"hello"
+    assert f("\u00a0pass\u3000word\u2003\u0085".encode()) == "pass\u3000word".encode()      # NBSP, ideographic space, em space, NEL
+    assert f("\u2028\u2029\u202f\u205f\u1680".encode()) == b""
+    assert f("caf\u00e9 ".encode()) == "caf\u00e9".encode()
+    assert f(b"caf\xe9") is None and f(b"\xc0\xaf") is None and f(b"\xed\xa0\x80") is None and f(b"\xf4\x90\x80\x80") is None  # latin-1, overlong, surrogate, > U+10FFFF
+    assert f("\u200bzero-width is not White_Space\u200b".encode()) == "\u200bzero-width is not White_Space\u200b".encode()
+    for s in ("", "a", "\u00e9\u00a0", "\U0001F600 x \u2009"):
+        assert f(s.encode()) == s.strip(" \t\n\r\x0b\x0c\x85\xa0\u1680\u2000\u2001\u2002\u2003\u2004\u2005\u2006\u2007\u2008\u2009\u200a\u2028\u2029\u202f\u205f\u3000").encode()
+    # Matcher::load: NBSP-padded address is trimmed, a latin-1 line is an error
+    t = tmp_path / "t.txt"
+    t.write_bytes("\u00a01BgGZ9tcN4rm9KBzDn7KprQz87SZ26SAMH\u00a0\n# c\n".encode())
+    h160, kind, n = C.create_string_buffer(20 * 4), C.create_string_buffer(4), C.c_size_t()
+    assert host.vkh_matcher_load(str(t).encode(), h160, kind, 4, C.byref(n)) == 1 and n.value == 1
+    t.write_bytes(b"1BgGZ9tcN4rm9KBzDn7KprQz87SZ26SAMH\ncaf\xe9\n")
+    assert host.vkh_matcher_load(str(t).encode(), h160, kind, 4, C.byref(n)) == -1

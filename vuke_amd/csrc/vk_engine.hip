@@ -413,15 +413,37 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     const u32 B = R * slots;
     const u64 tile_inputs = (u64)VK_BLOCK * R;
     const u64 ntiles = span / tile_inputs + 1;
-    const u32 grid = (u32)std::min<u64>(ntiles, max_grid);
+    u32 grid = (u32)std::min<u64>(ntiles, max_grid);
     const bool tree = e->algo == VK_ALGO_TREE && (kind == VK_T_MILKSAD || kind == VK_T_RAWKEYS || kind == VK_T_LCG);
-    const size_t need = (size_t)grid * VK_BLOCK * B * (tree ? 19 : 8) * sizeof(uint4);
+    // The workspace is one slice of B items per resident workgroup.  B >= slots, and slots grows with the chain depth of
+    // sha256_chain (up to 8 * 4096): keep the allocation under 16 GiB by launching fewer workgroups (the tile counter hands
+    // the same tiles to a smaller grid), and say what is wrong if even one workgroup does not fit.
+    const size_t per_wg = (size_t)VK_BLOCK * B * (tree ? 19 : 8) * sizeof(uint4);
+    const size_t work_cap = (size_t)16 << 30;
+    if ((size_t)grid * per_wg > work_cap && (size_t)grid * per_wg > e->work_bytes) {
+        const size_t fit = std::max(work_cap, e->work_bytes) / per_wg;
+        if (fit == 0) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "batch-inversion workspace for %u keys per input needs %.1f GiB per workgroup (chain depth too large for one device pass)",
+                     slots, (double)per_wg / (double)((size_t)1 << 30));
+            return fail(e, VK_E_NOMEM, msg);
+        }
+        grid = (u32)std::min<size_t>(grid, fit);
+    }
+    const size_t need = (size_t)grid * per_wg;
     if (need > e->work_bytes) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         if (e->work) HIPCHK(e, hipFree(e->work));
         e->work = nullptr;
         e->work_bytes = 0;
-        HIPCHK(e, hipMalloc(&e->work, need));
+        hipError_t mc = hipMalloc(&e->work, need);
+        if (mc != hipSuccess) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "hipMalloc of the %.2f GiB batch-inversion workspace (%u workgroups x %u keys per lane) failed: %s", (double)need / (double)((size_t)1 << 30),
+                     grid, B, hipGetErrorString(mc));
+            e->work = nullptr;
+            return fail(e, VK_E_NOMEM, msg);
+        }
         e->work_bytes = need;
     }
     if (io.hit_cap > e->d_hits_cap) {

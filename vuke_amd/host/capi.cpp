@@ -50,6 +50,15 @@ int vkh_segwit_decode(const char *hrp, const char *addr, int *ver, uint8_t *out,
 }
 void vkh_sha256(const uint8_t *p, size_t n, uint8_t out[32]) { sha256(p, n, out); }
 
+// what the wordlist / stdin sources make of one raw line: -2 = dropped (not UTF-8), else the length of the trimmed text in out
+int vkh_line_filter(const char *line, size_t n, char *out, size_t cap)
+{
+    if (!utf8_valid(line, n)) return -2;
+    const char *a = line, *e = line + n;
+    trim_unicode(a, e);
+    return put(std::string(a, e), out, cap);
+}
+
 // Assemble a DerivedKey from device outputs and render it: mode 0 compact line, 1 verbose block,
 // 2 HIT block (kind = address type), 3 "decimal|binary|bit_length|hamming|leading_zeros|wif_c|wif_u|c|u|w"
 int vkh_render(const uint8_t key[32], const uint8_t hc[20], const uint8_t hu[20], int mode, int kind, const char *source,

@@ -10,6 +10,64 @@
 
 namespace vuke {
 
+bool utf8_valid(const char *p, size_t n)
+{ // the well-formed byte sequences of Unicode table 3-7 (what core::str::from_utf8 accepts)
+    const unsigned char *s = (const unsigned char *)p, *e = s + n;
+    while (s < e) {
+        const unsigned char c = *s;
+        if (c < 0x80) { s++; continue; }
+        int len;
+        unsigned char lo = 0x80, hi = 0xBF;
+        if (c >= 0xC2 && c <= 0xDF) len = 1;
+        else if (c == 0xE0) { len = 2; lo = 0xA0; }
+        else if ((c >= 0xE1 && c <= 0xEC) || c == 0xEE || c == 0xEF) len = 2;
+        else if (c == 0xED) { len = 2; hi = 0x9F; }
+        else if (c == 0xF0) { len = 3; lo = 0x90; }
+        else if (c >= 0xF1 && c <= 0xF3) len = 3;
+        else if (c == 0xF4) { len = 3; hi = 0x8F; }
+        else return false;
+        if (e - s <= len) return false;
+        if (s[1] < lo || s[1] > hi) return false;
+        for (int k = 2; k <= len; k++)
+            if (s[k] < 0x80 || s[k] > 0xBF) return false;
+        s += len + 1;
+    }
+    return true;
+}
+
+// length of a White_Space code point starting at p (0 if none); input is valid UTF-8
+static int ws_at(const unsigned char *p, const unsigned char *e)
+{
+    const unsigned char c = p[0];
+    if (c == ' ' || (c >= 9 && c <= 13)) return 1;
+    if (c == 0xC2 && e - p >= 2 && (p[1] == 0x85 || p[1] == 0xA0)) return 2;
+    if (e - p >= 3) {
+        if (c == 0xE1 && p[1] == 0x9A && p[2] == 0x80) return 3;                                   // U+1680
+        if (c == 0xE2 && p[1] == 0x80 && ((p[2] >= 0x80 && p[2] <= 0x8A) || p[2] == 0xA8 || p[2] == 0xA9 || p[2] == 0xAF)) return 3; // U+2000-200A, 2028, 2029, 202F
+        if (c == 0xE2 && p[1] == 0x81 && p[2] == 0x9F) return 3;                                   // U+205F
+        if (c == 0xE3 && p[1] == 0x80 && p[2] == 0x80) return 3;                                   // U+3000
+    }
+    return 0;
+}
+
+void trim_unicode(const char *&a, const char *&e)
+{
+    const unsigned char *s = (const unsigned char *)a, *t = (const unsigned char *)e;
+    for (int k; s < t && (k = ws_at(s, t)) != 0;) s += k;
+    for (;;) {
+        if (t == s) break;
+        // step back one code point
+        const unsigned char *q = t - 1;
+        while (q > s && (*q & 0xC0) == 0x80) q--;
+        const int k = ws_at(q, t);
+        if (k == 0 || q + k != t) break;
+        t = q;
+    }
+    a = (const char *)s;
+    e = (const char *)t;
+}
+
+
 namespace {
 inline uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 

@@ -108,24 +108,17 @@ const char *address_type_str(AddressType t)
     }
 }
 
-static std::string trim(const std::string &s)
-{ // str::trim(): ASCII + the whitespace that can occur in address files
-    size_t a = 0, b = s.size();
-    auto ws = [](unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; };
-    while (a < b && ws((unsigned char)s[a])) a++;
-    while (b > a && ws((unsigned char)s[b - 1])) b--;
-    return s.substr(a, b - a);
-}
-
 Matcher Matcher::load(const std::string &path)
 {
-    std::ifstream f(path);
+    std::ifstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("cannot open targets file: " + path);
     Matcher m;
     std::string line;
-    while (std::getline(f, line)) {
-        std::string s = trim(line);
-        if (!s.empty() && s[0] != '#') m.targets_.insert(s);
+    while (std::getline(f, line)) { // BufRead::lines: split at '\n'; `line?` propagates the error of a line that is not UTF-8
+        if (!utf8_valid(line.data(), line.size())) throw std::runtime_error("stream did not contain valid UTF-8");
+        const char *a = line.data(), *e = a + line.size();
+        trim_unicode(a, e); // str::trim()
+        if (a != e && *a != '#') m.targets_.insert(std::string(a, e));
     }
     return m;
 }

@@ -130,11 +130,10 @@ public:
     }
 
 private:
-    static bool ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; }
     void push(LineBatch &b, const char *a, const char *e)
     {
-        while (a < e && ws((unsigned char)*a)) a++;
-        while (e > a && ws((unsigned char)e[-1])) e--;
+        if (!utf8_valid(a, (size_t)(e - a))) return; // .lines().filter_map(Result::ok): a line that is not UTF-8 is dropped
+        trim_unicode(a, e);                           // str::trim(): Unicode White_Space, not only ASCII
         if (a == e) return;
         b.data.insert(b.data.end(), a, e);
         b.offs.push_back((uint32_t)b.data.size());
@@ -176,10 +175,14 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
         std::vector<vk_hit> hits;
         std::vector<DerivedKey> hit_derived;
     };
+    // one vk_transform_strings / vk_scan_strings call carries at most 2^28 keys: size the batch by keys, not by lines
+    uint32_t max_slots = 1;
+    for (const Transform &t : transforms) max_slots = std::max(max_slots, t.string_slots());
+    const size_t max_lines = std::max<size_t>(1, std::min<size_t>(1u << 20, (1u << 27) / max_slots));
     bool more = true;
     while (more) {
         b.clear();
-        more = reader.fill(b, 1u << 20, 256u << 20); // a million passphrases per batch
+        more = reader.fill(b, max_lines, 256u << 20); // a million passphrases per batch, fewer when one line makes many keys
         const size_t n = b.n();
         if (n == 0) continue;
         st.inputs_processed += n;
@@ -434,7 +437,11 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
         }
         check_rc(engine_, vk_targets_set(engine_, nullptr, nullptr, 0));
     } else {
-        const uint64_t chunk = 1ull << 16; // inputs per vk_generate call (host: 72 B raw + ~1 KB of text per key)
+        // inputs per vk_generate call, sized by KEYS (host: 72 B raw + ~1 KB of text per key): at most ~2^18 keys per call
+        // whatever the slot count (sha256_chain with a large --chain-depth has thousands of slots per input)
+        uint32_t max_slots = 1;
+        for (const Transform &t : transforms) max_slots = std::max(max_slots, t.takes_strings() ? t.string_slots() : t.slots());
+        const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(1ull << 16, (1ull << 18) / max_slots));
         for (uint64_t lo = start;; lo += chunk) {
             const uint64_t hi = (end - lo < chunk - 1) ? end : lo + chunk - 1;
             for (const Transform &t : transforms) {

@@ -24,6 +24,13 @@
 
 namespace vuke {
 
+// Rust string semantics the reference's line readers rely on (BufRead::lines + str::trim, src/source/wordlist.rs:24-30,
+// src/source/stdin.rs:45-50, src/matcher.rs:50-56): a line must be valid UTF-8, and trim() strips the Unicode White_Space
+// code points (U+0009-000D, U+0020, U+0085, U+00A0, U+1680, U+2000-200A, U+2028, U+2029, U+202F, U+205F, U+3000).
+bool utf8_valid(const char *p, size_t n);
+void trim_unicode(const char *&a, const char *&e);
+
+
 using Key = std::array<uint8_t, 32>;
 
 // ---------------------------------------------------------------- text codecs (codecs.cpp)
