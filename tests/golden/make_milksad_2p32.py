@@ -25,7 +25,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import vko  # noqa: E402
 
-PARTIAL = os.path.join(HERE, "milksad_2p32.partial.jsonl")
+PARTIAL = os.environ.get("VK_PARTIAL", os.path.join(HERE, "milksad_2p32.partial.jsonl"))  # several machines may share the work
 OUT = os.path.join(HERE, "milksad_2p32.json")
 PLANTED = os.path.join(HERE, "milksad_planted.json")
 WLOG2 = 24
