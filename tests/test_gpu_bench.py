@@ -74,8 +74,10 @@ def test_strong_mode_reports_wall_time():
 
 
 def test_two_ranks_share_the_device():
-    """The N > 1 path end to end (RCCL all-reduce of the counters, digest gather, disjoint blocks) with both ranks on GPU 0."""
-    o = run_bench("--share-device", "0", "--layout", "0", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", nproc=2)
+    """The N > 1 path end to end (launcher, rank-major disjoint blocks, counter all-reduce, max-over-ranks time, digest
+    gather) with both ranks on GPU 0.  RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the rehearsal's
+    collectives run over gloo; on the driver's 8-GPU node the same code path runs with backend nccl, one rank per GPU."""
+    o = run_bench("--share-device", "0", "--backend", "gloo", "--layout", "0", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", nproc=2)
     check_contract(o, n_gpus=2)
     from vuke_amd import workloads as wl
     planted = wl.c2_planted_seeds()
@@ -83,5 +85,5 @@ def test_two_ranks_share_the_device():
     assert o["digests_checked_against_oracle"] == 6
     g = wl.load_golden("milksad_2p32.json")
     assert o["digest"] == wl.hexd(wl.fold_digests([wl.unhexd(d) for d in g["block_digests"][:4]]))
-    o = run_bench("--share-device", "0", "--layout", "0", "--strong", "--emulate-gpus", "8", "--no-cpu-baseline", nproc=2)
+    o = run_bench("--share-device", "0", "--backend", "gloo", "--layout", "0", "--strong", "--emulate-gpus", "8", "--no-cpu-baseline", nproc=2)
     assert o["strong"]["blocks_per_rank"] == 2 and o["n_gpus"] == 2
