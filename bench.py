@@ -164,6 +164,8 @@ class Sha256Scan(Workload):
             k.append(kind)
         eng.targets_set(h, k)
         self.pseeds = [p["seed"] for p in self.fx["planted"]]
+        full = wl.load_golden("bench_c3_full.json")   # the oracle over the config's whole input range, block by block
+        self.block_digest = {b["lo"]: wl.unhexd(b["digest"]) for b in full["blocks"]} if full else {}
 
     def warmup(self, eng):
         w = self.fx["warmup"]
@@ -176,6 +178,8 @@ class Sha256Scan(Workload):
         b = self.rank * self.args.steps + s
         lo, hi = b * n, (b + 1) * n - 1
         st, _ = eng.sweep(self.spec, lo, hi, flags=3, hit_cap=2048)
+        if lo in self.block_digest:
+            self.check_digest(st["digest"], self.block_digest[lo])
         st["expected"] = sum(1 for p in self.pseeds if lo <= p <= hi)
         st["units"] = st["keys"]
         return st
@@ -199,6 +203,8 @@ class LcgAll(Workload):
         eng.targets_set([bytes.fromhex(p["h160"]) for p in pl], [ffi.TARGET_P2PKH] * len(pl))
         self.pseeds = [p["seed"] for p in pl]
         self.nblocks = wl.C4_SEEDS // wl.C4_STEP_SEEDS
+        full = wl.load_golden("bench_c4_full.json")   # the oracle over all four variants x the whole 2^31 seed space
+        self.block_digest = {b["lo"]: (b["keys"], wl.unhexd(b["digest"])) for b in full["blocks"]} if full else {}
 
     def warmup(self, eng):
         w = self.fx["warmup"]
@@ -211,6 +217,9 @@ class LcgAll(Workload):
         b = (self.rank * self.args.steps + s) % self.nblocks
         lo, hi = b * n, (b + 1) * n - 1
         st, _ = eng.sweep(self.spec, lo, hi, flags=1, hit_cap=2048)
+        if lo in self.block_digest:
+            keys, dg = self.block_digest[lo]
+            self.check_digest((st["keys"],) + tuple(st["digest"]), (keys,) + dg)
         st["expected"] = sum(1 for p in self.pseeds if lo <= p <= hi)
         st["units"] = st["keys"]
         return st
@@ -398,7 +407,7 @@ def main():
         w.warmup(eng)
 
     units = keys_done = matches = expected = launches = 0
-    kernel_s = 0.0
+    kernel_s = clock_acc = 0.0
     digest = (0, 0, 0, 0)
     sync()
     t0 = time.perf_counter()
@@ -409,6 +418,7 @@ def main():
         matches += st["matches"]
         expected += st["expected"]
         kernel_s += st["kernel_seconds"]
+        clock_acc += st.get("shader_clock_ghz", 0.0) * st["kernel_seconds"]
         launches += st["launches"]
         digest = wl.fold_digests([digest, st["digest"]])
     sync()
@@ -442,8 +452,14 @@ def main():
                 "unit": "T lane-ops/s = executed VALU wave-instructions (rocprofv3 SQ_INSTS_VALU) x 64 lanes / s; peak = the 16-lanes-per-clock "
                         "class (v_mad_u64_u32, carry adds, v_add3, v_alignbit): 256 CU x 4 SIMD x 16 lanes x 2.4 GHz",
                 "kernel": w.kernel, "kernel_ms_per_launch": 1e3 * per_launch_s, "keys_per_launch": per_launch_keys}
+        clock_ghz = clock_acc / kernel_s if kernel_s else 0.0
+        if clock_ghz:
+            roof["shader_clock_ghz"] = clock_ghz  # live: s_memtime / s_memrealtime of workgroup 0 of every sweep launch of this run
         if pmc:
             per_key = pmc["valu_insts_per_key"]
+            if clock_ghz:
+                # the same fraction against the peak at the clock the part actually held (DVFS lowers it under this load)
+                roof["frac_at_measured_clock"] = per_key * rate / (PEAK_INT32 * clock_ghz / 2.4)
             roof.update({"achieved": per_key * rate / 1e12, "frac": per_key * rate / PEAK_INT32,
                          "valu_insts_per_key": per_key, "pmc_source": pmc["source"], "pmc_csrc_hash": pmc["csrc_hash"], "pmc_git": pmc.get("git"),
                          "cycles_per_valu_inst_per_simd": pmc.get("cycles_per_valu_inst_per_simd"),

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 1
+#define VK_ABI_VERSION 2 /* 2: vk_sweep_stats.shader_clock_ghz, vk_scan_strings */
 
 /* error codes */
 #define VK_OK 0
@@ -110,6 +110,8 @@ typedef struct vk_sweep_stats {
     double kernel_seconds; /* hipEvent time of the device work on the engine's stream */
     uint32_t launches;     /* kernel launches this call made */
     uint32_t _pad;
+    double shader_clock_ghz; /* shader clock the sweep kernels ran at: s_memtime cycles / s_memrealtime of workgroup 0, over the
+                                call's launches (the part lowers its clock under this load; 0 if no sweep kernel ran) */
 } vk_sweep_stats;
 
 typedef struct vk_engine vk_engine;

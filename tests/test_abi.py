@@ -28,14 +28,14 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/vuke_hip.h but not exported"
     assert sorted(_ffi.EXPORTS) == names
-    assert L.vk_abi_version() == 1
+    assert L.vk_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     import ctypes as C
     from vuke_amd import _ffi
     assert C.sizeof(_ffi.Hit) == 72
-    assert C.sizeof(_ffi.SweepStats) == 80
+    assert C.sizeof(_ffi.SweepStats) == 88
     assert C.sizeof(_ffi.TransformSpec) == 16
     assert C.sizeof(_ffi.EngineOpts) == 32
 

@@ -206,3 +206,22 @@ def test_config5_key_chains_at_size(eng, vko):
     eng.targets_set([], [])
     assert st["matches"] == len(chosen) and [h["index"] for h in hits] == [20 * i + 7 for i in chosen]
     assert all(h["addr_kind"] == 1 for h in hits)
+
+
+def test_configs_3_and_4_at_their_stated_sizes_against_the_oracle(eng):
+    """BASELINE config 3 (sha256 transform, 3 keys per input, both hash160s, inputs 0 .. 3*2^25-1 >= the stated 10^8) and
+    config 4 (all four LCG variants x the WHOLE 2^31 seed space, 4*2^31 - 1 keys) block by block against the CPU oracle's
+    counters and digests (tests/golden/bench_c3_full.json, bench_c4_full.json; make_c34_full.py, ~9 x 10^9 oracle keys)."""
+    from vuke_amd import _ffi as ffi
+    from vuke_amd import workloads as wl
+    for name, spec in (("bench_c3_full.json", ffi.spec(ffi.T_SHA256)), ("bench_c4_full.json", ffi.spec(ffi.T_LCG))):
+        g = wl.load_golden(name)
+        assert g is not None, f"tests/golden/{name} is missing: run tests/golden/make_c34_full.py"
+        parts, keys = [], 0
+        for b in g["blocks"]:
+            st, _ = eng.sweep(spec, b["lo"], b["hi"], flags=g["flags"])
+            assert (st["inputs"], st["keys"], wl.hexd(st["digest"])) == (b["inputs"], b["keys"], b["digest"]), (name, b["lo"])
+            parts.append(st["digest"])
+            keys += st["keys"]
+        assert keys == g["keys"] and wl.hexd(wl.fold_digests(parts)) == g["digest"]
+    assert wl.load_golden("bench_c4_full.json")["keys"] == 4 * 2**31 - 1   # minstd skips seed 2^31 - 1 (src/lcg.rs:77-83)

@@ -31,7 +31,8 @@ class Hit(C.Structure):
 
 class SweepStats(C.Structure):
     _fields_ = [("inputs", C.c_uint64), ("keys", C.c_uint64), ("matches", C.c_uint64), ("hits_dropped", C.c_uint64),
-                ("digest", C.c_uint64 * 4), ("kernel_seconds", C.c_double), ("launches", C.c_uint32), ("_pad", C.c_uint32)]
+                ("digest", C.c_uint64 * 4), ("kernel_seconds", C.c_double), ("launches", C.c_uint32), ("_pad", C.c_uint32),
+                ("shader_clock_ghz", C.c_double)]
 
 
 class EngineOpts(C.Structure):
@@ -159,7 +160,7 @@ class Engine:
               for h in hits[:n]]
         hl.sort(key=lambda h: (h["seed"], h["sub_index"]))
         return dict(inputs=st.inputs, keys=st.keys, matches=st.matches, hits_dropped=st.hits_dropped,
-                    digest=tuple(st.digest), kernel_seconds=st.kernel_seconds, launches=st.launches), hl
+                    digest=tuple(st.digest), kernel_seconds=st.kernel_seconds, launches=st.launches, shader_clock_ghz=st.shader_clock_ghz), hl
 
     def generate(self, spec, lo, hi, flags=F_COMPRESSED | F_UNCOMPRESSED):
         slots = self._L.vk_slots_per_input(C.byref(spec))
@@ -278,7 +279,7 @@ class Engine:
                      for h in hits[:m]), key=lambda h: (h["index"], h["sub_index"]))
         warn = (self._L.vk_last_error(self._e) or b"").decode()
         return dict(inputs=st.inputs, keys=st.keys, matches=st.matches, hits_dropped=st.hits_dropped, digest=tuple(st.digest),
-                    kernel_seconds=st.kernel_seconds, launches=st.launches, warning=warn), hl
+                    kernel_seconds=st.kernel_seconds, launches=st.launches, shader_clock_ghz=st.shader_clock_ghz, warning=warn), hl
 
     def last_warning(self):
         return (self._L.vk_last_error(self._e) or b"").decode()

@@ -260,7 +260,7 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     }
     HIPCHK(e, hipEventCreate(&e->ev0));
     HIPCHK(e, hipEventCreate(&e->ev1));
-    HIPCHK(e, hipMalloc(&e->d_stats, 8 * sizeof(u64)));
+    HIPCHK(e, hipMalloc(&e->d_stats, 12 * sizeof(u64)));
     if (e->blocks_per_cu == 0) {
         int occ = 0;
         HIPCHK(e, vk_sweep_occupancy(&occ));
@@ -454,7 +454,7 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
         HIPCHK(e, hipMalloc(&e->d_hits, io.hit_cap * sizeof(vk_hit_dev)));
         e->d_hits_cap = io.hit_cap;
     }
-    HIPCHK(e, hipMemsetAsync(e->d_stats, 0, 8 * sizeof(u64), e->stream));
+    HIPCHK(e, hipMemsetAsync(e->d_stats, 0, 12 * sizeof(u64), e->stream));
 
     vk_sweep_params p;
     memset(&p, 0, sizeof p);
@@ -490,7 +490,7 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
         return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
-    u64 hs[8];
+    u64 hs[12];
     HIPCHK(e, hipMemcpyAsync(hs, e->d_stats, sizeof hs, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     float ms = 0.f;
@@ -509,6 +509,10 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     st->digest[1] ^= hs[4];
     st->digest[2] ^= hs[5];
     st->digest[3] += hs[6];
+    if (hs[9]) { // shader clock over the launches of this call, weighted by their length (s_memrealtime ticks at 100 MHz)
+        const double ghz = (double)hs[8] / ((double)hs[9] / 100e6) / 1e9, w = (double)ms * 1e-3;
+        st->shader_clock_ghz = (st->shader_clock_ghz * st->kernel_seconds + ghz * w) / (st->kernel_seconds + w);
+    }
     st->kernel_seconds += (double)ms * 1e-3;
     st->launches += 1;
     return VK_OK;

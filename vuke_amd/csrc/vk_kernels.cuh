@@ -69,7 +69,7 @@ struct vk_sweep_params {
     const uint4 *table;
     const uint4 *tgt;  // slots of 2 x uint4: {h0,h1,h2,h3}, {h4, kindbits, 0, 0}
     vk_hit_dev *hits;
-    u64 *stats;        // [0] keys [1] matches [2] hit cursor [3..6] digest [7] tile counter
+    u64 *stats;        // [0] keys [1] matches [2] hit cursor [3..6] digest [7] tile counter [8] shader cycles [9] 100 MHz ticks of workgroup 0
     uint4 *work;       // batch-inversion workspace
     const u32 *in_keys;   // VK_T_RAWKEYS: n x 8 words (raw bytes)
     const unsigned char *in_valid; // VK_T_RAWKEYS: optional n flags, 0 = no key in this slot (vk_scan_strings)
@@ -153,6 +153,9 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
 {
     const u32 tid = threadIdx.x;
     const u32 B = p.R * p.slots;
+    // workgroup 0 is resident for the whole launch (tiles come from a counter): its shader-cycle and constant-rate counters
+    // give the clock the part actually held under this load
+    const u64 clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     u64 n_keys = 0, n_match = 0;
     u64 dg[4] = {0, 0, 0, 0};
     // workspace of this workgroup: item b, quad q, lane t at wk[(b*8 + q) * VK_BLOCK] -- one contiguous
@@ -394,6 +397,10 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
     dg[1] = wave_xor(dg[1]);
     dg[2] = wave_xor(dg[2]);
     dg[3] = wave_add(dg[3]);
+    if (blockIdx.x == 0 && tid == 0) {
+        p.stats[8] = __builtin_amdgcn_s_memtime() - clk0;
+        p.stats[9] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
     if ((tid & 63) == 0) {
         atomicAdd((unsigned long long *)&p.stats[0], (unsigned long long)n_keys);
         atomicAdd((unsigned long long *)&p.stats[1], (unsigned long long)n_match);
