@@ -269,6 +269,8 @@ class Chains(Workload):
         self.warm_packed = ffi.pack_strings(lines[:nwarm])
         self.expected = sum(1 for p in pl if a <= p["input"] < b)
         self.planted_here = [(p["input"] - a, p["sub_index"]) for p in pl if a <= p["input"] < b]
+        full = wl.load_golden("bench_c5_full.json")   # the oracle over all 100 000 inputs (one rank sweeps them all only at N = 1)
+        self.full = full[self.which] if (full and self.world == 1) else None
 
     def warmup(self, eng):
         st, _ = eng.scan_strings(self.spec, None, flags=3, hit_cap=2048, packed=self.warm_packed)
@@ -279,6 +281,8 @@ class Chains(Workload):
     def step(self, eng, s):
         st, hits = eng.scan_strings(self.spec, None, flags=3, hit_cap=2048, packed=self.packed)
         st["expected"] = self.expected
+        if self.full:
+            self.check_digest((st["keys"],) + tuple(st["digest"]), (self.full["keys"],) + self.wl.unhexd(self.full["digest"]))
         if [(h["index"], h["sub_index"]) for h in hits] != self.planted_here:
             st["matches"] = -1  # wrong hit set: fails the parity check below
         st["units"] = st["inputs"]
@@ -307,7 +311,7 @@ def reduce_counters(dist, dev, counters, elapsed):
     import torch
     tot = torch.tensor(list(counters), dtype=torch.int64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     return [int(x) for x in tot.tolist()], float(tmax.item())
@@ -326,6 +330,8 @@ def main():
     # rehearsal knobs (not used by the driver): run the N-rank path on a box with fewer GPUs than ranks
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal)")
     ap.add_argument("--share-device", type=int, default=-1, help="put every rank on this one GPU (rehearsal only)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run every collective even with one rank "
+                                                               "(exercises the RCCL call sequence of the N > 1 path on a one-GPU box)")
     # table geometry of the flagship run: 9 signed-digit windows (120 GB of the 288 GB HBM, 8 point additions per key),
     # 256 keys per lane per field inversion, 2 resident workgroups per CU.  --layout 0 --window-bits 24 is the library
     # default (11.8 GB, 10 additions).
@@ -358,8 +364,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_device >= 0:
         local_rank = args.share_device
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
@@ -379,7 +389,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -425,13 +435,13 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # counters: one tiny all-reduce over RCCL (the only collective on this path)
-    red_dev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")
+    red_dev = dev if (not use_dist or args.backend == "nccl") else torch.device("cpu")
     (total_units, total_keys, total_matches, total_expected, dg_checked, dg_bad), t = reduce_counters(
         dist, red_dev, [units, keys_done, matches, expected, w.digest_checked, w.digest_bad], elapsed)
     wall_s = time.perf_counter() - t_wall0
     # the digests of all ranks (XOR words and the wrapping sum): gathered, folded on rank 0
     all_digests = [digest]
-    if world > 1:
+    if use_dist:
         gathered = [None] * world
         dist.all_gather_object(gathered, [int(x) for x in digest])
         all_digests = [tuple(g) for g in gathered]
@@ -523,7 +533,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

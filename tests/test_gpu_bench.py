@@ -63,6 +63,11 @@ def test_other_baseline_configs_have_a_bench_line(cfg, steps, matches):
         assert o["matches"] == matches
     if cfg.startswith("5"):
         assert o["inputs_per_s"] > 1e4 and o["value"] == pytest.approx(20 * o["inputs_per_s"], rel=1e-3)
+        assert o["digests_checked_against_oracle"] == 2   # the warm-up inputs and the oracle's digest over all 100 000 inputs
+    if cfg == "3":
+        assert o["digests_checked_against_oracle"] == 2   # warm-up window + block 0 of the oracle's full-size golden
+    if cfg == "4":
+        assert o["digests_checked_against_oracle"] == 3   # warm-up window + blocks 0 and 1 of the oracle's 32-block golden
 
 
 def test_strong_mode_reports_wall_time():
@@ -87,3 +92,12 @@ def test_two_ranks_share_the_device():
     assert o["digest"] == wl.hexd(wl.fold_digests([wl.unhexd(d) for d in g["block_digests"][:4]]))
     o = run_bench("--share-device", "0", "--backend", "gloo", "--layout", "0", "--strong", "--emulate-gpus", "8", "--no-cpu-baseline", nproc=2)
     assert o["strong"]["blocks_per_rank"] == 2 and o["n_gpus"] == 2
+
+
+def test_rccl_call_sequence_with_one_rank():
+    """The collectives of the N > 1 path over RCCL itself (backend nccl: init with device_id, barrier, all_reduce SUM / MAX on
+    device tensors, all_gather_object, destroy) on the one GPU of the box, world size 1 -- the two-rank rehearsal above has to
+    use gloo because RCCL refuses two ranks on one device."""
+    o = run_bench("--force-dist", "--layout", "0", "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    check_contract(o)
+    assert o["n_gpus"] == 1 and o["matches"] == 65 and o["digests_checked_against_oracle"] == 2
