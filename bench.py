@@ -9,7 +9,7 @@ data-path collective; RCCL is used only to all-reduce counters after the timed r
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5m|5e] [--strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Other configs under the same contract (inputs in vuke_amd/workloads.py):
+Other configs under the same contract (inputs in bench_workloads.py):
   --config 3   scan --transform=sha256 vs 1 000 000 targets (both hash160s), step = 2^25 inputs (3 keys each)
   --config 4   all LCG variants, step = 2^26 seeds (4 keys each) of the 2^31 seed space, range-split over ranks
   --config 5m  100 000 synthetic MultiBit-HD mnemonics -> 20 keys each -> probe (vk_scan_strings), lines split over ranks
@@ -385,7 +385,7 @@ def main():
 
     import vuke_amd
     from vuke_amd import _ffi as ffi
-    from vuke_amd import workloads as wl
+    import bench_workloads as wl
 
     def sync():
         torch.cuda.synchronize()
@@ -542,7 +542,7 @@ def cpu_baseline(config):
     workload.  value = the leanest form (one k*G per key through 16-bit windows and a shared inversion + only the hash160s
     the config needs); ref_faithful = everything KeyDeriver::derive does per key."""
     from oracle import vko
-    from vuke_amd import workloads as wl
+    import bench_workloads as wl
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:

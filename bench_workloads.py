@@ -12,7 +12,7 @@ import json
 import os
 import struct
 
-GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
 MASK64 = 2**64 - 1
 
 

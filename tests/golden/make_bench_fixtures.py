@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generate tests/golden/bench_c3.json, bench_c4.json, bench_c5.json from the CPU oracle: the planted targets of
-BASELINE configs 3, 4 and 5 (inputs defined in vuke_amd/workloads.py) and, per config, the oracle's
+BASELINE configs 3, 4 and 5 (inputs defined in bench_workloads.py) and, per config, the oracle's
 counters and digest over the warm-up window bench.py sweeps before its timed steps -- so that every expected value
 bench.py and the -m gpu tests compare against comes from the oracle, never from the device.
 
@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import vko  # noqa: E402
-from vuke_amd import workloads as wl  # noqa: E402
+import bench_workloads as wl  # noqa: E402
 
 
 def stats(st):

@@ -19,7 +19,7 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import vko  # noqa: E402
-from vuke_amd import workloads as wl  # noqa: E402
+import bench_workloads as wl  # noqa: E402
 
 PDIR = os.environ.get("VK_PARTIAL_DIR", HERE)
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generate tests/golden/bench_c5_full.json: the CPU oracle over BASELINE config 5 at its stated size -- all 100 000 synthetic
-MultiBit-HD mnemonics and all 100 000 Electrum v1 seeds of vuke_amd/workloads.py, 20 keys each: key count and the digest of
+MultiBit-HD mnemonics and all 100 000 Electrum v1 seeds of bench_workloads.py, 20 keys each: key count and the digest of
 both hash160s of every key (what bench.py --config 5m / 5e sweeps in one step).  Minutes on 16 cores.
 
     python tests/golden/make_c5_full.py [--threads 16]
@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import vko  # noqa: E402
-from vuke_amd import workloads as wl  # noqa: E402
+import bench_workloads as wl  # noqa: E402
 
 
 def main():

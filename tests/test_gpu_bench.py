@@ -84,7 +84,7 @@ def test_two_ranks_share_the_device():
     collectives run over gloo; on the driver's 8-GPU node the same code path runs with backend nccl, one rank per GPU."""
     o = run_bench("--share-device", "0", "--backend", "gloo", "--layout", "0", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", nproc=2)
     check_contract(o, n_gpus=2)
-    from vuke_amd import workloads as wl
+    import bench_workloads as wl
     planted = wl.c2_planted_seeds()
     assert o["matches"] == sum(1 for p in planted if p < 4 << 28)          # ranks 0 and 1 sweep blocks 0,1 and 2,3
     assert o["digests_checked_against_oracle"] == 6

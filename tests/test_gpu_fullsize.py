@@ -27,7 +27,7 @@ def test_full_2p32_milksad_sweep_finds_every_planted_seed(eng):
     from vuke_amd import _ffi as ffi
     spec = ffi.spec(ffi.T_MILKSAD)
     # planted seeds, private keys and hash160s are the ORACLE's (tests/golden/milksad_planted.json), not the device's own
-    from vuke_amd import workloads as wl
+    import bench_workloads as wl
     pl = wl.load_golden("milksad_planted.json")["planted"]
     planted = [p["seed"] for p in pl]
     assert planted == wl.c2_planted_seeds()
@@ -58,7 +58,7 @@ def test_bench_geometry_full_2p32_sweep_against_the_oracles_golden():
     Reference behaviour: src/transform/milksad.rs:17-29, src/derive.rs:78-118, src/matcher.rs:72-98."""
     import vuke_amd
     from vuke_amd import _ffi as ffi
-    from vuke_amd import workloads as wl
+    import bench_workloads as wl
     g = wl.load_golden("milksad_2p32.json")
     assert g is not None, "tests/golden/milksad_2p32.json is missing: run tests/golden/make_milksad_2p32.py"
     pl = wl.load_golden("milksad_planted.json")["planted"]
@@ -213,7 +213,7 @@ def test_configs_3_and_4_at_their_stated_sizes_against_the_oracle(eng):
     config 4 (all four LCG variants x the WHOLE 2^31 seed space, 4*2^31 - 1 keys) block by block against the CPU oracle's
     counters and digests (tests/golden/bench_c3_full.json, bench_c4_full.json; make_c34_full.py, ~9 x 10^9 oracle keys)."""
     from vuke_amd import _ffi as ffi
-    from vuke_amd import workloads as wl
+    import bench_workloads as wl
     for name, spec in (("bench_c3_full.json", ffi.spec(ffi.T_SHA256)), ("bench_c4_full.json", ffi.spec(ffi.T_LCG))):
         g = wl.load_golden(name)
         assert g is not None, f"tests/golden/{name} is missing: run tests/golden/make_c34_full.py"

@@ -82,8 +82,8 @@ def test_strong_partition_is_one_disjoint_sweep():
 
 def test_bench_fixtures_are_consistent_with_the_workload_definitions():
     """The committed oracle fixtures (tests/golden/bench_c*.json, milksad_planted.json) describe exactly the inputs
-    vuke_amd/workloads.py generates: same planted seeds in the same order, same first synthetic input."""
-    from vuke_amd import workloads as wl
+    bench_workloads.py generates: same planted seeds in the same order, same first synthetic input."""
+    import bench_workloads as wl
     assert [p["seed"] for p in wl.load_golden("milksad_planted.json")["planted"]] == wl.c2_planted_seeds()
     c3 = wl.load_golden("bench_c3.json")
     assert [(p["seed"], p["sub_index"], p["addr_kind"]) for p in c3["planted"]] == wl.c3_planted()
@@ -98,7 +98,7 @@ def test_bench_fixtures_are_consistent_with_the_workload_definitions():
 
 def test_bench_fixture_spot_checks_against_the_oracle(vko):
     """A few entries of every bench fixture recomputed by the oracle (the generator is tests/golden/make_bench_fixtures.py)."""
-    from vuke_amd import workloads as wl
+    import bench_workloads as wl
     c3 = wl.load_golden("bench_c3.json")
     for p in c3["planted"][:5] + c3["planted"][-3:]:
         d = vko.derive(vko.transform_key(vko.spec(vko.T_SHA256), p["seed"], p["sub_index"]))
@@ -120,7 +120,7 @@ def test_bench_fixture_spot_checks_against_the_oracle(vko):
 def test_golden_2p32_file_is_self_consistent_when_present():
     """tests/golden/milksad_2p32.json (hours of oracle CPU): windows fold into blocks, blocks into the full digest, and
     the committed 2^20-window fixture agrees with it where they overlap only through the fold rule."""
-    from vuke_amd import workloads as wl
+    import bench_workloads as wl
     g = wl.load_golden("milksad_2p32.json")
     if g is None:
         pytest.skip("full-space golden not generated yet")

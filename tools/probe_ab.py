@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import vuke_amd
 from vuke_amd import _ffi as ffi
-from vuke_amd import workloads as wl
+import bench_workloads as wl
 algo = int(os.environ.get("VK_ALGO", "0"))
 batch = int(os.environ.get("VK_BATCH", "256"))
 e = vuke_amd.Engine(0, layout=int(os.environ.get("VK_LAYOUT", "1")), batch=batch, blocks_per_cu=int(os.environ.get("VK_BLOCKS", "2")), algo=algo)
