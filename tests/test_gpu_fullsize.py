@@ -225,3 +225,40 @@ def test_configs_3_and_4_at_their_stated_sizes_against_the_oracle(eng):
             keys += st["keys"]
         assert keys == g["keys"] and wl.hexd(wl.fold_digests(parts)) == g["digest"]
     assert wl.load_golden("bench_c4_full.json")["keys"] == 4 * 2**31 - 1   # minstd skips seed 2^31 - 1 (src/lcg.rs:77-83)
+
+
+def test_randomized_parity_on_the_bench_geometry(vko):
+    """the geometry the headline is quoted on (layout 1 = signed9 / 120 GB, batch 256, 2 workgroups per
+    CU) against the ORACLE in a driver-run test: random transform specs, ranges around every seed ceiling, flags -- the case
+    generator of tools/fuzz_parity.py -- plus a 2^22-seed Milksad soak.  Counters and digest must equal the oracle's."""
+    import os
+    import random
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+    rnd = random.Random(20261004)
+    threads = min(16, len(os.sched_getaffinity(0)))
+    e = vuke_amd.Engine(0, layout=1, batch=256, blocks_per_cu=2)
+    try:
+        edges = [0, 2**31 - 1, 2**31, 2**32 - 1, 2**32, 2**63, 2**64 - 1, 10**9, 10**18]
+        for c in range(160):
+            kind = rnd.choice([ffi.T_SHA256, ffi.T_MILKSAD, ffi.T_MT64, ffi.T_LCG, ffi.T_XORSHIFT, ffi.T_SHA256_CHAIN, ffi.T_DOUBLE_SHA256, ffi.T_MD5, ffi.T_DIRECT])
+            variant = rnd.choice([ffi.VARIANT_ALL, 0, 1, 2, 3]) if kind in (ffi.T_LCG, ffi.T_XORSHIFT, ffi.T_SHA256_CHAIN) else ffi.VARIANT_ALL
+            endian = rnd.randrange(2) if kind == ffi.T_LCG else 0
+            depth = rnd.choice([1, 2, 7, 10]) if kind == ffi.T_SHA256_CHAIN else 10
+            gs, osp = ffi.spec(kind, variant, endian, depth), vko.spec(kind, variant, endian, depth)
+            slots = vko.slots_per_input(osp)
+            n = rnd.choice([1, 2, 255, 256, 257, 1000, 65536, rnd.randrange(1, 1 << 17)])
+            n = max(1, min(n, (1 << 17) // slots))
+            centre = rnd.choice(edges + [rnd.getrandbits(rnd.randrange(1, 65))])
+            lo = max(0, min(centre - rnd.randrange(0, n + 1), 2**64 - n))
+            hi = lo + n - 1
+            flags = rnd.choice([1, 2, 3])
+            st, _ = e.sweep(gs, lo, hi, flags=flags)
+            ost, _ = vko.sweep(osp, lo, hi, flags=flags | vko.F_BATCHED, nthreads=threads)
+            assert (st["inputs"], st["keys"], st["digest"]) == (ost["inputs"], ost["keys"], ost["digest"]), (c, kind, variant, endian, depth, lo, hi, flags)
+        lo = 3_000_000_000
+        st, _ = e.sweep(ffi.spec(ffi.T_MILKSAD), lo, lo + 2**22 - 1, flags=3)
+        ost, _ = vko.sweep(vko.spec(vko.T_MILKSAD), lo, lo + 2**22 - 1, flags=3 | vko.F_BATCHED, nthreads=threads)
+        assert (st["keys"], st["digest"]) == (ost["keys"], ost["digest"]) and st["keys"] == 2**22
+    finally:
+        e.close()
