@@ -6,7 +6,11 @@ Scheme (see vk_field.cuh): product scanning; column k = i + j accumulates into t
 (limb k, limb k+1); the multiplier's carry-out is counted into cy[k] = limb k+2, which is where
 the next column of the same parity starts.  Each asm statement handles one even column and the
 following odd column, interleaved, so dependent multiplies are always 3 issue slots apart; the
-even column carries through vcc, the odd one through a scratch SGPR pair.
+even column carries through vcc, the odd one through a scratch SGPR pair.  A column that continues from the counter of the
+column two before it takes the pair (counter, 0) as the SOURCE addend of its first multiply-add -- the accumulator itself
+is a fresh early-clobber output -- so the compiler only has to put a zero next to the counter (one plain v_mov_b32) instead
+of copying a 64-bit pair into the tied accumulator (v_mov_b64, a 16-lane-class instruction, plus the s_nop the tied form
+drew after every statement): +1.3 % on the Milksad sweep, same-box (profiles/r02_kernel_experiments.txt).
 
 Operand discipline of every statement emitted here (audited in round 2, profiles/r02_short_fold_root_cause.txt): a
 statement of more than one instruction either early-clobbers its outputs ("=&v" / "=&s") or, where an operand is
@@ -29,7 +33,7 @@ def col_products_sqr(k):
     return [(i, k - i) for i in range(max(0, k - 7), min(k, 7) + 1) if i < k - i]
 
 
-def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, zero_o=False):
+def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, zero_o=False, start_e=None, start_o=None):
     """one asm statement: even column ke and odd column ke+1.  A column whose start value is zero takes the literal 0
     as the addend of its first multiply (no register to clear); the first carry of a column *sets* its counter
     (0 + 0 + carry), so the counters need no clearing either."""
@@ -45,11 +49,11 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, z
 
     have_e, have_o = bool(prods_e), bool(prods_o)
     if have_e:
-        out("=&v" if zero_e else "+v", f"acc[{ke}]")
+        out("=&v" if (zero_e or start_e) else "+v", f"acc[{ke}]")
         if len(prods_e) > 1:
             out("=&v", f"cy[{ke}]")
     if have_o:
-        out("=&v" if zero_o else "+v", f"acc[{ko}]")
+        out("=&v" if (zero_o or start_o) else "+v", f"acc[{ko}]")
         if len(prods_o) > 1:
             out("=&v", f"cy[{ko}]")
             out("=&s", "sc")
@@ -62,6 +66,10 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, z
     for n, nm in enumerate(used):
         idx[nm] = base + n
         ops_in.append(("v", f"{nm[0]}.v[{nm[1]}]"))
+    for st in (start_e, start_o):
+        if st:
+            idx[st] = len(ops_out) + len(ops_in)
+            ops_in.append(("v", st))
 
     def r(e):
         return f"%{idx[e]}"
@@ -71,12 +79,12 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, z
     for step in range(max(ne, no)):
         if step < ne:
             i, j = prods_e[step]
-            add = "0" if (zero_e and step == 0) else r(f'acc[{ke}]')
+            add = "0" if (zero_e and step == 0) else (r(start_e) if (start_e and step == 0) else r(f'acc[{ke}]'))
             body.append(f"v_mad_u64_u32 {r(f'acc[{ke}]')}, vcc, {r((a_name, i))}, {r((a_name if same else b_name, j))}, {add}")
         if step < no:
             i, j = prods_o[step]
             sd = r("sc") if no > 1 else "vcc"
-            add = "0" if (zero_o and step == 0) else r(f'acc[{ko}]')
+            add = "0" if (zero_o and step == 0) else (r(start_o) if (start_o and step == 0) else r(f'acc[{ko}]'))
             body.append(f"v_mad_u64_u32 {r(f'acc[{ko}]')}, {sd}, {r((a_name, i))}, {r((a_name if same else b_name, j))}, {add}")
         if step < ne and step > 0:
             prev = "0" if step == 1 else r(f'cy[{ke}]')
@@ -107,14 +115,19 @@ def gen_cols(name, prods_fn, same):
     has_cy = [len(prods_fn(k)) > 1 for k in range(15)]   # columns with one product cannot overflow
     for ke in range(0, 15, 2):
         pe, po = prods_fn(ke), (prods_fn(ke + 1) if ke + 1 < 15 else [])
-        zero = {}
+        zero, start = {}, {}
         for k in (ke, ke + 1):
             if k < 15:
                 zero[k] = not (k >= 2 and has_cy[k - 2])
-                if not (zero[k] and prods_fn(k)):
+                if not zero[k] and prods_fn(k):
+                    # the counter pair (cy, 0) is a SOURCE of the column's first multiply-add, not its tied accumulator
+                    L.append(f"    const u64 cz{k} = (u64)cy[{k - 2}];\n")
+                    start[k] = f"cz{k}"
+                elif not (zero[k] and prods_fn(k)):
                     L.append(f"    acc[{k}] = {'0ull' if zero[k] else '(u64)cy[%d]' % (k - 2)};\n")
         if pe or po:
-            emit_pair(L, ke, pe, po, "a", "b", same, zero_e=zero.get(ke, False), zero_o=zero.get(ke + 1, False))
+            emit_pair(L, ke, pe, po, "a", "b", same, zero_e=zero.get(ke, False), zero_o=zero.get(ke + 1, False),
+                      start_e=start.get(ke), start_o=start.get(ke + 1))
     L.append(f"    return {'cy[13]' if has_cy[13] else '0u'};\n}}\n\n")
     return "".join(L)
 
