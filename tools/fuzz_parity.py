@@ -31,7 +31,7 @@ for c in range(cases):
     flags = rnd.choice([1, 2, 3])
     e = rnd.choice(engines)
     st, _ = e.sweep(gs, lo, hi, flags=flags)
-    ost, _ = vko.sweep(os_, lo, hi, flags=flags, nthreads=threads)
+    ost, _ = vko.sweep(os_, lo, hi, flags=flags | (vko.F_BATCHED if c % 2 else 0), nthreads=threads)  # both oracle k*G paths
     ok = (st["inputs"], st["keys"], st["digest"]) == (ost["inputs"], ost["keys"], ost["digest"])
     bad += not ok
     if not ok or c % 10 == 9:
