@@ -262,3 +262,16 @@ def test_randomized_parity_on_the_bench_geometry(vko):
         assert (st["keys"], st["digest"]) == (ost["keys"], ost["digest"]) and st["keys"] == 2**22
     finally:
         e.close()
+
+
+def test_large_oracle_windows_of_every_other_transform(eng):
+    """One large oracle-swept window (16.8 M - 67 M keys, both hash160s) per transform kind that has no full-size golden of
+    its own: mt64, xorshift x4, sha256_chain (80 keys per input), double_sha256, md5, direct, lcg little-endian, armory --
+    around the seed ceilings where there is one (tests/golden/soak_windows.json, make_soak_windows.py: 3.7 x 10^8 oracle keys)."""
+    import bench_workloads as wl
+    from vuke_amd import _ffi as ffi
+    g = wl.load_golden("soak_windows.json")
+    assert g is not None and len(g["windows"]) == 8
+    for w in g["windows"]:
+        st, _ = eng.sweep(ffi.spec(*w["spec"]), w["lo"], w["hi"], flags=w["flags"])
+        assert (st["inputs"], st["keys"], wl.hexd(st["digest"])) == (w["inputs"], w["keys"], w["digest"]), w["name"]
