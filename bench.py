@@ -103,6 +103,7 @@ class Milksad(Workload):
         self.ffi, self.wl = ffi, wl
         self.spec = ffi.spec(ffi.T_MILKSAD)
         pl = wl.load_golden("milksad_planted.json")["planted"]
+        self.planted = pl
         self.pseeds = [p["seed"] for p in pl]
         eng.targets_set([bytes.fromhex(p["h160_c"]) for p in pl], [ffi.TARGET_P2PKH] * len(pl))
         g = wl.load_golden("milksad_2p32.json")
@@ -137,6 +138,9 @@ class Milksad(Workload):
         if self.block_digest:
             self.check_digest(st["digest"], self.block_digest[b])
         st["expected"] = sum(1 for p in self.pseeds if lo <= p <= hi)
+        want = [(p["seed"], p["privkey"], p["h160_c"]) for p in self.planted if lo <= p["seed"] <= hi]
+        if [(h["seed"], h["privkey"].hex(), h["h160"].hex()) for h in hits] != want:
+            st["matches"] = -1  # wrong hit records
         st["units"] = st["keys"]
         return st
 
@@ -177,10 +181,13 @@ class Sha256Scan(Workload):
         n = self.wl.C3_STEP_INPUTS
         b = self.rank * self.args.steps + s
         lo, hi = b * n, (b + 1) * n - 1
-        st, _ = eng.sweep(self.spec, lo, hi, flags=3, hit_cap=2048)
+        st, hits = eng.sweep(self.spec, lo, hi, flags=3, hit_cap=2048)
         if lo in self.block_digest:
             self.check_digest(st["digest"], self.block_digest[lo])
         st["expected"] = sum(1 for p in self.pseeds if lo <= p <= hi)
+        want = sorted((p["seed"], p["sub_index"], p["addr_kind"], p["privkey"], p["h160"]) for p in self.fx["planted"] if lo <= p["seed"] <= hi)
+        if [(h["seed"], h["sub_index"], h["addr_kind"], h["privkey"].hex(), h["h160"].hex()) for h in hits] != want:
+            st["matches"] = -1  # wrong hit records (seed, slot, address kind, key, hash160): fails the parity check
         st["units"] = st["keys"]
         return st
 
@@ -216,7 +223,10 @@ class LcgAll(Workload):
         n = self.wl.C4_STEP_SEEDS
         b = (self.rank * self.args.steps + s) % self.nblocks
         lo, hi = b * n, (b + 1) * n - 1
-        st, _ = eng.sweep(self.spec, lo, hi, flags=1, hit_cap=2048)
+        st, hits = eng.sweep(self.spec, lo, hi, flags=1, hit_cap=2048)
+        want = sorted((p["seed"], p["sub_index"], p["addr_kind"], p["privkey"], p["h160"]) for p in self.fx["planted"] if lo <= p["seed"] <= hi)
+        if [(h["seed"], h["sub_index"], h["addr_kind"], h["privkey"].hex(), h["h160"].hex()) for h in hits] != want:
+            st["matches"] = -1  # wrong hit records
         if lo in self.block_digest:
             keys, dg = self.block_digest[lo]
             self.check_digest((st["keys"],) + tuple(st["digest"]), (keys,) + dg)
