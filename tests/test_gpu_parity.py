@@ -31,7 +31,9 @@ def be(x):
     return x.to_bytes(32, "big")
 
 
-def test_field_ops(eng):
+def field_cases():
+    """Operands and expected results of the field-op checks, shared by the device test below and by the host emulation of the
+    generated code (tests/test_host_field.py): [(op, f)] and the operand lists a, b."""
     rnd = random.Random(11)
     vals = [0, 1, 2, P - 1, P - 2, P, P + 1, 2**256 - 1, 2**256 - 2, 2**255, 0x1000003D1, 2**256 - 0x1000003D1,
             2**224 - 1, (2**256 - 1) ^ (2**128 - 1)]
@@ -44,19 +46,22 @@ def test_field_ops(eng):
             2**224 - 1, 2**255, (2**32 - 491) << 224, (2**32 - 490) << 224, (2**32 - 489) << 224, (2**32 - 979) << 224, (2**32 - 978) << 224, P - 2, P - 1, P, P + 1, 2**256 - 2**64, 2**256 - 2**32 - 978, 2**256 - 2**32 - 977, 2**256 - 978, 2**256 - 977, 2**256 - 2, 2**256 - 1]
     a += [x for x in edge for _ in edge]
     b += [y for _ in edge for y in edge]
+    ops = [(0, lambda x, y: x * y % P), (3, lambda x, y: (x + y) % P), (4, lambda x, y: (x - y) % P),
+           (5, lambda x, y: (x - 3 * y) % P), (6, lambda x, y: (-x - y) % P), (7, lambda x, y: (-x - 3 * y) % P),  # fe_sub3 = a - b - 2c
+           # one case per aliasing form of the generated statements (result = first / second / both operands)
+           (8, lambda x, y: x * y % P), (9, lambda x, y: x * y % P), (10, lambda x, y: x * x % P), (11, lambda x, y: x * x % P),
+           (12, lambda x, y: 2 * x % P), (13, lambda x, y: (y - x) % P), (14, lambda x, y: -2 * x % P),
+           (15, lambda x, y: pow(x, 32, P) * y % P), (1, lambda x, y: x * x % P)]
+    return ops, a, b
+
+
+def test_field_ops(eng):
+    ops, a, b = field_cases()
     ab, bb = [be(x) for x in a], [be(x) for x in b]
-    for op, f in ((0, lambda x, y: x * y % P), (3, lambda x, y: (x + y) % P), (4, lambda x, y: (x - y) % P),
-                  (5, lambda x, y: (x - 3 * y) % P), (6, lambda x, y: (-x - y) % P), (7, lambda x, y: (-x - 3 * y) % P),  # fe_sub3 = a - b - 2c
-                  # one case per aliasing form of the generated statements (result = first / second / both operands)
-                  (8, lambda x, y: x * y % P), (9, lambda x, y: x * y % P), (10, lambda x, y: x * x % P), (11, lambda x, y: x * x % P),
-                  (12, lambda x, y: 2 * x % P), (13, lambda x, y: (y - x) % P), (14, lambda x, y: -2 * x % P),
-                  (15, lambda x, y: pow(x, 32, P) * y % P)):
+    for op, f in ops:
         got = eng.field_op(op, ab, bb)
         for x, y, g in zip(a, b, got):
             assert int.from_bytes(g, "big") == f(x, y), (op, hex(x), hex(y))
-    got = eng.field_op(1, ab)
-    for x, g in zip(a, got):
-        assert int.from_bytes(g, "big") == x * x % P
     nz = [x for x in a if x % P][:300]
     got = eng.field_op(2, [be(x) for x in nz])
     for x, g in zip(nz, got):

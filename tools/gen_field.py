@@ -22,7 +22,44 @@ The C++ callers may alias result and operands freely: results are written only b
 """
 import os
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vuke_amd", "csrc", "vk_field_gen.cuh")
+OUT_DIR = os.environ.get("VK_GEN_OUT_DIR", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vuke_amd", "csrc"))
+OUT = os.path.join(OUT_DIR, "vk_field_gen.cuh")
+OUT_HOST = os.path.join(OUT_DIR, "vk_field_gen_host.h")
+
+# ---- second backend: the same statements as plain C++ for one lane (VK_HOST_EMU).  Every asm statement the generator emits is
+# registered here with its operand tables; main() writes vk_field_gen_host.h = the gfx950 file with each statement replaced by
+# calls into a ten-instruction emulator (vk_field.cuh).  tests/test_host_field.py compiles the field layer that way with g++
+# and holds it to python integers on the edge operands of the GPU field test: the arithmetic of the generated code -- carry
+# accounting, flagged and exact paths, aliasing -- is checked on a machine without a GPU.  (Hardware hazards are not: those
+# are what the GPU tests and the coalescer lint are for.)
+HOST = {}
+EMU = {"v_mad_u64_u32": "emu_mad", "v_add_co_u32": "emu_add_co", "v_addc_co_u32": "emu_addc_co", "v_sub_co_u32": "emu_sub_co",
+       "v_subb_co_u32": "emu_subb_co", "v_cndmask_b32": "emu_cndmask", "v_add_u32": "emu_add", "v_mul_u32_u24": "emu_mul_u24",
+       "v_lshlrev_b32": "emu_lshlrev", "v_alignbit_b32": "emu_alignbit", "s_or_b64": "emu_s_or"}
+
+
+def host_register(asm_text, body, exprs):
+    """body: instruction lines with %N placeholders; exprs: C++ expression of operand N."""
+    import re
+    out = ["    { // host form of the statement (generated)", "        u64 vcc = 0, emu_dead = 0;", "        (void)vcc; (void)emu_dead;"]
+    for line in body:
+        mn, rest = line.split(None, 1)
+        ops = [o.strip() for o in rest.split(",")]
+        cpp = []
+        for o in ops:
+            m = re.fullmatch(r"%(\d+)", o)
+            if m:
+                cpp.append(exprs[int(m.group(1))])
+            elif o == "vcc":
+                cpp.append("vcc")
+            elif o == "s[100:101]":
+                cpp.append("emu_dead")
+            else:
+                cpp.append(o + ("ull" if (mn == "v_mad_u64_u32" and o == "0") else "u"))
+        out.append(f"        {EMU[mn]}({', '.join(cpp)});")
+    out.append("    }")
+    HOST[asm_text] = "\n".join(out) + "\n"
+
 
 
 def col_products_mul(k):
@@ -103,6 +140,7 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, z
     s += "        : " + ", ".join(f'"{c}"({e})' for c, e in ops_out) + "\n"
     s += "        : " + ", ".join(f'"{c}"({e})' for c, e in ops_in) + "\n"
     s += f"        : {clob});\n"
+    host_register(s, body, [e for _, e in ops_out] + [e for _, e in ops_in])
     lines.append(s)
 
 
@@ -147,6 +185,7 @@ def gen_merge():
     s += "        : " + ", ".join(f'"=&v"(t[{j}])' for j in range(1, 8)) + ', "=&s"(c)\n'
     s += "        : " + ", ".join(f'"v"(e[{j}])' for j in range(1, 8)) + ", " + ", ".join(f'"v"(o[{j}])' for j in range(1, 8)) + "\n"
     s += '        : "vcc");\n'
+    host_register(s, body, [f"t[{j}]" for j in range(1, 8)] + ["c"] + [f"e[{j}]" for j in range(1, 8)] + [f"o[{j}]" for j in range(1, 8)])
     L.append(s)
     # second half: t8..t15, carry in %24
     body = []
@@ -156,8 +195,9 @@ def gen_merge():
     s = '    asm("' + '\\n\\t"\n        "'.join(body) + '"\n'
     s += "        : " + ", ".join(f'"=&v"(t[{j}])' for j in range(8, 16)) + "\n"
     s += "        : " + ", ".join(f'"v"(e[{j}])' for j in range(8, 16)) + ", " + ", ".join(f'"v"(o[{j}])' for j in range(8, 16)) + ', "s"(c)\n'
-    s += '        : "vcc");\n}\n\n'
-    L.append(s)
+    s += '        : "vcc");\n'
+    host_register(s, body, [f"t[{j}]" for j in range(8, 16)] + [f"e[{j}]" for j in range(8, 16)] + [f"o[{j}]" for j in range(8, 16)] + ["c"])
+    L.append(s + "}\n\n")
     return "".join(L)
 
 
@@ -195,6 +235,7 @@ class Asm:
         s += indent + "    : " + ", ".join(f'"{c}"({e})' for c, e in self.outs) + "\n"
         s += indent + "    : " + ", ".join(f'"{c}"({e})' for c, e in self.ins) + "\n"
         s += indent + "    : " + ", ".join(f'"{c}"' for c in self.clob) + ");\n"
+        host_register(s, lines, [e for _, e in self.outs] + [e for _, e in self.ins])
         return s
 
 
@@ -526,7 +567,9 @@ def gen_reduce_flags():
     L.append(a.render())
     # fold limb 8 with one multiply-add: f = s8 * 977 + (s8 : s0)
     L.append("    u64 f = ((u64)s[8] << 32) | lo[0];\n")
-    L.append('    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(f), "=&s"(kc) : "v"(s[8]), "s"(VK_PC0));\n')
+    one = '    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(f), "=&s"(kc) : "v"(s[8]), "s"(VK_PC0));\n'
+    host_register(one, ["v_mad_u64_u32 %0, %1, %2, %3, %0"], ["f", "kc", "s[8]", "VK_PC0"])
+    L.append(one)
     L.append("    const u32 fl = (u32)f, fh = (u32)(f >> 32);\n")
     # r1 = s1 + f.hi, r2 = s2 + carry; the carry out of limb 2 is the last flag
     a = Asm()
@@ -556,6 +599,15 @@ def main():
     txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_sqr_tail() + gen_addsub() + gen_sub3() + gen_reduce() + gen_reduce_fast() + gen_reduce_flags()
     open(OUT, "w").write(txt)
     print("wrote", OUT, len(txt.splitlines()), "lines")
+    host = txt.replace("// GENERATED by tools/gen_field.py -- do not edit.", "// GENERATED by tools/gen_field.py -- do not edit.  HOST form (VK_HOST_EMU): every asm statement of vk_field_gen.cuh as\n// calls into the one-lane instruction emulator of vk_field.cuh; test infrastructure, never part of the device build.", 1)
+    n = 0
+    for a, h in HOST.items():
+        assert a in host, a[:200]
+        n += host.count(a)
+        host = host.replace(a, h)
+    assert "asm(" not in host, "a statement was not registered for the host backend"
+    open(OUT_HOST, "w").write(host)
+    print("wrote", OUT_HOST, n, "statements translated")
 
 
 if __name__ == "__main__":

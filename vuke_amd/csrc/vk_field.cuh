@@ -9,13 +9,44 @@
 // Replaces (behaviourally) the field code of libsecp256k1 that the reference reaches via
 // src/derive.rs:97; written from SEC2 parameters, not from that library.
 #pragma once
+#ifndef VK_HOST_EMU
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 typedef uint32_t u32;
 typedef uint64_t u64;
 
+#ifndef VK_HOST_EMU
 #define VK_DEV __device__ __forceinline__
+#else
+// ---- VK_HOST_EMU: the field layer compiled for the host, one lane, every generated asm statement replaced by calls into the
+// instruction emulator below (vk_field_gen_host.h, written by tools/gen_field.py next to the device header).  TEST
+// INFRASTRUCTURE: tests/test_host_field.py builds it with g++ and holds the arithmetic to python integers on a machine without
+// a GPU.  Nothing in the device build sees this branch.
+#define VK_DEV static inline
+#define __device__
+#define __noinline__ __attribute__((noinline))
+#define __constant__
+#define __builtin_amdgcn_ballot_w64(x) ((x) ? 1ull : 0ull)
+// semantics of the ten instructions the generator emits, for one lane; carries are the lane's bit 0 of a 64-bit mask
+static inline void emu_mad(u64 &d, u64 &c, u32 a, u32 b, u64 add)
+{
+    const unsigned __int128 t = (unsigned __int128)a * b + add;
+    d = (u64)t;
+    c = (u64)(t >> 64) & 1u;
+}
+static inline void emu_add_co(u32 &d, u64 &c, u32 x, u32 y) { const u64 t = (u64)x + y; d = (u32)t; c = t >> 32; }
+static inline void emu_addc_co(u32 &d, u64 &co, u32 x, u32 y, u64 ci) { const u64 t = (u64)x + y + (ci & 1u); d = (u32)t; co = t >> 32; }
+static inline void emu_sub_co(u32 &d, u64 &c, u32 x, u32 y) { c = x < y; d = x - y; }
+static inline void emu_subb_co(u32 &d, u64 &co, u32 x, u32 y, u64 ci) { const u64 s = (u64)y + (ci & 1u); const u64 b = (u64)x < s; d = (u32)((u64)x - s); co = b; }
+static inline void emu_cndmask(u32 &d, u32 x, u32 y, u64 m) { d = (m & 1u) ? y : x; }
+static inline void emu_add(u32 &d, u32 x, u32 y) { d = x + y; }
+static inline void emu_mul_u24(u32 &d, u32 x, u32 y) { d = (x & 0xFFFFFFu) * (y & 0xFFFFFFu); }
+static inline void emu_lshlrev(u32 &d, u32 sh, u32 x) { d = x << (sh & 31u); }
+static inline void emu_alignbit(u32 &d, u32 hi, u32 lo, u32 sh) { d = (u32)((((u64)hi << 32) | lo) >> (sh & 31u)); }
+static inline void emu_s_or(u64 &d, u64 x, u64 y) { d = x | y; }
+#endif
 
 struct fe {
     u32 v[8];
@@ -44,6 +75,16 @@ VK_DEV void fe_set_one(fe &r)
 // 64 multiplies + 49 carry counts + 15 merge adds, versus ~320 instructions (two thirds of them
 // v_mov / 64-bit adds) for the same product written in plain C++.
 
+#ifdef VK_HOST_EMU
+typedef unsigned long vk_carry;
+VK_DEV void mad_nc(u64 &acc, u32 a, u32 b) { u64 c; emu_mad(acc, c, a, b, acc); }
+VK_DEV void mad_cy(u64 &acc, u32 &cy, u32 a, u32 b) { u64 c; emu_mad(acc, c, a, b, acc); emu_addc_co(cy, c, 0u, cy, c); }
+VK_DEV u32 add_co(vk_carry &co, u32 x, u32 y) { u32 r; u64 c; emu_add_co(r, c, x, y); co = c; return r; }
+VK_DEV u32 addc_co(vk_carry &co, u32 x, u32 y, vk_carry ci) { u32 r; u64 c; emu_addc_co(r, c, x, y, ci); co = c; return r; }
+VK_DEV u32 addc(u32 x, u32 y, vk_carry ci) { u32 r; u64 c; emu_addc_co(r, c, x, y, ci); return r; }
+VK_DEV u64 mul_wide_s(u32 a, u32 s) { u64 r, c; emu_mad(r, c, a, s, 0ull); return r; }
+VK_DEV bool lane_in_mask(vk_carry mask) { return mask & 1ull; }
+#else
 // acc = a * b + acc; the sum is known not to overflow 64 bits
 VK_DEV void mad_nc(u64 &acc, u32 a, u32 b)
 {
@@ -89,6 +130,7 @@ VK_DEV bool lane_in_mask(vk_carry mask)
     u32 lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     return (mask >> lane) & 1ull;
 }
+#endif // VK_HOST_EMU
 // rare paths of the generated add / sub / reduce: one more +-C where a lane wrapped 2^256 twice
 VK_DEV void fe_wrap_add(fe &r, vk_carry mask)
 {
@@ -167,7 +209,11 @@ VK_DEV void fe_ripple_sub(fe &r, int from, vk_carry mask)
     }
 }
 
+#ifdef VK_HOST_EMU
+#include "vk_field_gen_host.h" // the same statements for one lane on the host (tests/test_host_field.py)
+#else
 #include "vk_field_gen.cuh" // fe_mul_cols, fe_sqr_cols, merge_eo (generated by tools/gen_field.py)
+#endif
 
 // How the 16-limb product is reduced (tools/gen_field.py):
 //   1  fe_reduce16_flags: 19 VALU instructions, no precondition test; every carry the short form can lose is flagged in an
