@@ -8,6 +8,8 @@ data-path collective; RCCL is used only to all-reduce counters after the timed r
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5m|5e] [--strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+A plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) starts those N ranks itself: the parent, before it
+imports torch or touches the GPU, runs the torch.distributed.run line above as a child process and returns its status.
 
 Other configs under the same contract (inputs in bench_workloads.py):
   --config 3   scan --transform=sha256 vs 1 000 000 targets (both hash160s), step = 2^25 inputs (3 keys each)
@@ -39,13 +41,45 @@ PEAK_INT32 = 256 * 4 * 16 * 2.4e9
 HBM_PEAK = 8.0e12
 
 
+def weak_stride(steps, nblocks, world):
+    """Blocks between the starting points of neighbouring ranks in the weak-scaling run.  When the rank count divides the block
+    count, rank r starts at r*nblocks/world: the first nblocks/world steps of all ranks together are then exactly ONE sweep of
+    the whole space (disjoint blocks), which is what `sweep_2p32_wall_s` times; later steps wrap.  Otherwise rank-major."""
+    return nblocks // world if (world <= nblocks and nblocks % world == 0) else steps
+
+
 def block_of(rank, step, steps, block_log2=28, strong=False, world=1):
     """Seed block (inclusive lo, hi) of the 2^32 Milksad space that `rank` sweeps at `step`.  Weak scaling (driver default):
-    rank-major blocks (rank*steps + step), wrapping inside the seed space.  --strong: the world shares ONE sweep, rank r owns
-    the contiguous run of nblocks/world blocks starting at r*nblocks/world (disjoint, no wrap, together the whole space)."""
+    rank r walks blocks r*16/world, r*16/world + 1, ... wrapping inside the seed space (per-GPU work fixed at `steps` blocks).
+    --strong: the world shares ONE sweep, rank r owns the contiguous run of 16/world blocks starting at r*16/world and stops
+    there (disjoint, no wrap, together the whole space)."""
     nblocks = 1 << (32 - block_log2)
-    b = (rank * (nblocks // world) + step) if strong else (rank * steps + step) % nblocks
+    b = (rank * (nblocks // world) + step) if strong else (rank * weak_stride(steps, nblocks, world) + step) % nblocks
     return b << block_log2, ((b + 1) << block_log2) - 1
+
+
+def launcher_cmd(gpus, argv, port):
+    """The command a plain `bench.py --gpus N` runs as a child: one rank per GPU under torch.distributed.run, same arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher above it: start the N ranks as a CHILD process (never an exec, and
+    before this process imports torch or makes any GPU call), let rank 0's JSON line through and hand back the child's status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = launcher_cmd(args.gpus, [a for a in argv if a != "--print-launch"], port)
+    if args.print_launch:
+        print(json.dumps(cmd))
+        return 0
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def csrc_hash():
@@ -116,6 +150,14 @@ class Milksad(Workload):
 
     def step_total(self):
         return self.per_rank if self.args.strong else self.args.steps
+
+    def full_sweep_steps(self):
+        """Steps after which all ranks together have swept every block of the 2^32 space exactly once (0 = this run never
+        does): 16/world when the rank count divides 16 (block_of: rank r starts at block r*16/world) and the run is that long."""
+        if self.nblocks % self.world or self.world > self.nblocks:
+            return 0
+        n = self.nblocks // self.world
+        return n if self.step_total() >= n else 0
 
     def block_of(self, step):
         lo, _ = block_of(self.rank, step, self.args.steps, self.wl.C2_BLOCK_LOG2, self.args.strong, self.world)
@@ -317,14 +359,16 @@ def make_workload(args, rank, world):
 
 # ------------------------------------------------------------------------------------------------ main
 def reduce_counters(dist, dev, counters, elapsed):
-    """Sum the integer counters and take the max elapsed time over ranks (one tiny collective each)."""
+    """Sum the integer counters and take the max over ranks of the elapsed time(s) (one tiny collective each).
+    `elapsed` is one float (returned as a float) or a list of floats (returned as a list)."""
     import torch
+    many = isinstance(elapsed, (list, tuple))
     tot = torch.tensor(list(counters), dtype=torch.int64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor(list(elapsed) if many else [elapsed], dtype=torch.float64, device=dev)
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    return [int(x) for x in tot.tolist()], float(tmax.item())
+    return [int(x) for x in tot.tolist()], ([float(x) for x in tmax.tolist()] if many else float(tmax.item()))
 
 
 def main():
@@ -340,6 +384,7 @@ def main():
     # rehearsal knobs (not used by the driver): run the N-rank path on a box with fewer GPUs than ranks
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal)")
     ap.add_argument("--share-device", type=int, default=-1, help="put every rank on this one GPU (rehearsal only)")
+    ap.add_argument("--print-launch", action="store_true", help="with --gpus N > 1 and no launcher: print the child command as JSON and exit")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run every collective even with one rank "
                                                                "(exercises the RCCL call sequence of the N > 1 path on a one-GPU box)")
     # table geometry of the flagship run: 9 signed-digit windows (120 GB of the 288 GB HBM, 8 point additions per key),
@@ -350,6 +395,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--blocks-per-cu", type=int, default=2)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     if args.steps is None:
         args.steps = {"2": 16, "3": 3, "4": 8, "5m": 10, "5e": 3}[args.config]
     if args.strong and args.config != "2":
@@ -386,9 +433,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=args.backend)
-    elif args.gpus != 1:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-        sys.exit(2)
+    if args.gpus != world and not args.force_dist:
+        print(f"bench.py: --gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the launcher's rank count is used", file=sys.stderr)
     n_gpus = world
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -429,10 +475,14 @@ def main():
     units = keys_done = matches = expected = launches = 0
     kernel_s = clock_acc = 0.0
     digest = (0, 0, 0, 0)
+    full_after = w.full_sweep_steps() if (args.config == "2" and not args.emulate_gpus) else 0
+    t_full = 0.0
     sync()
     t0 = time.perf_counter()
     for s in range(steps):
         st = w.step(eng, s)
+        if s + 1 == full_after:   # vk_sweep has returned its counters: this rank's share of one whole 2^32 sweep is done
+            t_full = time.perf_counter() - t0
         units += st["units"]
         keys_done += st["keys"]
         matches += st["matches"]
@@ -446,8 +496,8 @@ def main():
 
     # counters: one tiny all-reduce over RCCL (the only collective on this path)
     red_dev = dev if (not use_dist or args.backend == "nccl") else torch.device("cpu")
-    (total_units, total_keys, total_matches, total_expected, dg_checked, dg_bad), t = reduce_counters(
-        dist, red_dev, [units, keys_done, matches, expected, w.digest_checked, w.digest_bad], elapsed)
+    (total_units, total_keys, total_matches, total_expected, dg_checked, dg_bad), (t, t_full, create_max, setup_max) = reduce_counters(
+        dist, red_dev, [units, keys_done, matches, expected, w.digest_checked, w.digest_bad], [elapsed, t_full, engine_create_s, setup_s])
     wall_s = time.perf_counter() - t_wall0
     # the digests of all ranks (XOR words and the wrapping sum): gathered, folded on rank 0
     all_digests = [digest]
@@ -525,8 +575,19 @@ def main():
         }
         if w.unit_name == "inputs":
             out["inputs_per_s"] = total_units / t
+        # what the job pays before the first key: slowest rank's vk_engine_create (allocation + table build on the device) and
+        # target upload; outside `value` (sustained throughput), inside every *_end_to_end_s below
+        out["engine_create_s"] = create_max
+        out["table_build_s"] = info["table_build_seconds"]
+        out["targets_and_fixtures_s"] = setup_max
         if args.config == "2":
             out["sweep_2p32_seconds_at_this_rate"] = (1 << 32) / value
+            if full_after:
+                # MEASURED, not extrapolated: the first 16/N timed steps of the N ranks are disjoint blocks covering the whole seed
+                # space (block_of), every block's digest checked against the oracle's; max over ranks of the time they took
+                out["sweep_2p32_wall_s"] = t_full
+                out["sweep_2p32_steps"] = full_after
+                out["sweep_2p32_end_to_end_s"] = create_max + setup_max + t_full
             ab = w.algo_bytes_per_key(info)
             out["roofline_hbm"] = {"bound": "hbm", "achieved": ab * rate / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ab * rate / HBM_PEAK,
                                    "traffic": roof.get("traffic"), "algorithmic_bytes_per_key": ab,

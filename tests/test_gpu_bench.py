@@ -12,9 +12,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args, nproc=1, timeout=900):
+def run_bench(*args, nproc=1, timeout=900, own_launch=False):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if nproc == 1:
+    if own_launch:   # the driver's command shape: plain python, bench.py starts its ranks itself
+        env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), *args]
+    elif nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]
     else:
         s = socket.socket()
@@ -86,12 +89,28 @@ def test_two_ranks_share_the_device():
     check_contract(o, n_gpus=2)
     import bench_workloads as wl
     planted = wl.c2_planted_seeds()
-    assert o["matches"] == sum(1 for p in planted if p < 4 << 28)          # ranks 0 and 1 sweep blocks 0,1 and 2,3
+    blocks = (0, 1, 8, 9)                                                   # rank r starts at block r * 16/2
+    assert o["matches"] == sum(1 for p in planted if (p >> 28) in blocks)
     assert o["digests_checked_against_oracle"] == 6
     g = wl.load_golden("milksad_2p32.json")
-    assert o["digest"] == wl.hexd(wl.fold_digests([wl.unhexd(d) for d in g["block_digests"][:4]]))
+    assert o["digest"] == wl.hexd(wl.fold_digests([wl.unhexd(g["block_digests"][b]) for b in blocks]))
+    assert "sweep_2p32_wall_s" not in o                                     # two steps are not a whole sweep
     o = run_bench("--share-device", "0", "--backend", "gloo", "--layout", "0", "--strong", "--emulate-gpus", "8", "--no-cpu-baseline", nproc=2)
     assert o["strong"]["blocks_per_rank"] == 2 and o["n_gpus"] == 2
+
+
+def test_plain_gpus_2_starts_its_own_ranks():
+    """The driver's command shape for N > 1 -- `python bench.py --gpus 2 ...`, no torch.distributed.run around it: bench.py starts
+    the two ranks as a child process itself, rank 0's line comes through, blocks are disjoint and oracle-checked."""
+    o = run_bench("--share-device", "0", "--backend", "gloo", "--layout", "0", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                  nproc=2, own_launch=True)
+    check_contract(o, n_gpus=2)
+    import bench_workloads as wl
+    blocks = (0, 1, 8, 9)
+    assert o["matches"] == sum(1 for p in wl.c2_planted_seeds() if (p >> 28) in blocks)
+    g = wl.load_golden("milksad_2p32.json")
+    assert o["digest"] == wl.hexd(wl.fold_digests([wl.unhexd(g["block_digests"][b]) for b in blocks]))
+    assert o["digests_checked_against_oracle"] == 6 and o["engine_create_s"] > 0
 
 
 def test_rccl_call_sequence_with_one_rank():

@@ -116,41 +116,47 @@ def test_lcg_all_variants_key_counts_across_ceilings(eng):
     assert st["keys"] == 2 * h
 
 
+def _hit_records(hits):
+    return sorted((h["seed"], h["sub_index"], h["addr_kind"], h["privkey"].hex(), h["h160"].hex()) for h in hits)
+
+
+def _planted_records(planted):
+    return sorted((p["seed"], p["sub_index"], p["addr_kind"], p["privkey"], p["h160"]) for p in planted)
+
+
 def test_config3_sha256_scan_against_a_million_targets(eng):
     """BASELINE config 3 at full size: seeds 0..99 999 999 x 3 keys, 1 000 000 targets = 999 000 decoys +
-    1 000 planted (seed 7919*j, slot j%3, kind cycling p2pkh_c / p2pkh_u / p2wpkh): exactly the planted keys are hit."""
-    import hashlib
-    import struct
+    1 000 planted (seed 7919*j, slot j%3, kind cycling p2pkh_c / p2pkh_u / p2wpkh).  The planted hash160s and the expected
+    hit records (seed, slot, address kind, private key, hash160) are the ORACLE's (tests/golden/bench_c3.json,
+    make_bench_fixtures.py) -- nothing the device computed is used to build the expectation."""
+    import bench_workloads as wl
     from vuke_amd import _ffi as ffi
     spec = ffi.spec(ffi.T_SHA256)
-    planted = [(7919 * j, j % 3, j % 3) for j in range(1000)]
-    rows = eng.transform_batch(spec, [s for s, _, _ in planted])
-    keys = [rows[i][sub] for i, (_, sub, _) in enumerate(planted)]
-    _, hc, hu = eng.derive_batch(keys)
-    h160s = [u if kind == 1 else c for (_, _, kind), c, u in zip(planted, hc, hu)]
-    kinds = [ffi.TARGET_P2WPKH if kind == 2 else ffi.TARGET_P2PKH for _, _, kind in planted]
-    for j in range(999_000):
-        h160s.append(hashlib.sha256(b"decoy" + struct.pack("<Q", j)).digest()[:20])
-        kinds.append(j & 1)
+    fx = wl.load_golden("bench_c3.json")
+    planted = fx["planted"]
+    assert [(p["seed"], p["sub_index"], p["addr_kind"]) for p in planted] == wl.c3_planted()
+    h160s = [bytes.fromhex(p["h160"]) for p in planted]
+    kinds = [ffi.TARGET_P2WPKH if p["addr_kind"] == 2 else ffi.TARGET_P2PKH for p in planted]
+    for d, kind in wl.c3_decoys():
+        h160s.append(d)
+        kinds.append(kind)
     eng.targets_set(h160s, kinds)
-    st, hits = eng.sweep(spec, 0, 99_999_999, flags=3, hit_cap=4096)
+    st, hits = eng.sweep(spec, 0, wl.C3_INPUTS - 1, flags=3, hit_cap=4096)
     eng.targets_set([], [])
     assert (st["inputs"], st["keys"], st["matches"], st["hits_dropped"]) == (10**8, 3 * 10**8, 1000, 0)
-    assert sorted((h["seed"], h["sub_index"], h["addr_kind"]) for h in hits) == sorted(planted)
-    assert {(h["seed"], h["sub_index"]): h["privkey"] for h in hits} == {(s, sub): k for (s, sub, _), k in zip(planted, keys)}
+    assert _hit_records(hits) == _planted_records(planted)
 
 
 def test_config4_all_lcg_variants_over_2p31_seeds(eng):
     """BASELINE config 4 at full size on one GPU: every LCG variant x seeds 0..2^31-1 in eight contiguous 2^28 blocks
-    (the 8-GPU split), 256 planted keys per variant; counters, hits and the digest of the whole agree with the blocks."""
+    (the 8-GPU split), 256 planted keys per variant with hash160 and private key from the ORACLE (tests/golden/bench_c4.json);
+    counters, full hit records and the digest of the whole agree with the blocks."""
+    import bench_workloads as wl
     from vuke_amd import _ffi as ffi
     spec = ffi.spec(ffi.T_LCG)
-    planted = sorted({((0x9E3779B1 * j + 777 * v) & 0x7FFFFFFF, v) for v in range(4) for j in range(256)} - {(2**31 - 1, 1)})
-    rows = eng.transform_batch(spec, [s for s, _ in planted])
-    keys = [rows[i][v] for i, (_, v) in enumerate(planted)]
-    assert all(k is not None for k in keys)
-    _, hc, _ = eng.derive_batch(keys)
-    eng.targets_set(hc, [ffi.TARGET_P2PKH] * len(hc))
+    planted = wl.load_golden("bench_c4.json")["planted"]
+    assert [(p["seed"], p["sub_index"]) for p in planted] == wl.c4_planted() and len(planted) == 1024
+    eng.targets_set([bytes.fromhex(p["h160"]) for p in planted], [ffi.TARGET_P2PKH] * len(planted))
     parts, hits = [], []
     for b in range(8):
         st, h = eng.sweep(spec, b << 28, ((b + 1) << 28) - 1, flags=ffi.F_COMPRESSED, hit_cap=4096)
@@ -159,10 +165,11 @@ def test_config4_all_lcg_variants_over_2p31_seeds(eng):
     eng.targets_set([], [])
     assert sum(p["inputs"] for p in parts) == 2**31
     assert sum(p["keys"] for p in parts) == 4 * 2**31 - 1          # minstd skips seed 2^31 - 1 (src/transform/lcg.rs: seed <= m - 1)
-    assert sum(p["matches"] for p in parts) == len(planted)
-    assert sorted((h["seed"], h["sub_index"]) for h in hits) == planted
+    assert sum(p["matches"] for p in parts) == len(planted) and sum(p["hits_dropped"] for p in parts) == 0
+    assert _hit_records(hits) == _planted_records(planted)
     whole, _ = eng.sweep(spec, 0, 2**31 - 1, flags=ffi.F_COMPRESSED)
     assert whole["keys"] == 4 * 2**31 - 1 and whole["digest"] == fold(p["digest"] for p in parts)
+    assert wl.hexd(whole["digest"]) == wl.load_golden("bench_c4_full.json")["digest"]   # the oracle's, over the whole config
 
 
 def test_config5_key_chains_at_size(eng, vko):

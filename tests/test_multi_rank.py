@@ -19,10 +19,10 @@ from oracle import vko
 dist.init_process_group(backend="gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 steps, block_log2 = 3, 8
-blocks = [bench.block_of(rank, s, steps, block_log2) for s in range(steps)]
+blocks = [bench.block_of(rank, s, steps, block_log2, world=world) for s in range(steps)]
 keys = matches = 0
 dg = [0, 0, 0, 0]
-m = vko.Matcher([vko.derive(vko.milksad_key(5)).p2pkh_compressed.decode(), vko.derive(vko.milksad_key(1300)).p2pkh_compressed.decode()])
+m = vko.Matcher([vko.derive(vko.milksad_key(5)).p2pkh_compressed.decode(), vko.derive(vko.milksad_key((1 << 31) + 300)).p2pkh_compressed.decode()])
 for lo, hi in blocks:
     st, hits = vko.sweep(vko.spec(vko.T_MILKSAD), lo, hi, flags=1, matcher=m, nthreads=1)
     keys += st["keys"]; matches += st["matches"]
@@ -54,8 +54,9 @@ def test_two_rank_partition_and_reduce(tmp_path):
     import json
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     blocks = [tuple(b) for rb in out["blocks"] for b in rb]
-    # disjoint, contiguous cover of 6 blocks of 2^8 seeds
-    assert sorted(blocks) == [(i * 256, i * 256 + 255) for i in range(6)]
+    # disjoint: rank r starts at block r * nblocks/world (here 2^24 blocks of 2^8 seeds), three blocks each
+    half = 1 << 23
+    assert sorted(blocks) == [(i * 256, i * 256 + 255) for i in (0, 1, 2, half, half + 1, half + 2)]
     assert out["tot"] == [6 * 256, 2] and out["tmax"] == 2.0
 
 
@@ -64,11 +65,65 @@ def test_block_partition_wraps_inside_the_seed_space():
     seen = set()
     for rank in range(8):
         for s in range(2):
-            lo, hi = bench.block_of(rank, s, 2, 28)
+            lo, hi = bench.block_of(rank, s, 2, 28, world=8)
             assert hi - lo + 1 == 1 << 28 and hi < 1 << 32
             seen.add(lo)
     assert len(seen) == 16  # 8 ranks x 2 steps = the whole 2^32 space, no overlap
-    assert bench.block_of(3, 5, 16, 28) == bench.block_of(0, (3 * 16 + 5) % 16, 16, 28)
+    assert bench.block_of(3, 14, 20, 28, world=4) == bench.block_of(0, (3 * 4 + 14) % 16, 20, 28, world=1)
+
+
+def test_weak_run_contains_one_whole_sweep_for_every_driver_gpu_count():
+    """The driver's line (--steps 20) at N = 1, 2, 4, 8: the first 16/N steps of the N ranks are disjoint and cover all 16
+    blocks of the 2^32 space -- that prefix is what `sweep_2p32_wall_s` measures; a rank count that does not divide 16 falls
+    back to rank-major blocks and reports no such time."""
+    import bench
+    for world in (1, 2, 4, 8, 16):
+        n = 16 // world
+        first = [bench.block_of(r, s, 20, 28, world=world)[0] >> 28 for r in range(world) for s in range(n)]
+        assert sorted(first) == list(range(16))
+        assert bench.weak_stride(20, 16, world) == n
+    assert bench.weak_stride(20, 16, 3) == 20 and bench.weak_stride(20, 16, 32) == 20
+    a = type("A", (), {"strong": False, "steps": 20})()
+    for world, want in ((1, 16), (2, 8), (8, 2), (3, 0)):
+        m = bench.Milksad(a, 0, world)
+        m.nblocks = 16
+        assert m.full_sweep_steps() == want
+    a.steps = 4
+    m = bench.Milksad(a, 0, 2)
+    m.nblocks = 16
+    assert m.full_sweep_steps() == 0   # the run is shorter than one sweep: nothing measured, nothing reported
+
+
+def test_plain_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher above it (the shape of the driver's N = 1 command) must start N ranks itself:
+    the parent builds the torch.distributed.run command, runs it as a child and returns the child's status."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for extra in (["--strong"], ["--steps", "20", "--warmup", "2"], ["--config", "4"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", *extra, "--print-launch"],
+                           capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        cmd = json.loads(r.stdout)
+        i = cmd.index(os.path.join(ROOT, "bench.py"))
+        assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd[:i] and "--nnodes=1" in cmd[:i]
+        assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[i + 1:] == ["--gpus", "8", *extra]
+    # under a launcher (WORLD_SIZE set) the same command does NOT start ranks again: it goes on to need a device
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--print-launch"], capture_output=True, text=True,
+                       timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "torch.distributed.run" not in r.stdout
+
+
+def test_self_launch_runs_the_ranks_as_a_child_and_returns_their_status():
+    """Without a GPU the two ranks fail (no device); what is checked is that they were started -- both rank numbers appear in
+    the launcher's failure report -- and that the parent hands the failure back instead of exiting 2 on an argument check."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by tests/test_gpu_bench.py")
+    assert r.returncode not in (0, 2), (r.returncode, r.stderr[-1500:])
+    assert "rank      : 1" in r.stderr or "rank: 1" in r.stderr or "local_rank: 1" in r.stderr, r.stderr[-3000:]
 
 
 def test_strong_partition_is_one_disjoint_sweep():
