@@ -220,8 +220,8 @@ int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy /* n_files*32 */, size
 
 /* Transform::apply_batch for string inputs (Input::from_string; wordlist / stdin sources).  String i is
  * data[offsets[i] .. offsets[i+1]).  slots = vk_slots_per_string(t): the hash transforms (sha256, double_sha256, md5,
- * direct) and armory emit one key per string of any length, sha256_chain variants x depth, VK_T_ELECTRUM (strings up to 64
- * bytes) and VK_T_MULTIBIT (up to 256 bytes) chain_depth keys; the PRNG transforms need a numeric seed and return
+ * direct) and armory emit one key per string of any length, sha256_chain variants x depth, VK_T_ELECTRUM and VK_T_MULTIBIT
+ * (strings up to 448 bytes each) chain_depth keys; the PRNG transforms need a numeric seed and return
  * VK_E_UNSUPPORTED.  keys_out = n*slots*32, valid = n*slots, slot order = emit order.  A string over the device limit of
  * the two KDF chains never aborts the batch (the reference skips bad inputs silently, src/transform/electrum.rs:49-52): its
  * slots stay invalid, the call returns VK_OK, and when the reference would have produced keys for it (a multibit line, an
@@ -283,6 +283,14 @@ uint32_t vk_slots_per_string(const vk_transform_spec *t);
 
 /* Test hook: (d << (window_bits*w)) * G table entry as 64 bytes X||Y big-endian. */
 int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digit, uint8_t xy[64]);
+/* Test hook: n bytes at `offset` of the engine's device scratch slot `slot` (inputs, outputs and chain state of the last
+ * batch call; layout is internal).  Used by the GPU tests to look at intermediate values of the key-derivation chains. */
+int vk_debug_scratch(vk_engine *e, int slot, size_t offset, uint8_t *out, size_t n);
+/* Test hook: the multibit chain of the following vk_transform_strings calls stops after `stages` of its five kernels
+ * (1 prepare, 2 + first stretch, 3 + repacking, 4 + second stretch; 0 = run to the end, the default), leaving the chain state
+ * in scratch slot 7 for vk_debug_scratch.  No keys are produced by a stopped chain. */
+int vk_debug_chain_stop(vk_engine *e, int stages);
+
 /* Test hook: field multiply / inverse on the device, big-endian 32-byte operands. */
 int vk_debug_field(vk_engine *e, int op /* 0 mul, 1 sqr, 2 inv, 3 add, 4 sub */, const uint8_t *a, const uint8_t *b,
                    size_t n, uint8_t *out);

@@ -19,8 +19,10 @@ static int is_hex_string(const uint8_t *s, size_t n)
 /* src/electrum.rs:150-168: x = SHA256(seed||seed); 99 999 x: x = SHA256(x||seed) */
 void vko_electrum_stretch(const uint8_t *seed, size_t len, uint32_t rounds, uint8_t out[32])
 {
-    uint8_t buf[32 + 256];
-    if (len > 128) len = 128;
+    /* a seed of any length (the reference hashes the whole slice; round 3: the fixed buffer of rounds 1-2 cut seeds at 128 bytes,
+     * unreachable while the device took at most 64) */
+    uint8_t small[32 + 2 * 128];
+    uint8_t *buf = 32 + 2 * len <= sizeof small ? small : (uint8_t *)malloc(32 + 2 * len);
     memcpy(buf, seed, len);
     memcpy(buf + len, seed, len);
     vko_sha256(buf, 2 * len, out);
@@ -29,6 +31,7 @@ void vko_electrum_stretch(const uint8_t *seed, size_t len, uint32_t rounds, uint
         memcpy(buf + 32, seed, len);
         vko_sha256(buf, 32 + len, out);
     }
+    if (buf != small) free(buf);
 }
 
 /* ElectrumTransform::apply_batch for one input: keys[i] valid iff valid[i]; returns 0 when the

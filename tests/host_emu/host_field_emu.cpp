@@ -1,8 +1,10 @@
-// host_field_emu.cpp -- TEST INFRASTRUCTURE: the generated field layer (vuke_amd/csrc/vk_field.cuh) compiled for the host with
-// VK_HOST_EMU (every inline-asm statement replaced by calls into a one-lane instruction emulator, vk_field_gen_host.h) and
+// host_field_emu.cpp -- TEST INFRASTRUCTURE: the generated field layer (vuke_amd/csrc/vk_field.cuh) compiled for the host with its
+// two macro-named headers pointed at this directory (every inline-asm statement replaced by calls into a one-lane instruction
+// emulator: vk_field_prims_host.h, vk_field_gen_host.h) and
 // driven from stdin: lines "op a_hex64 b_hex64" -> one line of 64 hex digits per input (canonical result).  The op numbers are
 // those of vk_debug_field / vk_field_kernel (vk_aux_kernels.cuh).  Built and run by tests/test_host_field.py.
-#define VK_HOST_EMU 1
+#define VK_FIELD_PRIMS_H "vk_field_prims_host.h"
+#define VK_FIELD_GEN_H "vk_field_gen_host.h"
 #include "vk_field.cuh"
 
 #include <cstdio>

@@ -352,10 +352,13 @@ def test_electrum_strings_and_scan_keys(eng, vko):
     import vuke_amd
     with pytest.raises(vuke_amd.VkError):
         eng.sweep(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), 0, 10)          # string transform: not a range sweep
-    # an over-long seed no longer fails the batch (the reference never aborts on an input): no keys, a warning for the all-hex one
-    assert eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), [b"a" * 65]) == [[None] * 20]
+    # seeds beyond 64 bytes take the device's long-seed path (the reference accepts any length); beyond the 448-byte staging slice a
+    # seed never fails the batch (the reference never aborts on an input): no keys, a warning for the all-hex one
+    assert eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), [b"a" * 65]) == [[k for _, k in vko.electrum_keys(b"a" * 65)[1]]]
+    assert eng.last_warning() == ""
+    assert eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), [b"a" * 449]) == [[None] * 20]
     assert eng.last_warning().startswith("warning: 1 input string(s) longer than the device limit")
-    assert eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), [b"x" * 65]) == [[None] * 20] and eng.last_warning() == ""
+    assert eng.transform_strings(ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), [b"x" * 449]) == [[None] * 20] and eng.last_warning() == ""
 
 
 def test_multibit_chain(eng, vko):
@@ -374,12 +377,63 @@ def test_multibit_chain(eng, vko):
     ms = [" ".join(rnd.choice(words) for _ in range(n)) for n in (12, 15, 18, 21, 24) for _ in range(4)]
     ms += ["  " + ms[0].replace(" ", "\t", 2) + " \n", " ".join(words[:11]), " ".join(words[:12]) + " zzzzzzzzz", "", " ".join(words[:13]),
            " ".join(words[:11]) + " " + words[5][:-1]]
+    # the password is the string AS GIVEN: 12 words spread over 359 and 447 bytes (beyond the 256 of round 2, keys longer than one
+    # SHA-512 block are hashed first), one byte over the 448-byte staging limit (no keys, reported), a NUL inside a word
+    ms += [(" " * 25).join(words[100:112]), ("\t" * 33).join(words[100:112]), " ".join(words[:11]) + " " + words[11] + "\0"]
+    ms[-2] = ms[-2] + " " * (447 - len(ms[-2]))
+    ms.append(ms[-2] + "  ")
+    assert len(ms[-3]) == 447 and len(ms[-1]) == 449
     got = eng.transform_strings(spec, [m.encode() for m in ms])
+    assert eng.last_warning().startswith("warning: 1 input string(s) longer")
     for m, row in zip(ms, got):
         exp = vko.multibit_keys(wl, m)
         want = [k for _, k in exp[2]] if exp else []
+        if len(m) > 448:
+            assert want and row == [None] * 20   # the reference would derive keys; the device reports the line instead (warning above)
+            continue
         assert [k for k in row if k is not None] == want, m
-    assert sum(1 for r in got for k in r if k is not None) == 21 * 20
+    assert sum(1 for r in got for k in r if k is not None) == 23 * 20
+
+
+def test_multibit_chain_stage_by_stage_against_hashlib(eng):
+    """The five kernels of the MultiBit chain one at a time (vk_debug_chain_stop) against hashlib / hmac: U1 of both stretches, the
+    two PBKDF2 results after the ring has carried every group through its 32 chunks, and the rebuilt 48-word password -- for
+    lanes 0, 1 and 63 of the first group and lanes of the second (round 3's first ring advanced lane 0 of every group only)."""
+    import hashlib
+    import hmac
+    import struct
+    from tests.test_oracle_multibit import synthetic_wordlist
+    from vuke_amd import _ffi as ffi
+    words = synthetic_wordlist()
+    eng.bip39_wordlist_set(words)
+    rnd = random.Random(5)
+    ms = [" ".join(rnd.choice(words) for _ in range(12)).encode() for _ in range(70)]
+    spec = ffi.spec(ffi.T_MULTIBIT, 0, 0, 2)
+
+    def state_t(idx):
+        g, lane = idx >> 6, idx & 63
+        return b"".join(struct.pack(">Q", struct.unpack("<Q", eng.debug_scratch(7, ((g * 32 + 24 + w) * 64 + lane) * 8, 8))[0]) for w in range(8))
+
+    def repack48(seed1):
+        bits = int.from_bytes(seed1 + hashlib.sha256(seed1).digest()[:2], "big")
+        return " ".join(words[(bits >> (11 * (47 - k))) & 0x7FF] for k in range(48)).encode()
+
+    try:
+        for stop in (1, 2, 3, 4):
+            eng.debug_chain_stop(stop)
+            rows = eng.transform_strings(spec, ms)
+            assert all(k is None for r in rows for k in r)
+            for idx in (0, 1, 63, 64, 69):
+                seed1 = hashlib.pbkdf2_hmac("sha512", ms[idx], b"mnemonic", 2048)
+                w48 = repack48(seed1)
+                want = {1: hmac.new(ms[idx], b"mnemonic\0\0\0\1", "sha512").digest(), 2: seed1,
+                        3: hmac.new(w48, b"mnemonic\0\0\0\1", "sha512").digest(), 4: hashlib.pbkdf2_hmac("sha512", w48, b"mnemonic", 2048)}[stop]
+                assert state_t(idx) == want, (stop, idx)
+                if stop == 3:
+                    assert eng.debug_scratch(6, idx * 512, 512) == w48 + bytes(512 - len(w48))
+    finally:
+        eng.debug_chain_stop(0)
+    assert all(k is not None for r in eng.transform_strings(spec, ms[:3]) for k in r)
 
 
 def test_multibit_issue_445_vector_through_the_device(eng):
@@ -427,15 +481,17 @@ def test_scan_strings_fused_path(eng, vko):
         # the oracle on the same strings
         for (i, s, k) in picks:
             assert vko.transform_string(ospec, lines[i], s) == k
-    # electrum: a 65-byte line (hex or not) and a 300-byte line no longer abort the batch
+    # electrum: the reference takes a hex seed of ANY length (ElectrumDeriver::from_hex_seed); the device does up to 448 bytes
+    # (65 .. 448 on a slower one-lane path), a longer all-hex line is reported, a non-hex one is dropped as the reference drops it
     es = ffi.spec(ffi.T_ELECTRUM, 0, 0, 2)
-    seeds = [b"acb740e454c3134901d7c8f16497cc1c", b"z" * 65, b"ab" * 33, b"f" * 300, b"0123"]
+    seeds = [b"acb740e454c3134901d7c8f16497cc1c", b"z" * 65, b"ab" * 33, b"f" * 300, b"0123", b"e" * 449, b"z" * 500, b"5" * 64, b"9" * 65, b"c" * 448]
     rows = eng.transform_strings(es, seeds)
-    assert "1 input string(s) longer" not in eng.last_warning() and "2 input string(s) longer" in eng.last_warning()  # the two all-hex ones
-    assert [sum(k is not None for k in r) for r in rows] == [2, 0, 0, 0, 2]
-    assert rows[0] == [k for _, k in vko.electrum_keys(seeds[0], count=2)[1]]
+    assert eng.last_warning().startswith("warning: 1 input string(s) longer")  # the all-hex 449-byte one
+    assert [sum(k is not None for k in r) for r in rows] == [2, 0, 2, 2, 2, 0, 0, 2, 2, 2]
+    for i in (0, 2, 3, 4, 7, 8, 9):
+        assert rows[i] == [k for _, k in vko.electrum_keys(seeds[i], count=2)[1]], i
     st, _ = eng.scan_strings(es, seeds)
-    assert (st["inputs"], st["keys"]) == (5, 4) and st["warning"].startswith("warning: 2 ")
+    assert (st["inputs"], st["keys"]) == (10, 14) and st["warning"].startswith("warning: 1 ")
     rows = eng.transform_strings(es, seeds[:1])
     assert eng.last_warning() == ""
 

@@ -1,6 +1,6 @@
-"""The generated field arithmetic on a machine without a GPU: vuke_amd/csrc/vk_field.cuh compiled for the host with
-VK_HOST_EMU -- tools/gen_field.py writes every inline-asm statement a second time as calls into a one-lane instruction emulator
-(vk_field_gen_host.h) -- and held to python integers on the operands of the device's field test (every pair of edge values,
+"""The generated field arithmetic on a machine without a GPU: vuke_amd/csrc/vk_field.cuh compiled for the host with its
+primitive and generated headers swapped for tests/host_emu/ -- tools/gen_field.py writes every inline-asm statement a second time
+as calls into a one-lane instruction emulator (vk_field_gen_host.h, vk_field_prims_host.h) -- and held to python integers on the operands of the device's field test (every pair of edge values,
 all aliasing forms, the flagged and the exact reduction).  This checks the ARITHMETIC of the generated code (carry accounting,
 rare paths, operand order); hardware hazards and the compiler are what the GPU tests and tools/lint_coalescer.py check."""
 import filecmp
@@ -14,11 +14,12 @@ from tests.test_gpu_parity import P, field_cases
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "vuke_amd", "csrc")
+EMU = os.path.join(ROOT, "tests", "host_emu")
 
 
 def build(tmp_path, *defines):
     exe = tmp_path / ("emu" + "".join(defines).replace("=", "_").replace("-D", "_"))
-    cmd = ["g++", "-O1", "-std=c++17", "-Wno-unknown-pragmas", "-I", CSRC, *defines, "-o", str(exe), os.path.join(ROOT, "tests", "host_emu", "host_field_emu.cpp")]
+    cmd = ["g++", "-O1", "-std=c++17", "-Wno-unknown-pragmas", "-I", CSRC, "-I", EMU, *defines, "-o", str(exe), os.path.join(ROOT, "tests", "host_emu", "host_field_emu.cpp")]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
     return str(exe)
 
@@ -33,9 +34,12 @@ def run(exe, op, a, b):
 def test_generated_files_are_what_the_generator_writes(tmp_path):
     env = dict(os.environ, VK_GEN_OUT_DIR=str(tmp_path))
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_field.py")], check=True, env=env, capture_output=True)
-    for f in ("vk_field_gen.cuh", "vk_field_gen_host.h"):
-        assert filecmp.cmp(os.path.join(CSRC, f), str(tmp_path / f), shallow=False), f"{f} is stale: run tools/gen_field.py"
-    assert "asm(" not in open(os.path.join(CSRC, "vk_field_gen_host.h")).read()
+    for d, f in ((CSRC, "vk_field_gen.cuh"), (EMU, "vk_field_gen_host.h")):
+        assert filecmp.cmp(os.path.join(d, f), str(tmp_path / f), shallow=False), f"{f} is stale: run tools/gen_field.py"
+    assert "asm(" not in open(os.path.join(EMU, "vk_field_gen_host.h")).read()
+    # test infrastructure stays out of the kernel sources (and so out of the hash the PMC profiles are keyed on)
+    assert not os.path.exists(os.path.join(CSRC, "vk_field_gen_host.h"))
+    assert "HOST_EMU" not in open(os.path.join(CSRC, "vk_field.cuh")).read()
 
 
 @pytest.mark.parametrize("defines", [(), ("-DVK_REDUCE_FLAGS=0",)], ids=["flagged-reduction", "round1-reduction"])

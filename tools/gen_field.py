@@ -22,13 +22,15 @@ The C++ callers may alias result and operands freely: results are written only b
 """
 import os
 
-OUT_DIR = os.environ.get("VK_GEN_OUT_DIR", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vuke_amd", "csrc"))
-OUT = os.path.join(OUT_DIR, "vk_field_gen.cuh")
-OUT_HOST = os.path.join(OUT_DIR, "vk_field_gen_host.h")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the device header goes to the kernel sources, the host rendering (test infrastructure) under tests/: a change to the host
+# backend must not alter the hash of vuke_amd/csrc that the committed PMC profiles are keyed on (bench.csrc_hash)
+OUT = os.path.join(os.environ.get("VK_GEN_OUT_DIR", os.path.join(_ROOT, "vuke_amd", "csrc")), "vk_field_gen.cuh")
+OUT_HOST = os.path.join(os.environ.get("VK_GEN_OUT_DIR", os.path.join(_ROOT, "tests", "host_emu")), "vk_field_gen_host.h")
 
-# ---- second backend: the same statements as plain C++ for one lane (VK_HOST_EMU).  Every asm statement the generator emits is
+# ---- second backend: the same statements as plain C++ for one lane (tests/host_emu/).  Every asm statement the generator emits is
 # registered here with its operand tables; main() writes vk_field_gen_host.h = the gfx950 file with each statement replaced by
-# calls into a ten-instruction emulator (vk_field.cuh).  tests/test_host_field.py compiles the field layer that way with g++
+# calls into a ten-instruction emulator (tests/host_emu/vk_field_prims_host.h).  tests/test_host_field.py compiles the field layer that way with g++
 # and holds it to python integers on the edge operands of the GPU field test: the arithmetic of the generated code -- carry
 # accounting, flagged and exact paths, aliasing -- is checked on a machine without a GPU.  (Hardware hazards are not: those
 # are what the GPU tests and the coalescer lint are for.)
@@ -599,7 +601,7 @@ def main():
     txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_sqr_tail() + gen_addsub() + gen_sub3() + gen_reduce() + gen_reduce_fast() + gen_reduce_flags()
     open(OUT, "w").write(txt)
     print("wrote", OUT, len(txt.splitlines()), "lines")
-    host = txt.replace("// GENERATED by tools/gen_field.py -- do not edit.", "// GENERATED by tools/gen_field.py -- do not edit.  HOST form (VK_HOST_EMU): every asm statement of vk_field_gen.cuh as\n// calls into the one-lane instruction emulator of vk_field.cuh; test infrastructure, never part of the device build.", 1)
+    host = txt.replace("// GENERATED by tools/gen_field.py -- do not edit.", "// GENERATED by tools/gen_field.py -- do not edit.  HOST form: every asm statement of vuke_amd/csrc/vk_field_gen.cuh as\n// calls into the one-lane instruction emulator of vk_field_prims_host.h; test infrastructure, never part of the device build.", 1)
     n = 0
     for a, h in HOST.items():
         assert a in host, a[:200]

@@ -13,6 +13,7 @@ for cfg in $cfgs; do
     mkdir -p "$out"
     case "$cfg" in
         2) steps=3 ;; 3) steps=1 ;; 4) steps=2 ;; 5m) steps=3 ;; 5e) steps=1 ;;
+        *) echo "tools/profile.sh: unknown config '$cfg' (2 3 4 5m 5e)"; exit 2 ;;
     esac
     B="python3 bench.py --no-cpu-baseline --config $cfg"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- $B --steps $steps --warmup 0 > "$out/bench_stats.json" 2> "$out/stats.log"

@@ -11,16 +11,17 @@ typedef uint64_t u64;
 #define CHAINS 8
 #define UNROLL 8
 
-enum { ADD, XOR, MULLO, MULHI, MAD64, ALIGNBIT, ADD3, BFI, MAD24, MULHI24, FMA64, ADDC, LSHLADD, XAD, CNDMASK, PERM, CNDMASK_S, ADDC_S, MOV, MOV64, BITOP3, CMP, NOPS };
+enum { ADD, XOR, MULLO, MULHI, MAD64, ALIGNBIT, ADD3, BFI, MAD24, MULHI24, FMA64, ADDC, LSHLADD, XAD, CNDMASK, PERM, CNDMASK_S, ADDC_S, MOV, MOV64, BITOP3, CMP, LSHLADD64, ADDPAIR, NOPS };
 static const char *NAMES[NOPS] = {"v_add_u32", "v_xor_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_alignbit_b32",
                                   "v_add3_u32", "v_bfi_b32", "v_mad_u32_u24", "v_mul_hi_u32_u24", "v_fma_f64", "v_addc_co_u32",
                                   "v_lshl_add_u32", "v_xad_u32", "v_cndmask_b32", "v_perm_b32", "v_cndmask_b32 (sgpr mask)", "v_addc_co_u32 (sgpr carry)",
-                                  "v_mov_b32", "v_mov_b64", "v_bitop3_b32", "v_cmp_lt_u32"};
+                                  "v_mov_b32", "v_mov_b64", "v_bitop3_b32", "v_cmp_lt_u32", "v_lshl_add_u64", "v_add_co+v_addc_co (64-bit add, 2 instr)"};
 
 template <int OP>
-__global__ void __launch_bounds__(256) k(u64 *out, u32 seed, int iters)
+__global__ void __launch_bounds__(256) k(u64 *out, u32 seed, int iters, u32 live_lanes)
 {
     u32 t = blockIdx.x * 256 + threadIdx.x;
+    if ((threadIdx.x & 63u) >= live_lanes) return; // round 3: waves with EXEC = the low live_lanes lanes only
     u32 a[CHAINS], b[CHAINS];
     u64 c[CHAINS];
     double d[CHAINS];
@@ -61,6 +62,8 @@ __global__ void __launch_bounds__(256) k(u64 *out, u32 seed, int iters)
                 if (OP == MOV64) asm volatile("v_mov_b64 %0, %1" : "=v"(c[j]) : "v"(c[(j + 1) % CHAINS]));
                 if (OP == BITOP3) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a[j]) : "v"(b[j]));
                 if (OP == CMP) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a[j]), "v"(b[j]) : "vcc");
+                if (OP == LSHLADD64) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(c[j]) : "v"(c[(j + 1) % CHAINS]));
+                if (OP == ADDPAIR) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc" : "+v"(a[j]), "+v"(b[j]) : "v"(b[(j + 1) % CHAINS]) : "vcc");
             }
         }
     }
@@ -76,7 +79,7 @@ __global__ void __launch_bounds__(256) k(u64 *out, u32 seed, int iters)
 }
 
 template <int OP>
-static void run(int waves_per_simd, int cus, u64 *out)
+static void run(int waves_per_simd, int cus, u64 *out, u32 live_lanes = 64)
 {
     const int iters = 4000;
     // waves_per_simd waves on each SIMD: blocks of 256 threads = 4 waves = 1 per SIMD
@@ -84,10 +87,10 @@ static void run(int waves_per_simd, int cus, u64 *out)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<OP>, grid, block, 0, 0, out, 1u, 10);
+    hipLaunchKernelGGL(k<OP>, grid, block, 0, 0, out, 1u, 10, live_lanes);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<OP>, grid, block, 0, 0, out, 7u, iters);
+    hipLaunchKernelGGL(k<OP>, grid, block, 0, 0, out, 7u, iters, live_lanes);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -95,11 +98,13 @@ static void run(int waves_per_simd, int cus, u64 *out)
     u64 h[2];
     hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
     double ghz = (double)h[0] / ((double)h[1] / 100e6) / 1e9; // s_memrealtime ticks at 100 MHz
-    double wave_instr_per_wave = (double)iters * UNROLL * CHAINS;
+    double wave_instr_per_wave = (double)iters * UNROLL * CHAINS * (OP == ADDPAIR ? 2 : 1);
     double cyc_per_instr_per_simd = (double)h[0] / (wave_instr_per_wave * waves_per_simd);
     double lane_ops = (double)grid.x * 256 * wave_instr_per_wave;
-    printf("%-18s waves/SIMD=%d  %6.2f cyc/wave-instr/SIMD   %8.1f Tlane-ops/s   clk %.2f GHz  (%.2f ms)\n", NAMES[OP], waves_per_simd,
-           cyc_per_instr_per_simd, lane_ops / (ms * 1e-3) / 1e12, ghz, ms);
+    // wave-instructions per second per SIMD in shader cycles, from the wall time (the honest per-SIMD issue cost at this occupancy)
+    double wall_cyc = (ms * 1e-3) * ghz * 1e9 / (wave_instr_per_wave * waves_per_simd);
+    printf("%-18s waves/SIMD=%d live=%2u  %6.2f cyc/wave-instr/SIMD (wall %5.2f)  %8.1f Tlane-ops/s (64-lane equiv)  clk %.2f GHz  (%.2f ms)\n", NAMES[OP], waves_per_simd, live_lanes,
+           cyc_per_instr_per_simd, wall_cyc, lane_ops / (ms * 1e-3) / 1e12, ghz, ms);
 }
 
 template <int OP>
@@ -139,5 +144,15 @@ int main()
     sweep_occ<MOV64>(cus, out);
     sweep_occ<BITOP3>(cus, out);
     sweep_occ<CMP>(cus, out);
+    // round 3: 64-bit integer add as one instruction vs the carry pair (SHA-512 is 7 + 3 of them per round)
+    sweep_occ<LSHLADD64>(cus, out);
+    sweep_occ<ADDPAIR>(cus, out);
+    // round 3: does a wave whose EXEC holds only the low 32 / 16 lanes issue 16-lane-class VALU in fewer cycles?
+    for (u32 live : {64u, 32u, 16u}) {
+        for (int w : {1, 2, 4}) run<ALIGNBIT>(w, cus, out, live);
+        for (int w : {1, 2, 4}) run<MAD64>(w, cus, out, live);
+        for (int w : {1, 2, 4}) run<ADD>(w, cus, out, live);
+        printf("\n");
+    }
     return 0;
 }

@@ -63,7 +63,7 @@ EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
     "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
     "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_scan_strings", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
-    "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field",
+    "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop",
 ]
 
 _lib = None
@@ -105,6 +105,8 @@ def load():
     L.vk_slots_per_string.restype = u32
     L.vk_debug_table_entry.argtypes = [vp, u32, u32, vp]
     L.vk_debug_field.argtypes = [vp, C.c_int, cp, cp, sz, vp]
+    L.vk_debug_scratch.argtypes = [vp, C.c_int, sz, vp, sz]
+    L.vk_debug_chain_stop.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -255,6 +257,14 @@ class Engine:
             return rk, rv, dt
         return [[(rk[32 * (i * slots + s):32 * (i * slots + s) + 32] if rv[i * slots + s] else None) for s in range(slots)]
                 for i in range(n)]
+
+    def debug_chain_stop(self, stages):
+        self._chk(self._L.vk_debug_chain_stop(self._e, stages))
+
+    def debug_scratch(self, slot, offset, n):
+        out = C.create_string_buffer(n)
+        self._chk(self._L.vk_debug_scratch(self._e, slot, offset, out, n))
+        return out.raw
 
     def scan_keys(self, keys, flags=F_COMPRESSED | F_UNCOMPRESSED, hit_cap=4096):
         hits = (Hit * max(hit_cap, 1))()

@@ -1,4 +1,5 @@
-// vk_electrum.cuh -- Electrum v1 deterministic-wallet keys on gfx950, one seed string per lane.
+// vk_electrum.cuh -- Electrum v1 deterministic-wallet keys on gfx950, one seed string per lane, as three kernels around
+// the time-sliced stretch (vk_chain.cuh).
 //
 // Reference behaviour (src/electrum.rs:57-195, src/transform/electrum.rs:43-67):
 //   seed must be all ASCII hex digits, else the input is skipped;
@@ -7,147 +8,180 @@
 //   mpk = X || Y of master * G;
 //   seq_i = SHA256(SHA256("{i}:{0|1}:" || mpk)); skipped if seq_i >= n;
 //   key_i = master + seq_i mod n; skipped if zero.
-// The 100 000-round stretch dominates (2 x 10^5 compressions per seed against one k*G), so the
-// loop keeps the constant part of the message (seed bytes, padding, length) in registers and only
-// swaps the 8 chaining words; one-off message assembly uses a small per-lane byte buffer.
+//
+//   vk_electrum_prepare_kernel  hex check, x0, the constant tail of the stretch message (seed, padding, length)   (cold)
+//   vk_ring_kernel<electrum>    99 999 rounds in chunks: only the 8 chaining words change, the tail stays in registers (hot)
+//   vk_electrum_long_kernel     the same rounds for seeds of 65 .. 448 bytes (the reference accepts any length; such lines
+//                               are rare): tail words read from the staging slice every round, one lane per seed      (cold)
+//   vk_electrum_final_kernel    master * G, 20 sequence hashes, child keys                                         (cold, vk_chain_keys.cuh)
 #pragma once
-#include "vk_ec.cuh"
-#include "vk_hash.cuh"
-#include "vk_scalar.cuh"
+#include "vk_chain.cuh"
 
-#define VK_ELECTRUM_MAX_SEED 64 /* bytes; longer strings are rejected by the host entry point */
+#define VK_ELECTRUM_FAST_SEED 64 /* bytes: x || seed || padding then spans at most two SHA-256 blocks (register-resident tail) */
+#define VK_ELECTRUM_MAX_SEED 448 /* bytes: the staging slice minus padding */
 
-VK_DEV u32 load_be32(const unsigned char *p) { return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3]; }
-
-// SHA-256 of msg[0..len) (len <= 183) held in a lane-private byte buffer with room for padding
-VK_DEV void sha256_private(u32 out[8], unsigned char *buf, u32 len)
+// big-endian word i of the constant tail seed || 0x80 || 0.. || bit length of (32 + len) bytes; `last` = index of the length word
+VK_DEV u32 electrum_tail_word(const u64 *stage, u32 i, u32 len, u32 last)
 {
-    const u32 nblk = (len + 9 + 63) / 64;
-    for (u32 i = len; i < nblk * 64; i++) buf[i] = 0;
-    buf[len] = 0x80;
-    const u32 bits = len * 8;
-    buf[nblk * 64 - 4] = (unsigned char)(bits >> 24);
-    buf[nblk * 64 - 3] = (unsigned char)(bits >> 16);
-    buf[nblk * 64 - 2] = (unsigned char)(bits >> 8);
-    buf[nblk * 64 - 1] = (unsigned char)bits;
-    u32 st[8] = VK_SHA256_IV;
-#pragma unroll 1
-    for (u32 b = 0; b < nblk; b++) {
-        u32 w[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = load_be32(buf + 64 * b + 4 * i);
-        sha256_compress(st, w);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) out[i] = st[i];
+    u32 v = 4u * i < len ? stage_be32(stage, i) : 0;
+    const u32 rel = len - 4 * i; // bytes of the seed in this word, if 0..3: cut what follows off, set the 0x80 marker
+    if (rel - 1u < 3u) v &= 0xFFFFFFFFu << (32 - 8 * rel);
+    if (rel < 4u) v |= 0x80u << (24 - 8 * rel);
+    if (i == last) v |= (32 + len) * 8;
+    return v;
 }
 
-__global__ void __launch_bounds__(VK_BLOCK) vk_electrum_kernel(const unsigned char *__restrict__ data, const u32 *__restrict__ offs, u64 n,
-                                                                 u32 for_change, u32 count, u32 rounds, const uint4 *__restrict__ table,
-                                                                 const vk_win_desc *__restrict__ wins, u32 nwin, u32 *__restrict__ keys_out,
-                                                                 unsigned char *__restrict__ valid_out)
+// state of one group: 33 rows of 64 u32 -- x[8], tail words tw[24], flags (bit 0: the message has a second block)
+#define VK_EL_WORDS 33u
+
+__global__ void __launch_bounds__(VK_BLOCK) vk_electrum_prepare_kernel(const unsigned char *__restrict__ data, const u32 *__restrict__ offs, u64 n,
+                                                                         u64 *__restrict__ stage_all, u32 *__restrict__ state, unsigned char *__restrict__ ok_out)
 {
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
     if (idx >= n) return;
+    ok_out[idx] = 0;
     const u32 len = offs[idx + 1] - offs[idx];
+    if (len > VK_ELECTRUM_MAX_SEED) return;
     const unsigned char *seed = data + offs[idx];
-    unsigned char buf[192];
-    bool ok = len <= VK_ELECTRUM_MAX_SEED;
-    if (ok) {
-        for (u32 i = 0; i < len; i++) {
-            const unsigned char c = seed[i];
-            ok = ok && ((c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F')); // is_ascii_hexdigit
-            buf[i] = c;
-            buf[len + i] = c;
+    u64 *stage = stage_all + idx * VK_STAGE_WORDS;
+    vk_stage_writer wr;
+    wr.init(stage);
+    bool ok = true;
+    for (u32 i = 0; i < len; i++) {
+        const unsigned char c = seed[i];
+        ok = ok && ((c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F')); // is_ascii_hexdigit
+        wr.put(c, 1);
+    }
+    wr.finish();
+    if (!ok) return;
+    // ---- x0 = SHA256(seed || seed): the doubled string is read byte by byte from the input (its second copy is unaligned)
+    u32 x[8] = VK_SHA256_IV;
+    {
+        const u32 mlen = 2 * len, nblk = (mlen + 9 + 63) / 64;
+#pragma unroll 1
+        for (u32 b = 0; b < nblk; b++) {
+            u32 w[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                u32 v = 0;
+                for (u32 j = 0; j < 4; j++) {
+                    const u32 k = 64 * b + 4 * i + j;
+                    const u32 byte = k < mlen ? seed[k < len ? k : k - len] : (k == mlen ? 0x80u : 0u);
+                    v = (v << 8) | byte;
+                }
+                if (16 * b + i == 16 * nblk - 1) v |= mlen * 8;
+                w[i] = v;
+            }
+            sha256_compress(x, w);
         }
     }
-    u32 *kout = keys_out + idx * count * 8;
-    unsigned char *vout = valid_out + idx * count;
-    if (!ok) return; // outputs were zeroed by the host
-    // ---- stretch
-    u32 x[8];
-    sha256_private(x, buf, 2 * len);
-    // constant tail of the message x || seed || pad: words 8.. of block 1 and all of block 2
+    // constant tail of the message x || seed || pad: words 8.. of block 1 and, if it exists, all of block 2
     const bool two = (32 + len + 9) > 64;
-    for (u32 i = 0; i < 96; i++) buf[i] = 0;
-    for (u32 i = 0; i < len; i++) buf[i] = seed[i];
-    buf[len] = 0x80;
-    {
-        const u32 bits = (32 + len) * 8, end = two ? 96 : 32;
-        buf[end - 2] = (unsigned char)(bits >> 8);
-        buf[end - 1] = (unsigned char)bits;
-    }
-    u32 tw[24];
+    u32 *s = state + (idx >> 6) * (VK_EL_WORDS * 64) + (idx & 63u);
 #pragma unroll
-    for (int i = 0; i < 24; i++) tw[i] = load_be32(buf + 4 * i);
+    for (int i = 0; i < 8; i++) s[64 * i] = x[i];
+    if (len > VK_ELECTRUM_FAST_SEED) { // stretched by vk_electrum_long_kernel; the ring carries the lane along with a harmless tail
+#pragma unroll
+        for (int i = 0; i < 24; i++) s[64 * (8 + i)] = 0;
+        s[64 * 32] = 0;
+        ok_out[idx] = 2;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 24; i++) s[64 * (8 + i)] = electrum_tail_word(stage, i, len, two ? 23u : 7u);
+    s[64 * 32] = two ? 1u : 0u;
+    ok_out[idx] = 1;
+}
+
+struct vk_electrum_body {
+    struct args {
+        u32 *state;
+        u32 iters;       // rounds after x0 (99 999)
+        u32 chunk_iters;
+    };
+    static __device__ __forceinline__ void run(const args &a, u32 g, u32 c)
+    {
+        u32 *s = a.state + (u64)g * (VK_EL_WORDS * 64) + (threadIdx.x & 63u);
+        u32 x[8], tw[24];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = s[64 * i];
+#pragma unroll
+        for (int i = 0; i < 24; i++) tw[i] = s[64 * (8 + i)];
+        const bool two = s[64 * 32] != 0;
+        const u32 first = c * a.chunk_iters;
+        const u32 n = min(a.chunk_iters, a.iters - first);
+#pragma unroll 1
+        for (u32 r = 0; r < n; r++) {
+            u32 st[8] = VK_SHA256_IV;
+            u32 w[16];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                w[i] = x[i];
+                w[8 + i] = tw[i];
+            }
+            sha256_compress(st, w);
+            if (two) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) w[i] = tw[8 + i];
+                sha256_compress(st, w);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = st[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[64 * i] = x[i];
+    }
+};
+
+// Seeds of 65 .. 448 bytes: x0 is in the state (the ring has meanwhile stretched it with a wrong tail: recomputed from the
+// staged seed here).  One lane per such seed, all rounds in one go; launched only when the host saw one.
+__global__ void __launch_bounds__(VK_BLOCK) vk_electrum_long_kernel(const unsigned char *__restrict__ data, const u32 *__restrict__ offs, u64 n, u32 rounds,
+                                                                      const u64 *__restrict__ stage_all, u32 *__restrict__ state, unsigned char *__restrict__ ok)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    if (idx >= n || ok[idx] != 2) return;
+    const u32 len = offs[idx + 1] - offs[idx];
+    const unsigned char *seed = data + offs[idx];
+    const u64 *stage = stage_all + idx * VK_STAGE_WORDS;
+    u32 x[8] = VK_SHA256_IV;
+    { // x0 again (the state's copy was advanced by the ring)
+        const u32 mlen = 2 * len, nb0 = (mlen + 9 + 63) / 64;
+#pragma unroll 1
+        for (u32 b = 0; b < nb0; b++) {
+            u32 w[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                u32 v = 0;
+                for (u32 j = 0; j < 4; j++) {
+                    const u32 k = 64 * b + 4 * i + j;
+                    const u32 byte = k < mlen ? seed[k < len ? k : k - len] : (k == mlen ? 0x80u : 0u);
+                    v = (v << 8) | byte;
+                }
+                if (16 * b + i == 16 * nb0 - 1) v |= mlen * 8;
+                w[i] = v;
+            }
+            sha256_compress(x, w);
+        }
+    }
+    const u32 nblk = (32 + len + 9 + 63) / 64, last = 16 * nblk - 9; // tail word index of the length field
 #pragma unroll 1
     for (u32 r = 1; r < rounds; r++) {
         u32 st[8] = VK_SHA256_IV;
-        u32 w[16];
+#pragma unroll 1
+        for (u32 b = 0; b < nblk; b++) {
+            u32 w[16];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            w[i] = x[i];
-            w[8 + i] = tw[i];
-        }
-        sha256_compress(st, w);
-        if (two) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) w[i] = tw[8 + i];
+            for (int i = 0; i < 16; i++) {
+                if (b == 0 && i < 8) w[i] = x[i];
+                else w[i] = electrum_tail_word(stage, 16 * b + i - 8, len, last);
+            }
             sha256_compress(st, w);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) x[i] = st[i];
     }
-    // ---- master key: SecretKey::from_slice accepts 1 <= x < n only
-    u32 m[8];
+    u32 *s = state + (idx >> 6) * (VK_EL_WORDS * 64) + (idx & 63u);
 #pragma unroll
-    for (int i = 0; i < 8; i++) m[i] = x[7 - i];
-    if (!scalar_is_key(m)) return; // 0 or >= n
-    jac P;
-    ecmult_table(P, m, table, wins, nwin);
-    fe zi, ax, ay;
-    fe_inv(zi, P.z);
-    jac_to_affine(ax, ay, P, zi);
-    // ---- child keys
-#pragma unroll 1
-    for (u32 i = 0; i < count; i++) {
-        // "{i}:{c}:" || X || Y
-        u32 pl = 0;
-        {
-            unsigned char dig[10];
-            u32 v = i, nd = 0;
-            do {
-                dig[nd++] = (unsigned char)('0' + v % 10);
-                v /= 10;
-            } while (v);
-            while (nd) buf[pl++] = dig[--nd];
-            buf[pl++] = ':';
-            buf[pl++] = for_change ? '1' : '0';
-            buf[pl++] = ':';
-        }
-        for (int j = 0; j < 8; j++) {
-            const u32 wx = FE_BE(ax, j), wy = FE_BE(ay, j);
-            buf[pl + 4 * j] = (unsigned char)(wx >> 24);
-            buf[pl + 4 * j + 1] = (unsigned char)(wx >> 16);
-            buf[pl + 4 * j + 2] = (unsigned char)(wx >> 8);
-            buf[pl + 4 * j + 3] = (unsigned char)wx;
-            buf[pl + 32 + 4 * j] = (unsigned char)(wy >> 24);
-            buf[pl + 32 + 4 * j + 1] = (unsigned char)(wy >> 16);
-            buf[pl + 32 + 4 * j + 2] = (unsigned char)(wy >> 8);
-            buf[pl + 32 + 4 * j + 3] = (unsigned char)wy;
-        }
-        u32 d1[8], seq[8];
-        sha256_private(d1, buf, pl + 64);
-        sha256_of_digest(seq, d1);
-        // Scalar::from_be_bytes: seq must be < n (zero allowed)
-        u32 s[8], c[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = seq[7 - j];
-        if (!scalar_lt_n(s)) continue;
-        // child = master + seq mod n; a zero result is rejected by add_tweak
-        if (!scalar_add_mod_n(c, m, s)) continue;
-#pragma unroll
-        for (int j = 0; j < 8; j++) kout[i * 8 + j] = bswap32(c[7 - j]);
-        vout[i] = 1;
-    }
+    for (int i = 0; i < 8; i++) s[64 * i] = x[i];
+    ok[idx] = 1;
 }

@@ -7,6 +7,7 @@
 #include "vk_sweep_launch.h"
 #include "vk_electrum.cuh"
 #include "vk_multibit.cuh"
+#include "vk_chain_keys.cuh"
 #include "vk_search.cuh"
 
 #include <algorithm>
@@ -33,8 +34,11 @@ struct vk_engine {
     u32 algo = 0;          // VK_ALGO_CHAIN / VK_ALGO_TREE (signed9 only)
     vk_win_desc wins[VK_MAX_WIN];
     u64 table_entries = 0;
-    u64 *d_wordlist = nullptr;     // BIP-39 list, 2048 x 8 bytes (vk_bip39_wordlist_set)
-    vk_mb_pass mb_pass = {};       // BIP-39 passphrase of the multibit chain (vk_multibit_passphrase_set; empty by default)
+    u64 *d_wordlist = nullptr;     // BIP-39 list, 2048 x 8 bytes (vk_bip39_wordlist_set), then the same words as an open-addressed set
+    u64 *d_mb_salt = nullptr;      // PBKDF2 salt message of the multibit chain, ready-padded blocks (vk_multibit_passphrase_set; "" by default)
+    u32 mb_salt_nblk = 0;
+    int ring_waves_per_simd = 0;   // resident worker waves per SIMD of the chain ring (occupancy query, once)
+    int chain_stop = 99;           // vk_debug_chain_stop
     vk_win_desc *d_wins = nullptr; // device copy of wins (kernels that take the layout by pointer)
     double table_build_seconds = 0.0;
     u32 batch = 128;
@@ -50,8 +54,9 @@ struct vk_engine {
     size_t work_bytes = 0;
     // device scratch for the batch entry points (inputs / outputs of one call), kept between calls: a hipMalloc +
     // hipFree pair per buffer per call cost more than the kernel for batches of a few hundred keys
-    void *scr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scr_cap[6] = {0, 0, 0, 0, 0, 0};
+    // slots 0-5: inputs / outputs; 6-9: the key-derivation chains (staging slices, chain state, validity, ring)
+    void *scr[10] = {};
+    size_t scr_cap[10] = {};
     std::mutex mu;
     std::string err;
 };
@@ -183,6 +188,7 @@ extern "C" void vk_engine_destroy(vk_engine *e)
     if (e->work) (void)hipFree(e->work);
     if (e->d_wins) (void)hipFree(e->d_wins);
     if (e->d_wordlist) (void)hipFree(e->d_wordlist);
+    if (e->d_mb_salt) (void)hipFree(e->d_mb_salt);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -759,9 +765,30 @@ extern "C" int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words)
                 return fail(e, VK_E_INVALID_ARG, "BIP-39 words must be zero padded and free of whitespace");
         }
     }
+    // the same words as an open-addressed set for validate_mnemonic (vk_multibit.cuh: wordset_has)
+    std::vector<u64> set(VK_WORDSET_SLOTS, 0);
+    for (int i = 0; i < 2048; i++) {
+        u64 w;
+        memcpy(&w, words + 8 * i, 8);
+        u32 h = (u32)((w * 0x9E3779B97F4A7C15ull) >> 52);
+        while (set[h] != 0 && set[h] != w) h = (h + 1) & (VK_WORDSET_SLOTS - 1);
+        set[h] = w;
+    }
     HIPCHK(e, hipSetDevice(e->device));
-    if (!e->d_wordlist) HIPCHK(e, hipMalloc(&e->d_wordlist, 2048 * 8));
+    if (!e->d_wordlist) HIPCHK(e, hipMalloc(&e->d_wordlist, (2048 + VK_WORDSET_SLOTS) * 8));
     HIPCHK(e, hipMemcpy(e->d_wordlist, words, 2048 * 8, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->d_wordlist + 2048, set.data(), VK_WORDSET_SLOTS * 8, hipMemcpyHostToDevice));
+    return VK_OK;
+}
+
+static int set_mb_salt(vk_engine *e, const uint8_t *pass, size_t len)
+{
+    u64 w[VK_SALT_WORDS];
+    const u32 nblk = vk_salt_blocks(w, pass, len);
+    HIPCHK(e, hipSetDevice(e->device));
+    if (!e->d_mb_salt) HIPCHK(e, hipMalloc(&e->d_mb_salt, sizeof w));
+    HIPCHK(e, hipMemcpy(e->d_mb_salt, w, sizeof w, hipMemcpyHostToDevice));
+    e->mb_salt_nblk = nblk;
     return VK_OK;
 }
 
@@ -771,9 +798,53 @@ extern "C" int vk_multibit_passphrase_set(vk_engine *e, const uint8_t *passphras
     std::lock_guard<std::mutex> lk(e->mu);
     if (len && !passphrase) return fail(e, VK_E_INVALID_ARG, "passphrase is NULL");
     if (len > VK_MULTIBIT_MAX_PASS) return fail(e, VK_E_UNSUPPORTED, "multibit passphrase longer than 96 bytes");
-    memset(&e->mb_pass, 0, sizeof e->mb_pass);
-    e->mb_pass.len = (u32)len;
-    if (len) memcpy(e->mb_pass.b, passphrase, len);
+    return set_mb_salt(e, passphrase, len);
+}
+
+// One stretch of a key-derivation chain through the ring of vk_chain.cuh: `groups` groups of 64 inputs, `iters` iterations
+// in chunks of `chunk_iters`.  Workers <= groups: with no more workers than groups a pop never waits.
+template <class Body>
+static int run_ring(vk_engine *e, u32 groups, u32 iters, u32 chunk_iters, typename Body::args a)
+{
+    if (groups == 0 || iters == 0) return VK_OK;
+    if (const char *v = getenv("VUKE_RING_CHUNK")) chunk_iters = std::max(1, atoi(v));
+    const u32 chunks = (iters + chunk_iters - 1) / chunk_iters;
+    if ((u64)groups * chunks >= (1ull << 32)) return fail(e, VK_E_INVALID_ARG, "too many chain chunks for one call");
+    u32 nslots = 1;
+    while (nslots < 2 * groups) nslots <<= 1;
+    const size_t bytes = sizeof(vk_ring) + (size_t)nslots * 8 + (size_t)groups * 4;
+    SCRATCH(e, ring_mem, unsigned char *, 9, bytes);
+    vk_ring *ring = (vk_ring *)ring_mem;
+    unsigned long long *slots = (unsigned long long *)(ring_mem + sizeof(vk_ring));
+    u32 *chunk_done = (u32 *)(ring_mem + sizeof(vk_ring) + (size_t)nslots * 8);
+    if (!e->ring_waves_per_simd) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, vk_ring_kernel<vk_pbkdf2_body>, 256, 0) != hipSuccess || nb < 1) nb = 1;
+        int ne = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ne, vk_ring_kernel<vk_electrum_body>, 256, 0) != hipSuccess || ne < 1) ne = 1;
+        e->ring_waves_per_simd = std::max(1, std::min(nb, ne)); // a 256-thread block is one wave on each SIMD of its CU
+    }
+    // Workers: as many waves per SIMD as keep EVERY worker busy (workers <= groups) and every SIMD equally loaded -- a whole
+    // number of waves per SIMD.  Measured (tools/probe_ring.py, profiles/r03_ring_probe.txt): at the config's 100 000 inputs
+    // = 1 563 groups, 1 024 workers (one per SIMD) finish in 84 ms / 609 ms (MultiBit / Electrum); 1 563 workers take 108 /
+    // 737 ms (the dispatcher doubles some CUs up and leaves others with one wave, and the doubled ones set the time) and 2 048
+    // workers 93 / 639 ms (a quarter of them spin for a group at any time).
+    int wps = e->ring_waves_per_simd;
+    if (const char *v = getenv("VUKE_RING_WAVES_PER_SIMD")) wps = std::max(1, std::min(wps, atoi(v)));
+    const u32 simds = (u32)e->cu_count * 4u;
+    const u32 per_simd = std::max(1u, std::min((u32)wps, groups / simds));
+    u32 workers = groups < simds ? groups : simds * per_simd;
+    const u32 resident = simds * (u32)wps;
+    if (const char *v = getenv("VUKE_RING_WORKERS")) workers = std::max(1u, std::min((u32)atoi(v), resident)); // experiments: may exceed groups
+    a.iters = iters;
+    a.chunk_iters = chunk_iters;
+    hipLaunchKernelGGL(vk_ring_init_kernel, dim3((nslots + 255) / 256), dim3(256), 0, e->stream, ring, slots, chunk_done, groups, chunks, nslots);
+    hipLaunchKernelGGL(vk_ring_kernel<Body>, dim3((workers + 3) / 4), dim3(256), 0, e->stream, ring, slots, chunk_done, chunks, a);
+    HIPCHK(e, hipGetLastError());
+    vk_ring h;
+    HIPCHK(e, hipMemcpyAsync(&h, ring, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (h.error || h.head < h.total) return fail(e, VK_E_HIP, "the chain ring stalled (a bounded wait ran out): internal error");
     return VK_OK;
 }
 
@@ -786,9 +857,11 @@ static int strings_to_device_keys(vk_engine *e, const vk_transform_spec *t, cons
     const bool kdf = t->kind == VK_T_ELECTRUM || t->kind == VK_T_MULTIBIT;
     const u32 max_len = t->kind == VK_T_MULTIBIT ? VK_MULTIBIT_MAX_MNEMONIC : kdf ? VK_ELECTRUM_MAX_SEED : 0x7FFFFFFFu;
     *overlong = 0;
+    size_t n_long = 0; // electrum seeds beyond the register-resident fast path
     for (size_t i = 0; i < n; i++) {
         if (offsets[i + 1] < offsets[i]) return fail(e, VK_E_INVALID_ARG, "offsets must be non-decreasing");
         const u32 len = offsets[i + 1] - offsets[i];
+        if (t->kind == VK_T_ELECTRUM && len > VK_ELECTRUM_FAST_SEED && len <= VK_ELECTRUM_MAX_SEED) n_long++;
         if (len > max_len) {
             // ElectrumTransform::apply_batch drops every non-hex string itself (src/transform/electrum.rs:49-52): only an
             // over-long string of hex digits is a key the reference would have produced and this path does not
@@ -811,18 +884,54 @@ static int strings_to_device_keys(vk_engine *e, const vk_transform_spec *t, cons
     if (c == hipSuccess) c = hipMemsetAsync(d_keys, 0, items * 32, e->stream);
     if (c == hipSuccess) c = hipMemsetAsync(d_valid, 0, items, e->stream);
     if (c == hipSuccess) c = hipEventRecord(e->ev0, e->stream);
-    if (c == hipSuccess) {
-        if (!kdf)
-            hipLaunchKernelGGL(vk_strings_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, to_dev(t), d_data, d_offs,
-                               (u64)n, slots, d_keys, d_valid, vk_ec_ctx{e->table, e->d_wins, e->nwin});
-        else if (t->kind == VK_T_MULTIBIT)
-            hipLaunchKernelGGL(vk_multibit_kernel, dim3((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_data, d_offs, (u64)n,
-                               t->chain_depth, e->d_wordlist, e->table, e->d_wins, e->nwin, d_keys, d_valid, e->mb_pass);
-        else
-            hipLaunchKernelGGL(vk_electrum_kernel, dim3((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_data, d_offs, (u64)n,
-                               t->variant, t->chain_depth, 100000u, e->table, e->d_wins, e->nwin, d_keys, d_valid);
-        c = hipGetLastError();
+    if (c != hipSuccess) {
+        e->err = std::string("string transform on the device: ") + hipGetErrorString(c);
+        return VK_E_HIP;
     }
+    const dim3 grid((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), block(VK_BLOCK);
+    const u32 groups = (u32)((n + 63) / 64);
+    if (!kdf) {
+        hipLaunchKernelGGL(vk_strings_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), block, 0, e->stream, to_dev(t), d_data, d_offs, (u64)n, slots,
+                           d_keys, d_valid, vk_ec_ctx{e->table, e->d_wins, e->nwin});
+    } else if (t->kind == VK_T_MULTIBIT) {
+        // prepare -> 2047 HMAC iterations -> 48 words, prepare again -> 2047 iterations -> master key and children
+        if (!e->d_mb_salt) {
+            const int rc = set_mb_salt(e, nullptr, 0);
+            if (rc) return rc;
+        }
+        SCRATCH(e, d_stage, u64 *, 6, n * VK_STAGE_BYTES);
+        SCRATCH(e, d_state, u64 *, 7, (size_t)groups * VK_PB_WORDS * 64 * 8);
+        SCRATCH(e, d_ok, unsigned char *, 8, n);
+        const u64 *wordset = e->d_wordlist + 2048;
+        hipLaunchKernelGGL(vk_mb_prepare_kernel, grid, block, 0, e->stream, d_data, d_offs, (u64)n, wordset, e->d_mb_salt, e->mb_salt_nblk, d_stage, d_state, d_ok);
+        vk_pbkdf2_body::args a = {d_state, 0, 0};
+        const int stop = e->chain_stop; // test hook (vk_debug_chain_stop): leave the chain after this many of its five kernels
+        if (stop <= 1) goto chain_done;
+        int rc;
+        rc = run_ring<vk_pbkdf2_body>(e, groups, 2047, 64, a);
+        if (rc) return rc;
+        if (stop <= 2) goto chain_done;
+        hipLaunchKernelGGL(vk_mb_middle_kernel, grid, block, 0, e->stream, (u64)n, e->d_wordlist, e->d_mb_salt, e->mb_salt_nblk, d_stage, d_state, d_ok);
+        if (stop <= 3) goto chain_done;
+        rc = run_ring<vk_pbkdf2_body>(e, groups, 2047, 64, a);
+        if (rc) return rc;
+        if (stop <= 4) goto chain_done;
+        hipLaunchKernelGGL(vk_mb_final_kernel, grid, block, 0, e->stream, (u64)n, t->chain_depth, d_state, d_ok, e->table, e->d_wins, e->nwin, d_keys, d_valid);
+    } else {
+        SCRATCH(e, d_stage, u64 *, 6, n * VK_STAGE_BYTES);
+        SCRATCH(e, d_state, u32 *, 7, (size_t)groups * VK_EL_WORDS * 64 * 4);
+        SCRATCH(e, d_ok, unsigned char *, 8, n);
+        hipLaunchKernelGGL(vk_electrum_prepare_kernel, grid, block, 0, e->stream, d_data, d_offs, (u64)n, d_stage, d_state, d_ok);
+        vk_electrum_body::args a = {d_state, 0, 0};
+        const int rc = run_ring<vk_electrum_body>(e, groups, 100000u - 1u, 500, a);
+        if (rc) return rc;
+        if (n_long) // seeds of 65 .. 448 bytes: rare, stretched one lane each outside the ring
+            hipLaunchKernelGGL(vk_electrum_long_kernel, grid, block, 0, e->stream, d_data, d_offs, (u64)n, 100000u, d_stage, d_state, d_ok);
+        hipLaunchKernelGGL(vk_electrum_final_kernel, grid, block, 0, e->stream, (u64)n, t->variant, t->chain_depth, d_state, d_ok, d_stage, e->table, e->d_wins,
+                           e->nwin, d_keys, d_valid);
+    }
+chain_done:
+    c = hipGetLastError();
     if (c == hipSuccess) c = hipEventRecord(e->ev1, e->stream);
     if (c == hipSuccess) c = hipStreamSynchronize(e->stream);
     float ms = 0.f;
@@ -842,7 +951,7 @@ static void note_overlong(vk_engine *e, const vk_transform_spec *t, size_t overl
     e->err.clear();
     if (overlong)
         e->err = "warning: " + std::to_string(overlong) + " input string(s) longer than the device limit (" +
-                 (t->kind == VK_T_MULTIBIT ? "multibit 256" : "electrum 64") + " bytes) produced no keys";
+                 "448 bytes) produced no keys";
 }
 
 extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
@@ -937,6 +1046,14 @@ extern "C" int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy, size_t n_f
     vk_bip32_path pd = {};
     pd.depth = depth;
     for (u32 i = 0; i < depth; i++) pd.comp[i] = path[i];
+    // salt message of every passphrase, ready-padded (pass_data may be NULL when every passphrase is empty)
+    std::vector<u64> salts(n_pass * VK_SALT_WORDS);
+    std::vector<u32> nblk(n_pass);
+    for (size_t j = 0; j < n_pass; j++) {
+        const size_t pl = pass_offsets[j + 1] - pass_offsets[j];
+        if (pl && !pass_data) return fail(e, VK_E_INVALID_ARG, "pass_data is NULL");
+        nblk[j] = vk_salt_blocks(&salts[j * VK_SALT_WORDS], pl ? pass_data + pass_offsets[j] : nullptr, pl);
+    }
     HIPCHK(e, hipSetDevice(e->device));
     const size_t pbytes = pass_offsets[n_pass], outs = (size_t)(items * count);
     SCRATCH(e, d_pass, unsigned char *, 0, pbytes + 1);
@@ -953,9 +1070,24 @@ extern "C" int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy, size_t n_f
     if (c == hipSuccess) c = hipMemcpy(d_ent, entropy, n_files * 32, hipMemcpyHostToDevice);
     if (c == hipSuccess) c = hipMemsetAsync(d_keys, 0, outs * 32, e->stream);
     if (c == hipSuccess) c = hipMemsetAsync(d_valid, 0, outs, e->stream);
-    if (c == hipSuccess) {
-        hipLaunchKernelGGL(vk_bitimage_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, d_ent, items, d_pass, d_offs,
-                           (u32)n_pass, pd, count, e->d_wordlist, e->table, e->d_wins, e->nwin, d_keys, d_valid);
+    if (c != hipSuccess) {
+        e->err = std::string("vk_bitimage_keys: ") + hipGetErrorString(c);
+        return VK_E_HIP;
+    }
+    {
+        const dim3 grid((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), block(VK_BLOCK);
+        const u32 groups = (u32)((items + 63) / 64);
+        SCRATCH(e, d_stage, u64 *, 6, (size_t)items * VK_STAGE_BYTES);
+        SCRATCH(e, d_state, u64 *, 7, (size_t)groups * VK_PB_WORDS * 64 * 8);
+        SCRATCH(e, d_salts, u64 *, 8, n_pass * (VK_SALT_WORDS * 8 + 4));
+        u32 *d_nblk = (u32 *)(d_salts + n_pass * VK_SALT_WORDS);
+        HIPCHK(e, hipMemcpy(d_salts, salts.data(), n_pass * VK_SALT_WORDS * 8, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(d_nblk, nblk.data(), n_pass * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(vk_bitimage_prepare_kernel, grid, block, 0, e->stream, d_ent, items, (u32)n_pass, e->d_wordlist, d_salts, d_nblk, d_stage, d_state);
+        vk_pbkdf2_body::args a = {d_state, 0, 0};
+        const int rc = run_ring<vk_pbkdf2_body>(e, groups, 2047, 64, a);
+        if (rc) return rc;
+        hipLaunchKernelGGL(vk_bitimage_final_kernel, grid, block, 0, e->stream, items, pd, count, d_state, e->table, e->d_wins, e->nwin, d_keys, d_valid);
         c = hipGetLastError();
     }
     if (c == hipSuccess) c = hipStreamSynchronize(e->stream);
@@ -1144,6 +1276,24 @@ extern "C" int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digi
         xy[4 * i] = (uint8_t)(xv >> 24); xy[4 * i + 1] = (uint8_t)(xv >> 16); xy[4 * i + 2] = (uint8_t)(xv >> 8); xy[4 * i + 3] = (uint8_t)xv;
         xy[32 + 4 * i] = (uint8_t)(yv >> 24); xy[32 + 4 * i + 1] = (uint8_t)(yv >> 16); xy[32 + 4 * i + 2] = (uint8_t)(yv >> 8); xy[32 + 4 * i + 3] = (uint8_t)yv;
     }
+    return VK_OK;
+}
+
+extern "C" int vk_debug_chain_stop(vk_engine *e, int stages)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->chain_stop = stages <= 0 ? 99 : stages;
+    return VK_OK;
+}
+
+extern "C" int vk_debug_scratch(vk_engine *e, int slot, size_t offset, uint8_t *out, size_t n)
+{
+    if (!e || !out) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (slot < 0 || slot >= 10 || !e->scr[slot] || offset + n > e->scr_cap[slot]) return fail(e, VK_E_INVALID_ARG, "vk_debug_scratch: slot / range");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpy(out, (const unsigned char *)e->scr[slot] + offset, n, hipMemcpyDeviceToHost));
     return VK_OK;
 }
 

@@ -392,13 +392,13 @@ void Transform::apply_batch(vk_engine *e, const std::vector<std::string> &inputs
 {
     const uint32_t k = string_slots();
     if (inputs.empty() || k == 0) return; // k == 0: a transform that needs Input::u64_val pushes nothing
-    // strings the device entry point cannot take (longer than 64 bytes) can still be valid hex seeds in the
+    // strings the device entry point cannot take (longer than 448 bytes) can still be valid hex seeds in the
     // reference; they are reported, not silently dropped
     std::vector<uint8_t> data;
     std::vector<uint32_t> offs{0};
     for (const std::string &s : inputs) {
-        if (takes_strings() && s.size() > (spec_.kind == VK_T_MULTIBIT ? 256u : 64u))
-            throw std::invalid_argument("input string too long for the device path (electrum 64, multibit 256 bytes)");
+        if (takes_strings() && s.size() > 448u)
+            throw std::invalid_argument("input string too long for the device path (electrum and multibit: 448 bytes)");
         data.insert(data.end(), s.begin(), s.end());
         offs.push_back((uint32_t)data.size());
     }
