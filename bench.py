@@ -380,7 +380,6 @@ def main():
     ap.add_argument("--strong", action="store_true", help="config 2: N ranks share one 2^32 sweep; also report end-to-end wall time")
     ap.add_argument("--emulate-gpus", type=int, default=0, help="--strong on one GPU: sweep only this rank-0 share of an M-GPU run (16/M blocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--algo", type=int, default=0, help="0 = XYZZ chain (default), 1 = VK_ALGO_TREE (experimental, see DESIGN.md section 8)")
     # rehearsal knobs (not used by the driver): run the N-rank path on a box with fewer GPUs than ranks
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal)")
     ap.add_argument("--share-device", type=int, default=-1, help="put every rank on this one GPU (rehearsal only)")
@@ -452,7 +451,7 @@ def main():
     sync()
     t_wall0 = time.perf_counter()
     try:
-        eng = vuke_amd.Engine(local_rank, window_bits=args.window_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=args.layout, algo=args.algo)
+        eng = vuke_amd.Engine(local_rank, window_bits=args.window_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=args.layout)
     except vuke_amd.VkError as exc:
         if args.layout == 0 or exc.code != ffi.VK_E_HIP:
             raise

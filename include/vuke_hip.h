@@ -121,9 +121,8 @@ typedef struct vk_engine vk_engine;
 #define VK_LAYOUT_SIGNED9 1u /* 9 signed-digit windows (4 x 29 + 5 x 28 bits): 8 additions per key, 120 GB table */
 
 /* summation of the table points */
-#define VK_ALGO_CHAIN 0u /* one Jacobian chain: 8 additions, 90 field multiplications per key */
-#define VK_ALGO_TREE 1u  /* first tree level as four affine additions under a second batch inversion: 70 multiplications per key,
-                            17 cooperative table reads instead of 9; built for milksad, lcg and raw keys, other kinds use the chain */
+#define VK_ALGO_CHAIN 0u /* one chain of additions: the first two table points in affine form, then an XYZZ accumulator */
+/* (1 was VK_ALGO_TREE in ABI versions 1-2: removed in round 3 -- vk_engine_create_ex answers VK_E_UNSUPPORTED) */
 
 typedef struct vk_engine_opts {
     uint32_t window_bits;  /* fixed-base window width of the k*G table: 4..26 (0 = default 24: 11.8 GB) */
@@ -133,7 +132,7 @@ typedef struct vk_engine_opts {
                               tiles are handed out dynamically, so the value only sizes the grid and the workspace */
     uint32_t layout;       /* VK_LAYOUT_*: 0 = uniform unsigned window_bits-wide windows (default) */
     void *stream;          /* hipStream_t to run on (NULL = engine creates its own) */
-    uint32_t algo;         /* VK_ALGO_*: how the nine table points of a key are summed (layout VK_LAYOUT_SIGNED9 only) */
+    uint32_t algo;         /* VK_ALGO_CHAIN (0); other values are rejected */
     uint32_t _pad;
 } vk_engine_opts;
 
@@ -176,6 +175,16 @@ int vk_sweep(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_
 int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_t seed_hi_inclusive,
                 uint32_t flags, uint8_t *privkeys /* n*32 */, uint8_t *h160_c /* n*20 */,
                 uint8_t *h160_u /* n*20 */, uint8_t *valid /* n */, vk_sweep_stats *out);
+
+/* RangeSource::process in generate mode as ConsoleOutput's compact format writes it (src/output/console.rs:77-81,
+ * src/source/range.rs:42-70): for every (input, slot) the reference emits, in input-major order, the line
+ *     {input}{slot_suffix[slot]},{transform_name},{private key, 64 hex digits},{P2PKH address of the compressed key}\n
+ * -- decimal input, hex, Base58Check (two SHA-256) and the line itself are produced on the device; the host only writes the
+ * text.  slot_suffix = vk_slots_per_input(t) strings (NULL = all empty): what Transform::apply_batch appends to the input's
+ * decimal string in the label of that slot (src/transform/lcg.rs:54-66, xorshift.rs:43-47, sha256_chain.rs:67); suffixes and
+ * transform_name are at most 31 bytes.  At most 2^21 (input, slot) pairs per call; text_cap >= 192 bytes per pair. */
+int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_t seed_hi_inclusive, const char *transform_name,
+                      const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out);
 
 /* KeyDeriver::derive for callers that already hold keys (wordlist / stdin sources): raw 32-byte
  * keys in, normalised keys and hash160s out.  Any output pointer may be NULL. */

@@ -748,37 +748,61 @@ def test_search_over_hash_transforms(eng, vko):
         eng.search(ffi.spec(ffi.T_SHA256), 0, 10, cascade=[(8, 0x80), (8, 0x81)])
 
 
-def test_tree_summation_algo(vko):
-    """VK_ALGO_TREE (vk_sweep_tree_kernel): first tree level of the table sum in affine coordinates under a second batch
-    inversion, quad-cooperative table reads.  Same counters, digest and hits as the oracle, for every launch shape."""
-    import vuke_amd
+def test_generate_lines_on_the_device_equal_the_oracles_text(eng, vko):
+    """vk_generate_lines (compact CSV text made on the device: decimal label + slot suffix, hex, Base58Check, line assembly,
+    prefix-sum compaction) against the oracle's records, for every label shape the range source has (src/transform/lcg.rs:54-66,
+    xorshift.rs:43-47, sha256_chain.rs:67), around seed ceilings (lines missing where the reference emits nothing), for 1- to
+    20-digit inputs and hash160s with leading zero bytes."""
     from vuke_amd import _ffi as ffi
-    e = vuke_amd.Engine(0, layout=1, algo=1, batch=64, blocks_per_cu=2)
-    try:
-        cases = [(ffi.T_MILKSAD, vko.T_MILKSAD, 0, 0), (ffi.T_MILKSAD, vko.T_MILKSAD, 5000, 5000 + 8191), (ffi.T_MILKSAD, vko.T_MILKSAD, 123, 123 + 70000),
-                 (ffi.T_MILKSAD, vko.T_MILKSAD, 2**32 - 300, 2**32 + 100), (ffi.T_LCG, vko.T_LCG, 2**31 - 500, 2**31 + 500), (ffi.T_LCG, vko.T_LCG, 0, 3000)]
-        for gk, ok, lo, hi in cases:
-            for flags in (1, 3):
-                st, _ = e.sweep(ffi.spec(gk), lo, hi, flags=flags)
-                ost, _ = vko.sweep(vko.spec(ok), lo, hi, flags=flags, nthreads=8)
-                assert (st["inputs"], st["keys"], st["digest"]) == (ost["inputs"], ost["keys"], ost["digest"]), (gk, lo, hi, flags)
-        # raw keys incl. the edge scalars (zero digits in every position, top-window special entry)
-        rnd = random.Random(5)
-        keys = [be(1), be(2), be(N - 1), be(N - 2), be(2**255), be(2**256 - 2**228 - 1), be(2**29), be(2**58 + 1), be(1 << 228), be((1 << 116) - 1), CHBS]
-        keys += [be(1 << i) for i in range(0, 256, 7)] + [be((1 << i) - 1) for i in range(1, 256, 11)] + [be(rnd.getrandbits(256) % N or 1) for _ in range(200)]
-        norm, hc, hu = e.derive_batch(keys)
-        for k, n, c, u in zip(keys, norm, hc, hu):
-            d = vko.derive(k)
-            assert (n, c, u) == (bytes(d.raw), bytes(d.h160_c), bytes(d.h160_u)), k.hex()
-        # planted hits
-        planted = [7, 4096, 65535, 70001]
-        d = [vko.derive(vko.milksad_key(s)) for s in planted]
-        e.targets_set([bytes(x.h160_c) for x in d], [0] * len(d))
-        st, hits = e.sweep(ffi.spec(ffi.T_MILKSAD), 0, 80000, flags=1)
-        e.targets_set([], [])
-        assert st["matches"] == 4 and [h["seed"] for h in hits] == planted
-    finally:
-        e.close()
+    LCG, XS, CH = ("glibc", "minstd", "msvc", "borland"), ("64", "128", "128plus", "128starstar"), ("iterated", "indexed:be", "indexed:le", "counter")
+    cases = [
+        (ffi.spec(ffi.T_SHA256), vko.spec(vko.T_SHA256), "sha256", [""] * 3, [(0, 300), (999_990, 1_000_010), (2**64 - 40, 2**64 - 1)]),
+        (ffi.spec(ffi.T_MILKSAD), vko.spec(vko.T_MILKSAD), "milksad", [""], [(2**32 - 100, 2**32 + 50), (7, 7)]),
+        (ffi.spec(ffi.T_LCG), vko.spec(vko.T_LCG), "lcg", [":" + n for n in LCG], [(2**31 - 100, 2**31 + 100), (0, 64)]),
+        (ffi.spec(ffi.T_LCG, 2, 1), vko.spec(vko.T_LCG, 2, 1), "lcg", [""], [(12345, 12400)]),
+        (ffi.spec(ffi.T_LCG, ffi.VARIANT_ALL, 1), vko.spec(vko.T_LCG, vko.VARIANT_ALL, 1), "lcg", [":" + n + ":le" for n in LCG], [(5, 40)]),
+        (ffi.spec(ffi.T_XORSHIFT), vko.spec(vko.T_XORSHIFT), "xorshift", [":" + n for n in XS], [(0, 50)]),
+        (ffi.spec(ffi.T_SHA256_CHAIN, ffi.VARIANT_ALL, 0, 3), vko.spec(vko.T_SHA256_CHAIN, vko.VARIANT_ALL, 0, 3), "sha256_chain",
+         [f"[{v}:{i}]" for _ in range(2) for v in CH for i in range(3)], [(2**32 - 20, 2**32 + 20), (0, 30)]),
+        (ffi.spec(ffi.T_MD5), vko.spec(vko.T_MD5), "md5", [""], [(0, 100)]),
+    ]
+    for gs, osp, name, suffix, ranges in cases:
+        slots = vko.slots_per_input(osp)
+        assert slots == len(suffix)
+        for lo, hi in ranges:
+            text, st = eng.generate_lines(gs, lo, hi, name, suffix)
+            want = []
+            for seed in range(lo, hi + 1):
+                for sub in range(slots):
+                    k = vko.transform_key(osp, seed, sub)
+                    if k is None:
+                        continue
+                    d = vko.derive(k)
+                    want.append(f"{seed}{suffix[sub]},{name},{d.private_key_hex.decode()},{d.p2pkh_compressed.decode()}")
+            assert text.decode().splitlines() == want, (name, lo, hi)
+            assert text.endswith(b"\n") and st["keys"] == len(want)
+    # hash160s with leading zero bytes (one '1' per zero byte of the payload): found with the device, checked against the oracle
+    g = eng.generate(ffi.spec(ffi.T_SHA256), 0, 3999)
+    zs = [i for i in range(g["n"]) if g["h160_c"][20 * i] == 0]
+    assert len(zs) >= 10
+    for i in zs[:12]:
+        seed, sub = divmod(i, 3)
+        text, _ = eng.generate_lines(ffi.spec(ffi.T_SHA256), seed, seed, "sha256", [""] * 3)
+        d = vko.derive(vko.transform_key(vko.spec(vko.T_SHA256), seed, sub))
+        assert d.p2pkh_compressed.startswith(b"11")
+        assert text.decode().splitlines()[sub] == f"{seed},sha256,{d.private_key_hex.decode()},{d.p2pkh_compressed.decode()}"
+    with pytest.raises(Exception):
+        eng.generate_lines(ffi.spec(ffi.T_SHA256), 0, 2**20, "sha256", [""] * 3)      # more than 2^21 (input, slot) pairs
+    with pytest.raises(Exception):
+        eng.generate_lines(ffi.spec(ffi.T_SHA256), 0, 1, "x" * 32, [""] * 3)          # name longer than 31 bytes
+
+
+def test_removed_tree_algo_is_rejected():
+    """vk_engine_opts.algo = 1 (the tree summation of rounds 1-2, removed in round 3) fails loudly instead of running something else."""
+    import vuke_amd
+    with pytest.raises(vuke_amd.VkError) as ei:
+        vuke_amd.Engine(0, layout=1, algo=1)
+    assert ei.value.code == vuke_amd._ffi.VK_E_UNSUPPORTED
 
 
 def test_bitimage_chain(eng, vko):

@@ -10,5 +10,5 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" $flags --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable -mllvm -pragma-unroll-threshold=200000 \
     -DVK_SWEEP_GROUP=0 -c -o "$obj/vk_sweep_g0.o" "$root/vuke_amd/csrc/vk_sweep_tu.hip"
 b="$root/vuke_amd/csrc/build"
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$root/vuke_amd/lib/variants/libvuke_hip_$name.so" "$b/vk_engine.o" "$obj/vk_sweep_g0.o" "$b"/vk_sweep_g[1-4].o
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$root/vuke_amd/lib/variants/libvuke_hip_$name.so" "$b/vk_engine.o" "$obj/vk_sweep_g0.o" "$b"/vk_sweep_g[1-2].o
 echo "built libvuke_hip_$name.so"

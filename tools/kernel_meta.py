@@ -48,7 +48,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json")
     args = ap.parse_args()
-    jobs = [(os.path.join(CSRC, "vk_sweep_tu.hip"), [f"-DVK_SWEEP_GROUP={g}"], f"sweep_g{g}") for g in range(5) if g != 4 or os.path.exists(os.path.join(CSRC, "vk_sweep_tree.cuh"))]
+    jobs = [(os.path.join(CSRC, "vk_sweep_tu.hip"), [f"-DVK_SWEEP_GROUP={g}"], f"sweep_g{g}") for g in range(3)]
     jobs.append((os.path.join(CSRC, "vk_engine.hip"), [], "engine"))
     with ThreadPoolExecutor(max_workers=4) as ex:
         rows = [r for rs in ex.map(lambda j: unit(*j), jobs) for r in rs]

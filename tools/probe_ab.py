@@ -6,9 +6,8 @@ sys.path.insert(0, ROOT)
 import vuke_amd
 from vuke_amd import _ffi as ffi
 import bench_workloads as wl
-algo = int(os.environ.get("VK_ALGO", "0"))
 batch = int(os.environ.get("VK_BATCH", "256"))
-e = vuke_amd.Engine(0, layout=int(os.environ.get("VK_LAYOUT", "1")), batch=batch, blocks_per_cu=int(os.environ.get("VK_BLOCKS", "2")), algo=algo)
+e = vuke_amd.Engine(0, layout=int(os.environ.get("VK_LAYOUT", "1")), batch=batch, blocks_per_cu=int(os.environ.get("VK_BLOCKS", "2")))
 sp = ffi.spec(ffi.T_MILKSAD)
 name = os.environ.get("VUKE_HIP_LIB", "default").split("/")[-1]
 w = wl.load_golden("digest_windows.json")[0]

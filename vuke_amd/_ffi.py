@@ -61,7 +61,7 @@ SEARCH_EXACT, SEARCH_MASKED, SEARCH_CASCADE = 0, 1, 2
 
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
-    "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
+    "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_generate_lines", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
     "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_scan_strings", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
     "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop",
 ]
@@ -90,6 +90,7 @@ def load():
     L.vk_targets_set.argtypes = [vp, cp, cp, sz]
     L.vk_sweep.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_generate.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, vp, vp, vp, vp, C.POINTER(SweepStats)]
+    L.vk_generate_lines.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, cp, C.POINTER(C.c_char_p), vp, sz, C.POINTER(sz), C.POINTER(SweepStats)]
     L.vk_derive_batch.argtypes = [vp, cp, sz, vp, vp, vp]
     L.vk_derive_batch_pub.argtypes = [vp, cp, sz, vp, vp, vp, vp]
     L.vk_transform_batch.argtypes = [vp, C.POINTER(TransformSpec), C.POINTER(u64), sz, vp, vp]
@@ -173,6 +174,19 @@ class Engine:
         self._chk(self._L.vk_generate(self._e, C.byref(spec), lo, hi, flags, priv, hc, hu, valid, C.byref(st)))
         return dict(slots=slots, n=n, privkeys=priv.raw, h160_c=hc.raw, h160_u=hu.raw, valid=valid.raw,
                     keys=st.keys, inputs=st.inputs, digest=tuple(st.digest), kernel_seconds=st.kernel_seconds)
+
+    def generate_lines(self, spec, lo, hi, name, suffixes=None):
+        """Compact CSV text of generate mode for [lo, hi] (vk_generate_lines): (bytes, stats)."""
+        slots = self._L.vk_slots_per_input(C.byref(spec))
+        n = (hi - lo + 1) * slots
+        buf = C.create_string_buffer(max(1, n * 192))
+        ln = C.c_size_t(0)
+        st = SweepStats()
+        arr = None
+        if suffixes is not None:
+            arr = (C.c_char_p * slots)(*[s if isinstance(s, bytes) else s.encode() for s in suffixes])
+        self._chk(self._L.vk_generate_lines(self._e, C.byref(spec), lo, hi, name if isinstance(name, bytes) else name.encode(), arr, buf, len(buf), C.byref(ln), C.byref(st)))
+        return buf.raw[:ln.value], dict(keys=st.keys, inputs=st.inputs, kernel_seconds=st.kernel_seconds)
 
     def derive_batch(self, keys):
         n = len(keys)

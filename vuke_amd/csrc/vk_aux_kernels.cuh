@@ -138,19 +138,50 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_table_combine_kernel(uint4 *win, 
 }
 
 // ---------------------------------------------------------------- Transform::apply_batch
+// seeds == nullptr: the inputs are the range base, base + 1, ... (the staged sweep of the chained transforms)
 template <u32 KIND>
-__global__ void __launch_bounds__(VK_BLOCK) vk_transform_kernel(vk_spec_dev spec, const u64 *seeds, u64 n, u32 slots,
+__global__ void __launch_bounds__(VK_BLOCK) vk_transform_kernel(vk_spec_dev spec, const u64 *seeds, u64 base, u64 n, u32 slots,
                                                                 u32 *keys_out, unsigned char *valid, vk_ec_ctx ec)
 {
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
     if (idx >= n * slots) return;
     const u64 i = idx / slots;
     const u32 sub = (u32)(idx - i * slots);
+    const u64 seed = seeds ? seeds[i] : base + i;
     u32 kw[8];
-    bool ok = KIND == VK_T_ARMORY ? transform_armory(kw, seeds[i], sub, ec) : transform_key<KIND>(kw, spec, seeds[i], sub);
+    bool ok = KIND == VK_T_ARMORY ? transform_armory(kw, seed, sub, ec) : transform_key<KIND>(kw, spec, seed, sub);
 #pragma unroll
     for (int j = 0; j < 8; j++) keys_out[idx * 8 + j] = ok ? bswap32(kw[j]) : 0u;
     valid[idx] = ok ? 1 : 0;
+}
+
+// sha256_chain over a range, one lane per (input, seed form, variant) walking its chain once: the iterated variant is
+// k_0 = SHA256(seed), k_i = SHA256(k_{i-1}) (src/sha256_chain.rs:88-145), so a lane per KEY would recompute i hashes for key i.
+// Slot order = transform_sha256_chain's: form * (V * D) + v * D + idx.
+__global__ void __launch_bounds__(VK_BLOCK) vk_sha256_chain_range_kernel(vk_spec_dev spec, u64 base, u64 n, u32 *keys_out, unsigned char *valid)
+{
+    const u32 nv = spec.variant == VK_VARIANT_ALL ? 4u : 1u, depth = spec.chain_depth, chains = 2u * nv;
+    const u64 t = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    if (t >= n * chains) return;
+    const u64 i = t / chains;
+    const u32 c = (u32)(t - i * chains), form = c / nv, vi = c - form * nv, v = spec.variant == VK_VARIANT_ALL ? vi : spec.variant;
+    const u64 seed = base + i, first = (i * chains + c) * depth; // key index of this chain's idx 0
+    u32 kw[8];
+    bool ok = true;
+#pragma unroll 1
+    for (u32 idx = 0; idx < depth; idx++) {
+        if (v == 0 && idx > 0) {
+            u32 nx[8];
+            sha256_of_digest(nx, kw);
+#pragma unroll
+            for (int j = 0; j < 8; j++) kw[j] = nx[j];
+        } else {
+            ok = transform_sha256_chain(kw, seed, form * nv * depth + vi * depth + idx, spec.variant, depth);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) keys_out[(first + idx) * 8 + j] = ok ? bswap32(kw[j]) : 0u;
+        valid[first + idx] = ok ? 1 : 0;
+    }
 }
 
 // Transform::apply_batch for Input::from_string inputs of the hash transforms: one lane per (string, slot)

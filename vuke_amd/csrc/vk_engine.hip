@@ -9,6 +9,8 @@
 #include "vk_multibit.cuh"
 #include "vk_chain_keys.cuh"
 #include "vk_search.cuh"
+#include "vk_lines.cuh"
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -31,7 +33,6 @@ struct vk_engine {
     int cu_count = 0;
     u32 W = 24, nwin = 11; // default: 11 windows x 2^24 entries x 64 B = 11.8 GB of the 288 GB HBM
     u32 layout = 0;        // 0 uniform unsigned W-bit windows, 1 nine signed windows (VK_LAYOUT_SIGNED9)
-    u32 algo = 0;          // VK_ALGO_CHAIN / VK_ALGO_TREE (signed9 only)
     vk_win_desc wins[VK_MAX_WIN];
     u64 table_entries = 0;
     u64 *d_wordlist = nullptr;     // BIP-39 list, 2048 x 8 bytes (vk_bip39_wordlist_set), then the same words as an open-addressed set
@@ -245,11 +246,9 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
         }
         e->table_entries = (u64)e->nwin << e->W;
     }
-    if (opts && opts->algo) {
-        if (opts->algo != VK_ALGO_TREE) return fail(e, VK_E_INVALID_ARG, "unknown algo");
-        if (e->layout != VK_LAYOUT_SIGNED9) return fail(e, VK_E_INVALID_ARG, "VK_ALGO_TREE needs VK_LAYOUT_SIGNED9 (nine windows)");
-        e->algo = opts->algo;
-    }
+    if (opts && opts->algo)
+        return fail(e, VK_E_UNSUPPORTED, "vk_engine_opts.algo: only VK_ALGO_CHAIN (0) is built; the tree summation of rounds 1-2 was removed in round 3 "
+                                         "(0.84-0.90 x the chain kernel in every form measured, DESIGN.md section 8)");
     if (opts && opts->batch) {
         if (opts->batch > 1024) return fail(e, VK_E_INVALID_ARG, "batch must be <= 1024");
         e->batch = opts->batch;
@@ -276,7 +275,7 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     HIPCHK(e, hipMemcpy(e->d_wins, e->wins, sizeof e->wins, hipMemcpyHostToDevice));
     // batch-inversion workspace for the full grid, once (a multi-GB hipMalloc inside a sweep call costs seconds);
     // run_range only grows it for specs whose slots per input exceed the batch
-    e->work_bytes = (size_t)e->cu_count * e->blocks_per_cu * VK_BLOCK * e->batch * (e->algo == VK_ALGO_TREE ? 19 : 8) * sizeof(uint4);
+    e->work_bytes = (size_t)e->cu_count * e->blocks_per_cu * VK_BLOCK * e->batch * 8 * sizeof(uint4);
     HIPCHK(e, hipMalloc(&e->work, e->work_bytes));
     // the k*G table: affine points (64 B each), built on the device window by window in two phases
     HIPCHK(e, hipMalloc(&e->table, e->table_entries * 64));
@@ -401,10 +400,68 @@ struct launch_io {
 };
 
 
+static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots, u64 lo, u64 span, u32 flags, const launch_io &io, vk_sweep_stats *st);
+
+// The chained transforms (sha256_chain: up to `depth` dependent hashes per key; armory: four chained k*G per key) are swept in
+// two kernels: their keys go to HBM first (64 bytes of traffic per key next to ~900 for the sweep itself), then the raw-key
+// instantiation of the sweep kernel reads them back.  Fused, their state sat on top of the sweep kernel's 250 registers
+// (6 and 127 spilled registers, 48 and 400 bytes of scratch per lane) and every key of a chain recomputed its predecessors.
+static int run_range_staged(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots, u64 lo, u64 span, u32 flags, const launch_io &io,
+                            vk_sweep_stats *st)
+{
+    const u64 max_items = 1ull << 26; // 2 GB of keys per stage
+    const u64 step_inputs = std::max<u64>(1, max_items / slots);
+    u64 done = 0; // inputs
+    for (;;) {
+        const u64 left = span - done; // inclusive
+        const u64 n = std::min<u64>(left, step_inputs - 1) + 1, items = n * slots;
+        SCRATCH(e, d_keys, u32 *, 5, items * 32 + items);
+        unsigned char *d_valid = (unsigned char *)d_keys + items * 32;
+        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+        if (kind == VK_T_SHA256_CHAIN) {
+            const u64 lanes = n * 2 * (spec.variant == VK_VARIANT_ALL ? 4 : 1);
+            hipLaunchKernelGGL(vk_sha256_chain_range_kernel, dim3((u32)((lanes + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, spec, lo + done, n,
+                               d_keys, d_valid);
+        } else {
+            hipLaunchKernelGGL(vk_transform_kernel<VK_T_ARMORY>, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, spec,
+                               (const u64 *)nullptr, lo + done, n, slots, d_keys, d_valid, vk_ec_ctx{e->table, e->d_wins, e->nwin});
+        }
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        launch_io sub = io;
+        sub.in_keys = d_keys;
+        sub.in_valid = d_valid;
+        const u64 item0 = done * slots; // generate-mode outputs are indexed by item
+        if (sub.out_priv) sub.out_priv += item0 * 8;
+        if (sub.out_h160c) sub.out_h160c += item0 * 5;
+        if (sub.out_h160u) sub.out_h160u += item0 * 5;
+        if (sub.out_valid) sub.out_valid += item0;
+        if (sub.out_pub) sub.out_pub += item0 * 16;
+        const u64 had = std::min<u64>(st->matches, io.hit_cap);
+        const vk_spec_dev raw = {VK_T_RAWKEYS, 0, 0, 0};
+        const int rc = run_range(e, raw, VK_T_RAWKEYS, 1, 0, items - 1, flags, sub, st);
+        if (rc) return rc;
+        st->kernel_seconds += (double)ms * 1e-3;
+        st->launches += 1;
+        const u64 got = std::min<u64>(st->matches, io.hit_cap);
+        for (u64 i = had; io.hits && i < got; i++) { // key index of this stage -> (input, slot)
+            const u64 idx = io.hits[i].seed;
+            io.hits[i].seed = lo + done + idx / slots;
+            io.hits[i].sub_index = (u32)(idx % slots);
+        }
+        if (n - 1 == left) return VK_OK;
+        done += n;
+    }
+}
+
 // run [lo, lo+span] (span+1 inputs) under `spec`; accumulates into *st
 static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots, u64 lo, u64 span, u32 flags,
                      const launch_io &io, vk_sweep_stats *st)
 {
+    if (kind == VK_T_SHA256_CHAIN || kind == VK_T_ARMORY) return run_range_staged(e, spec, kind, slots, lo, span, flags, io, st);
     HIPCHK(e, hipSetDevice(e->device));
     // Tile = VK_BLOCK lanes x R inputs per lane (R * slots keys share one field inversion).  R is the largest batch
     // that fits e->batch, then shrunk so that every workgroup of the grid gets the same number of full tiles
@@ -420,11 +477,10 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     const u64 tile_inputs = (u64)VK_BLOCK * R;
     const u64 ntiles = span / tile_inputs + 1;
     u32 grid = (u32)std::min<u64>(ntiles, max_grid);
-    const bool tree = e->algo == VK_ALGO_TREE && (kind == VK_T_MILKSAD || kind == VK_T_RAWKEYS || kind == VK_T_LCG);
     // The workspace is one slice of B items per resident workgroup.  B >= slots, and slots grows with the chain depth of
     // sha256_chain (up to 8 * 4096): keep the allocation under 16 GiB by launching fewer workgroups (the tile counter hands
     // the same tiles to a smaller grid), and say what is wrong if even one workgroup does not fit.
-    const size_t per_wg = (size_t)VK_BLOCK * B * (tree ? 19 : 8) * sizeof(uint4);
+    const size_t per_wg = (size_t)VK_BLOCK * B * 8 * sizeof(uint4);
     const size_t work_cap = (size_t)16 << 30;
     if ((size_t)grid * per_wg > work_cap && (size_t)grid * per_wg > e->work_bytes) {
         const size_t fit = std::max(work_cap, e->work_bytes) / per_wg;
@@ -489,10 +545,7 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     p.out_pub = io.out_pub;
 
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    if (tree) {
-        if (!vk_launch_sweep_tree(kind, p, grid, e->stream)) return fail(e, VK_E_UNSUPPORTED, "transform kind not built for VK_ALGO_TREE");
-    } else if (!(vk_launch_sweep_g0(kind, p, grid, e->stream) || vk_launch_sweep_g1(kind, p, grid, e->stream) ||
-          vk_launch_sweep_g2(kind, p, grid, e->stream) || vk_launch_sweep_g3(kind, p, grid, e->stream)))
+    if (!(vk_launch_sweep_g0(kind, p, grid, e->stream) || vk_launch_sweep_g1(kind, p, grid, e->stream) || vk_launch_sweep_g2(kind, p, grid, e->stream)))
         return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
@@ -635,6 +688,77 @@ extern "C" int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t lo
     return VK_OK;
 }
 
+// RangeSource::process in generate mode with ConsoleOutput's compact format, text made on the device (vk_lines.cuh).
+extern "C" int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const char *transform_name,
+                                 const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int rc = validate_spec(e, t);
+    if (rc) return rc;
+    if (hi < lo) return fail(e, VK_E_INVALID_ARG, "seed_hi < seed_lo");
+    if (!transform_name || !text || !text_len) return fail(e, VK_E_INVALID_ARG, "transform_name / text / text_len is NULL");
+    const u32 slots = vk_slots_per_input(t);
+    if (slots == 0) return fail(e, VK_E_UNSUPPORTED, "the transform emits nothing for numeric inputs");
+    if (hi - lo >= VK_LINES_MAX_ITEMS / slots) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines: at most 2^21 (input, slot) pairs per call");
+    const u64 items = (hi - lo + 1) * slots;
+    if (text_cap < items * VK_LINE_STRIDE) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines: text_cap must be at least 192 bytes per (input, slot) pair");
+    // label suffix of every slot and the transform name: one length byte + up to 31 characters each
+    std::vector<unsigned char> texts((size_t)(slots + 1) * VK_LINE_SUFFIX_BYTES, 0);
+    for (u32 i = 0; i <= slots; i++) {
+        const char *src = i < slots ? (slot_suffix ? slot_suffix[i] : "") : transform_name;
+        const size_t n = src ? strlen(src) : 0;
+        if (n >= VK_LINE_SUFFIX_BYTES) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines: label suffix / transform name longer than 31 bytes");
+        texts[(size_t)i * VK_LINE_SUFFIX_BYTES] = (unsigned char)n;
+        if (n) memcpy(&texts[(size_t)i * VK_LINE_SUFFIX_BYTES + 1], src, n);
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    SCRATCH(e, d_texts, unsigned char *, 0, texts.size());
+    SCRATCH(e, d_priv, u32 *, 1, items * 32);
+    SCRATCH(e, d_hc, u32 *, 2, items * 20);
+    SCRATCH(e, d_valid, unsigned char *, 4, items);
+    SCRATCH(e, d_slots, u64 *, 6, items * VK_LINE_STRIDE);
+    size_t temp_bytes = 0;
+    u32 *null32 = nullptr;
+    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, null32, null32, (int)items, e->stream));
+    const size_t off_lens = 0, off_offs = (items + 1) * 4, off_temp = ((off_offs + (items + 1) * 4 + 255) / 256) * 256;
+    SCRATCH(e, d_scan, unsigned char *, 7, off_temp + temp_bytes);
+    u32 *d_lens = (u32 *)(d_scan + off_lens), *d_offs32 = (u32 *)(d_scan + off_offs);
+    SCRATCH(e, d_text, unsigned char *, 8, items * VK_LINE_STRIDE);
+    HIPCHK(e, hipMemcpy(d_texts, texts.data(), texts.size(), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemsetAsync(d_valid, 0, items, e->stream));
+    vk_sweep_stats local;
+    memset(&local, 0, sizeof local);
+    launch_io io;
+    io.out_priv = d_priv;
+    io.out_h160c = d_hc;
+    io.out_valid = d_valid;
+    rc = run_range(e, to_dev(t), t->kind, slots, lo, hi - lo, VK_F_COMPRESSED | VK_F_EMIT, io, &local);
+    if (rc) return rc;
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    const u32 grid = (u32)((items + 255) / 256);
+    hipLaunchKernelGGL(vk_lines_kernel, dim3(grid), dim3(256), 0, e->stream, (u64)lo, items, slots, d_priv, d_hc, d_valid, d_texts, d_slots, d_lens);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(d_scan + off_temp, temp_bytes, d_lens, d_offs32, (int)items, e->stream));
+    hipLaunchKernelGGL(vk_lines_compact_kernel, dim3((u32)((items + 63) / 64 * 64 + 255) / 256), dim3(256), 0, e->stream, items, d_slots, d_lens, d_offs32, d_text);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    u32 tail[2] = {0, 0};
+    HIPCHK(e, hipMemcpyAsync(&tail[0], d_offs32 + (items - 1), 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(&tail[1], d_lens + (items - 1), 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    const size_t total = (size_t)tail[0] + tail[1];
+    if (total) HIPCHK(e, hipMemcpy(text, d_text, total, hipMemcpyDeviceToHost));
+    *text_len = total;
+    local.inputs = hi - lo + 1;
+    local.kernel_seconds += (double)ms * 1e-3;
+    local.launches += 2;
+    if (out) *out = local;
+    return VK_OK;
+}
+
 extern "C" int vk_derive_batch_pub(vk_engine *e, const uint8_t *keys, size_t n, uint8_t *normalised, uint8_t *h160_c, uint8_t *h160_u,
                                    uint8_t *pub_xy)
 {
@@ -700,7 +824,7 @@ static void launch_transform(const vk_spec_dev &s, const u64 *seeds, u64 n, u32 
                              const vk_ec_ctx &ec = vk_ec_ctx{nullptr, nullptr, 0})
 {
     const u64 items = n * slots;
-    hipLaunchKernelGGL(vk_transform_kernel<KIND>, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, st, s, seeds, n,
+    hipLaunchKernelGGL(vk_transform_kernel<KIND>, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, st, s, seeds, (u64)0, n,
                        slots, keys, valid, ec);
 }
 

@@ -94,13 +94,16 @@ VK_DEV u32 probe_targets(const uint4 *__restrict__ tgt, u32 mask, const u32 h[5]
     return 0;
 }
 
-VK_DEV void digest_fold(u64 dg[4], const u32 h[5])
+// The digest accumulators live in LDS, one column per lane ([word][lane]: conflict-free 8-byte accesses): they are touched
+// once per key, and as registers they were 8 VGPRs held across the whole tile loop -- the difference between 0 and a few
+// spilled registers in the instantiations whose transform carries more state (mt64, raw keys, double_sha256, sha256_chain).
+VK_DEV void digest_fold(u64 *dg /* LDS, this lane's column, stride VK_BLOCK */, const u32 h[5])
 {
     u64 a = (u64)h[0] | ((u64)h[1] << 32), b = (u64)h[2] | ((u64)h[3] << 32);
     dg[0] ^= a;
-    dg[1] ^= b;
-    dg[2] ^= (u64)h[4];
-    dg[3] += a + b + h[4];
+    dg[VK_BLOCK] ^= b;
+    dg[2 * VK_BLOCK] ^= (u64)h[4];
+    dg[3 * VK_BLOCK] += a + b + h[4];
 }
 
 VK_DEV void work_store(uint4 *base, u64 stride, const fe &f)
@@ -156,8 +159,11 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
     // workgroup 0 is resident for the whole launch (tiles come from a counter): its shader-cycle and constant-rate counters
     // give the clock the part actually held under this load
     const u64 clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-    u64 n_keys = 0, n_match = 0;
-    u64 dg[4] = {0, 0, 0, 0};
+    u32 n_keys = 0, n_match = 0; // per lane and launch: far below 2^32
+    __shared__ u64 s_dg[4 * VK_BLOCK];
+    u64 *dg = s_dg + tid;
+#pragma unroll
+    for (int i = 0; i < 4; i++) dg[i * VK_BLOCK] = 0;
     // workspace of this workgroup: item b, quad q, lane t at wk[(b*8 + q) * VK_BLOCK] -- one contiguous
     // B * 32 KB region per workgroup (a few TLB entries), every access a fully coalesced 16 B per lane
     const u64 nth = VK_BLOCK;
@@ -391,22 +397,18 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
         }
     }
     // ------------------------------------------------------------------- counters
-    n_keys = wave_add(n_keys);
-    n_match = wave_add(n_match);
-    dg[0] = wave_xor(dg[0]);
-    dg[1] = wave_xor(dg[1]);
-    dg[2] = wave_xor(dg[2]);
-    dg[3] = wave_add(dg[3]);
+    const u64 w_keys = wave_add((u64)n_keys), w_match = wave_add((u64)n_match);
+    const u64 d0 = wave_xor(dg[0]), d1 = wave_xor(dg[VK_BLOCK]), d2 = wave_xor(dg[2 * VK_BLOCK]), d3 = wave_add(dg[3 * VK_BLOCK]);
     if (blockIdx.x == 0 && tid == 0) {
         p.stats[8] = __builtin_amdgcn_s_memtime() - clk0;
         p.stats[9] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
     if ((tid & 63) == 0) {
-        atomicAdd((unsigned long long *)&p.stats[0], (unsigned long long)n_keys);
-        atomicAdd((unsigned long long *)&p.stats[1], (unsigned long long)n_match);
-        atomicXor((unsigned long long *)&p.stats[3], (unsigned long long)dg[0]);
-        atomicXor((unsigned long long *)&p.stats[4], (unsigned long long)dg[1]);
-        atomicXor((unsigned long long *)&p.stats[5], (unsigned long long)dg[2]);
-        atomicAdd((unsigned long long *)&p.stats[6], (unsigned long long)dg[3]);
+        atomicAdd((unsigned long long *)&p.stats[0], (unsigned long long)w_keys);
+        atomicAdd((unsigned long long *)&p.stats[1], (unsigned long long)w_match);
+        atomicXor((unsigned long long *)&p.stats[3], (unsigned long long)d0);
+        atomicXor((unsigned long long *)&p.stats[4], (unsigned long long)d1);
+        atomicXor((unsigned long long *)&p.stats[5], (unsigned long long)d2);
+        atomicAdd((unsigned long long *)&p.stats[6], (unsigned long long)d3);
     }
 }

@@ -5,7 +5,5 @@
 
 bool vk_launch_sweep_g0(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s); // milksad, mt64, raw keys
 bool vk_launch_sweep_g1(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s); // sha256, double_sha256, md5, direct
-bool vk_launch_sweep_g2(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s); // lcg, xorshift, sha256_chain
-bool vk_launch_sweep_g3(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s); // armory
-bool vk_launch_sweep_tree(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s);   // VK_ALGO_TREE instantiations (milksad, raw keys, lcg)
+bool vk_launch_sweep_g2(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s); // lcg, xorshift
 hipError_t vk_sweep_occupancy(int *blocks_per_cu);                                      // of the milksad instantiation

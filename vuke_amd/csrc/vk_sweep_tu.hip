@@ -1,13 +1,11 @@
-// vk_sweep_tu.hip -- instantiations of vk_sweep_kernel<KIND>, compiled once per group (-DVK_SWEEP_GROUP=0..3) so the four
-// heavy translation units build side by side (build.sh).
+// vk_sweep_tu.hip -- instantiations of vk_sweep_kernel<KIND>, compiled once per group (-DVK_SWEEP_GROUP=0..2) so the three
+// heavy translation units build side by side (build.sh).  sha256_chain and armory have no instantiation of their own: their
+// keys are staged through HBM and swept as raw keys (vk_engine.hip: run_range_staged).
 #include "../../include/vuke_hip.h"
 #include "vk_sweep_launch.h"
-#if VK_SWEEP_GROUP == 4
-#include "vk_sweep_tree.cuh"
-#endif
 
 #ifndef VK_SWEEP_GROUP
-#error "compile with -DVK_SWEEP_GROUP=0..4"
+#error "compile with -DVK_SWEEP_GROUP=0..2"
 #endif
 
 template <u32 KIND>
@@ -47,30 +45,6 @@ bool vk_launch_sweep_g2(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_
     switch (kind) {
     case VK_T_LCG: launch<VK_T_LCG>(p, grid, s); return true;
     case VK_T_XORSHIFT: launch<VK_T_XORSHIFT>(p, grid, s); return true;
-    case VK_T_SHA256_CHAIN: launch<VK_T_SHA256_CHAIN>(p, grid, s); return true;
-    default: return false;
-    }
-}
-#elif VK_SWEEP_GROUP == 4
-template <u32 KIND>
-static void launch_tree(const vk_sweep_params &p, u32 grid, hipStream_t s)
-{
-    hipLaunchKernelGGL(vk_sweep_tree_kernel<KIND>, dim3(grid), dim3(VK_BLOCK), 0, s, p);
-}
-bool vk_launch_sweep_tree(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s)
-{
-    switch (kind) {
-    case VK_T_MILKSAD: launch_tree<VK_T_MILKSAD>(p, grid, s); return true;
-    case VK_T_RAWKEYS: launch_tree<VK_T_RAWKEYS>(p, grid, s); return true;
-    case VK_T_LCG: launch_tree<VK_T_LCG>(p, grid, s); return true;
-    default: return false;
-    }
-}
-#else
-bool vk_launch_sweep_g3(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s)
-{
-    switch (kind) {
-    case VK_T_ARMORY: launch<VK_T_ARMORY>(p, grid, s); return true;
     default: return false;
     }
 }

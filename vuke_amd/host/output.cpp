@@ -43,6 +43,14 @@ void ConsoleOutput::hit(const std::string &source, const std::string &transform,
             d.wif_compressed.c_str(), d.wif_uncompressed.c_str(), d.p2pkh_compressed.c_str(), d.p2pkh_uncompressed.c_str(), d.p2wpkh.c_str());
 }
 
+bool ConsoleOutput::write_text(const char *text, size_t len)
+{
+    if (verbose_) return false;
+    std::lock_guard<std::mutex> lk(mu_);
+    fwrite(text, 1, len, fp_);
+    return true;
+}
+
 void ConsoleOutput::flush()
 {
     std::lock_guard<std::mutex> lk(mu_);

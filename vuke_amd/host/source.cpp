@@ -441,10 +441,34 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
         // whatever the slot count (sha256_chain with a large --chain-depth has thousands of slots per input)
         uint32_t max_slots = 1;
         for (const Transform &t : transforms) max_slots = std::max(max_slots, t.takes_strings() ? t.string_slots() : t.slots());
-        const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(1ull << 16, (1ull << 18) / max_slots));
+        // Compact console output of numeric transforms: the lines come back from the device as text (vk_generate_lines: decimal
+        // label, hex, Base58Check and line assembly in HIP), 2^21 keys per call; anything else takes the record path below.
+        bool text_path = !full && !want_pub && output.accepts_text() && max_slots <= (1u << 16);
+        for (const Transform &t : transforms) text_path = text_path && !t.takes_strings() && strlen(t.name()) < 32;
+        const uint64_t chunk = text_path ? std::max<uint64_t>(1, (1ull << 21) / max_slots)
+                                         : std::max<uint64_t>(1, std::min<uint64_t>(1ull << 16, (1ull << 18) / max_slots));
+        std::vector<uint8_t> text;
         for (uint64_t lo = start;; lo += chunk) {
             const uint64_t hi = (end - lo < chunk - 1) ? end : lo + chunk - 1;
             for (const Transform &t : transforms) {
+                if (text_path) {
+                    const uint32_t k = t.slots();
+                    if (k == 0) continue;
+                    std::vector<std::string> suffix(k);
+                    std::vector<const char *> sp(k);
+                    for (uint32_t s = 0; s < k; s++) {
+                        suffix[s] = t.label(0, s).substr(1); // what follows the decimal input in this slot's label
+                        sp[s] = suffix[s].c_str();
+                    }
+                    const size_t n = (size_t)(hi - lo + 1) * k;
+                    if (text.size() < n * 192) text.resize(n * 192);
+                    size_t len = 0;
+                    vk_sweep_stats ss;
+                    check_rc(engine_, vk_generate_lines(engine_, &t.spec(), lo, hi, t.name(), sp.data(), text.data(), text.size(), &len, &ss));
+                    st.keys_generated += ss.keys;
+                    output.write_text((const char *)text.data(), len);
+                    continue;
+                }
                 if (t.takes_strings()) {
                     std::vector<uint64_t> inputs;
                     for (uint64_t v = lo;; v++) { inputs.push_back(v); if (v == hi) break; }

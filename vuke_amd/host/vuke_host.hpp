@@ -167,6 +167,10 @@ public:
     virtual bool needs_full_record() const { return true; }
     // true: key() also reads pubkey_compressed / pubkey_uncompressed (the bulk generate path fetches them only on request)
     virtual bool needs_pubkeys() const { return false; }
+    // Ready-made output text: whole lines exactly as key() would have written them for a run of keys, in order (generate mode's
+    // compact lines made on the device, vk_generate_lines).  false = this sink wants records: the caller then goes through key().
+    virtual bool write_text(const char *, size_t) { return false; }
+    virtual bool accepts_text() const { return false; }
 };
 
 // MultiOutput (src/output/multi.rs): the same record to every sink, in order
@@ -234,6 +238,8 @@ public:
     void hit(const std::string &source, const std::string &transform, const DerivedKey &d, const MatchInfo &m) override;
     void flush() override;
     bool needs_full_record() const override { return verbose_; }
+    bool accepts_text() const override { return !verbose_; } // the compact format is one line per key
+    bool write_text(const char *text, size_t len) override;
 
 private:
     ConsoleOutput(FILE *fp, bool own, bool verbose) : fp_(fp), own_(own), verbose_(verbose) {}
