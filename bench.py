@@ -288,7 +288,7 @@ class Chains(Workload):
         super().__init__(args, rank, world)
         self.which = which
         self.tag = "c5m" if which == "multibit" else "c5e"
-        self.kernel = "vk_multibit_kernel" if which == "multibit" else "vk_electrum_kernel"
+        self.kernel = "vk_ring_kernel<vk_pbkdf2_body>" if which == "multibit" else "vk_ring_kernel<vk_electrum_body>"
         # SHA-512 compression 5520 ops; MultiBit = 2 x 2048 x 2 compressions + 40 k*G + 20 derives;
         # Electrum = 200 000 SHA-256 compressions + 21 k*G (+ 20 derives)
         self.canonical_ops_per_input = (2 * 2048 * 2 * 5520 + 40 * 213000 + 20 * 220000) if which == "multibit" else (200000 * 2168 + 21 * 213000 + 20 * 220000)

@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 2 /* 2: vk_sweep_stats.shader_clock_ghz, vk_scan_strings */
+#define VK_ABI_VERSION 3 /* 2: vk_sweep_stats.shader_clock_ghz, vk_scan_strings; 3: vk_generate_lines, vk_last_warning,
+                           vk_sweep_stats.inputs_skipped (was padding), string limits 448 bytes, vk_engine_opts.algo must be 0 */
 
 /* error codes */
 #define VK_OK 0
@@ -109,7 +110,8 @@ typedef struct vk_sweep_stats {
     uint64_t digest[4];    /* order-independent fold of every hash160 produced */
     double kernel_seconds; /* hipEvent time of the device work on the engine's stream */
     uint32_t launches;     /* kernel launches this call made */
-    uint32_t _pad;
+    uint32_t inputs_skipped; /* vk_scan_strings: input strings over the device limit for which the reference would have produced
+                                keys (they are in `inputs`, their keys are not in `keys`); 0 everywhere else */
     double shader_clock_ghz; /* shader clock the sweep kernels ran at: s_memtime cycles / s_memrealtime of workgroup 0, over the
                                 call's launches (the part lowers its clock under this load; 0 if no sweep kernel ran) */
 } vk_sweep_stats;
@@ -158,6 +160,11 @@ int vk_engine_info(const vk_engine *e, vk_engine_info_t *out);
 /* Message for the last failing call on this engine (valid until the next call); e may be NULL
  * to read the message of a failed vk_engine_create. */
 const char *vk_last_error(const vk_engine *e);
+/* What the last SUCCESSFUL vk_transform_strings / vk_scan_strings call on this engine wants the caller to know (today: a
+ * one-line "warning: N input string(s) longer than the device limit ..." when the reference would have produced keys for
+ * inputs the device skipped); empty otherwise -- every such call clears it on entry.  Copied out under the engine's lock:
+ * returns the message length, writes at most cap - 1 bytes and a NUL into buf (buf may be NULL to ask for the length). */
+size_t vk_last_warning(vk_engine *e, char *buf, size_t cap);
 
 /* Matcher::from_addresses on the device.  h160 = n x 20 bytes, kind = n bytes (VK_TARGET_*).
  * Builds an open-address table in HBM; replaces any previous set; n = 0 clears it. */
@@ -234,7 +241,7 @@ int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy /* n_files*32 */, size
  * VK_E_UNSUPPORTED.  keys_out = n*slots*32, valid = n*slots, slot order = emit order.  A string over the device limit of
  * the two KDF chains never aborts the batch (the reference skips bad inputs silently, src/transform/electrum.rs:49-52): its
  * slots stay invalid, the call returns VK_OK, and when the reference would have produced keys for it (a multibit line, an
- * all-hex electrum line) vk_last_error() holds a one-line "warning: N input string(s) ..." until the next call. */
+ * all-hex electrum line) vk_last_warning() holds a one-line "warning: N input string(s) ..." until the next such call. */
 int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
                          uint8_t *keys_out, uint8_t *valid);
 

@@ -31,7 +31,7 @@ class Hit(C.Structure):
 
 class SweepStats(C.Structure):
     _fields_ = [("inputs", C.c_uint64), ("keys", C.c_uint64), ("matches", C.c_uint64), ("hits_dropped", C.c_uint64),
-                ("digest", C.c_uint64 * 4), ("kernel_seconds", C.c_double), ("launches", C.c_uint32), ("_pad", C.c_uint32),
+                ("digest", C.c_uint64 * 4), ("kernel_seconds", C.c_double), ("launches", C.c_uint32), ("inputs_skipped", C.c_uint32),
                 ("shader_clock_ghz", C.c_double)]
 
 
@@ -61,7 +61,7 @@ SEARCH_EXACT, SEARCH_MASKED, SEARCH_CASCADE = 0, 1, 2
 
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
-    "vk_last_error", "vk_targets_set", "vk_sweep", "vk_generate", "vk_generate_lines", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
+    "vk_last_error", "vk_last_warning", "vk_targets_set", "vk_sweep", "vk_generate", "vk_generate_lines", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
     "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_scan_strings", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
     "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop",
 ]
@@ -87,6 +87,8 @@ def load():
     L.vk_engine_info.argtypes = [vp, C.POINTER(EngineInfo)]
     L.vk_last_error.argtypes = [vp]
     L.vk_last_error.restype = cp
+    L.vk_last_warning.argtypes = [vp, vp, sz]
+    L.vk_last_warning.restype = sz
     L.vk_targets_set.argtypes = [vp, cp, cp, sz]
     L.vk_sweep.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_generate.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, vp, vp, vp, vp, C.POINTER(SweepStats)]
@@ -301,12 +303,14 @@ class Engine:
         m = min(st.matches, hit_cap)
         hl = sorted((dict(index=h.seed, sub_index=h.sub_index, addr_kind=h.addr_kind, privkey=bytes(h.privkey), h160=bytes(h.h160))
                      for h in hits[:m]), key=lambda h: (h["index"], h["sub_index"]))
-        warn = (self._L.vk_last_error(self._e) or b"").decode()
-        return dict(inputs=st.inputs, keys=st.keys, matches=st.matches, hits_dropped=st.hits_dropped, digest=tuple(st.digest),
+        warn = self.last_warning()
+        return dict(inputs=st.inputs, inputs_skipped=st.inputs_skipped, keys=st.keys, matches=st.matches, hits_dropped=st.hits_dropped, digest=tuple(st.digest),
                     kernel_seconds=st.kernel_seconds, launches=st.launches, shader_clock_ghz=st.shader_clock_ghz, warning=warn), hl
 
     def last_warning(self):
-        return (self._L.vk_last_error(self._e) or b"").decode()
+        buf = C.create_string_buffer(512)
+        self._L.vk_last_warning(self._e, buf, len(buf))
+        return buf.value.decode()
 
     def search(self, spec, lo, hi, key=None, mask_bits=None, cascade=None):
         """Analyzer brute force: smallest matching seed in [lo, hi] (exact key, masked key, or cascade [(bits, target)])."""

@@ -60,6 +60,7 @@ struct vk_engine {
     size_t scr_cap[10] = {};
     std::mutex mu;
     std::string err;
+    std::string warn; // what a successful call wants the caller to know (vk_last_warning); cleared on entry of every call that can set it
 };
 
 // slot `i` of the engine's scratch, at least `bytes` long (contents undefined); nullptr + e->err on failure
@@ -1072,10 +1073,21 @@ chain_done:
 
 static void note_overlong(vk_engine *e, const vk_transform_spec *t, size_t overlong)
 {
-    e->err.clear();
-    if (overlong)
-        e->err = "warning: " + std::to_string(overlong) + " input string(s) longer than the device limit (" +
-                 "448 bytes) produced no keys";
+    (void)t;
+    if (overlong) e->warn = "warning: " + std::to_string(overlong) + " input string(s) longer than the device limit (448 bytes) produced no keys";
+}
+
+extern "C" size_t vk_last_warning(vk_engine *e, char *buf, size_t cap)
+{
+    if (!e) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    const size_t n = e->warn.size();
+    if (buf && cap) {
+        const size_t c = std::min(n, cap - 1);
+        memcpy(buf, e->warn.data(), c);
+        buf[c] = 0;
+    }
+    return n;
 }
 
 extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
@@ -1083,6 +1095,7 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
 {
     if (!e) return VK_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
+    e->warn.clear();
     int rc = validate_spec(e, t, true);
     if (rc) return rc;
     if (n == 0) return VK_OK;
@@ -1113,6 +1126,7 @@ extern "C" int vk_scan_strings(vk_engine *e, const vk_transform_spec *t, const u
 {
     if (!e) return VK_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
+    e->warn.clear();
     int rc = validate_spec(e, t, true);
     if (rc) return rc;
     if (!out) return fail(e, VK_E_INVALID_ARG, "stats out pointer is NULL");
@@ -1148,6 +1162,7 @@ extern "C" int vk_scan_strings(vk_engine *e, const vk_transform_spec *t, const u
         hits[i].sub_index = (u32)(idx % slots);
     }
     note_overlong(e, t, overlong);
+    out->inputs_skipped = (uint32_t)std::min<size_t>(overlong, 0xFFFFFFFFu);
     return VK_OK;
 }
 

@@ -98,11 +98,16 @@ struct LineBatch {
 
 class LineReader { // src/source/wordlist.rs:24-30, src/source/stdin.rs:45-50: trim, skip empty lines
 public:
-    explicit LineReader(FILE *fp) : fp_(fp), buf_(8u << 20) {}
+    // strict: the reference's StdinSource (`let line = line?;`, src/source/stdin.rs:45-46) stops at the first line that is not
+    // UTF-8 and returns the error; lines are handed to the transforms in batches of 1000 there, so the (fewer than 1000) lines
+    // read since the last full batch are never processed.  The wordlist source drops such a line and goes on
+    // (`filter_map(Result::ok)`, src/source/wordlist.rs:33-36).
+    explicit LineReader(FILE *fp, bool strict = false) : fp_(fp), strict_(strict), buf_(8u << 20) {}
+    bool failed() const { return failed_; }
     // appends lines to `b` until it holds max_lines or max_bytes; false at end of input
     bool fill(LineBatch &b, size_t max_lines, size_t max_bytes)
     {
-        while (b.n() < max_lines && b.data.size() < max_bytes) {
+        while (!failed_ && b.n() < max_lines && b.data.size() < max_bytes) {
             if (pos_ == len_) {
                 len_ = fread(buf_.data(), 1, buf_.size(), fp_);
                 pos_ = 0;
@@ -126,17 +131,26 @@ public:
             }
             pos_ = (size_t)(nl - buf_.data()) + 1;
         }
-        return true;
+        return !failed_;
     }
 
 private:
     void push(LineBatch &b, const char *a, const char *e)
     {
-        if (!utf8_valid(a, (size_t)(e - a))) return; // .lines().filter_map(Result::ok): a line that is not UTF-8 is dropped
+        if (!utf8_valid(a, (size_t)(e - a))) {
+            if (!strict_) return; // .lines().filter_map(Result::ok): a line that is not UTF-8 is dropped
+            failed_ = true;       // `line?`: the lines since the last batch of 1000 are lost with it
+            const size_t drop = std::min<size_t>(b.n(), (size_t)(accepted_ % 1000));
+            b.offs.resize(b.offs.size() - drop);
+            b.data.resize(b.offs.back());
+            accepted_ -= drop;
+            return;
+        }
         trim_unicode(a, e);                           // str::trim(): Unicode White_Space, not only ASCII
         if (a == e) return;
         b.data.insert(b.data.end(), a, e);
         b.offs.push_back((uint32_t)b.data.size());
+        accepted_++;
     }
     void push(LineBatch &b)
     {
@@ -144,6 +158,8 @@ private:
         line_.clear();
     }
     FILE *fp_;
+    bool strict_, failed_ = false;
+    uint64_t accepted_ = 0; // lines handed out so far
     std::vector<char> buf_;
     size_t pos_ = 0, len_ = 0;
     std::string line_; // a line that straddles two reads
@@ -163,7 +179,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
     }
     const uint32_t flags = VK_F_COMPRESSED | VK_F_UNCOMPRESSED;
     const bool full = output.needs_full_record(), want_pub = output.needs_pubkeys();
-    LineReader reader(fp);
+    LineReader reader(fp, path == "-");
     LineBatch b;
     // what the device side of one slice of a batch produces: the emitted keys in emit order with the slot each came from,
     // then either the hits (scan) or the derived values of every key (generate)
@@ -171,14 +187,15 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
         std::vector<uint8_t> flat, norm, hc, hu, xy;
         std::vector<uint32_t> slot_of; // generate: slot of every emitted key; scan: slot of every hit
         size_t nkeys = 0;              // keys the transform emitted for this slice
-        std::string warning;           // over-long inputs the device skipped (vk_last_error after VK_OK)
+        std::string warning;           // over-long inputs the device skipped (vk_last_warning after VK_OK)
         std::vector<vk_hit> hits;
         std::vector<DerivedKey> hit_derived;
     };
     // one vk_transform_strings / vk_scan_strings call carries at most 2^28 keys: size the batch by keys, not by lines
     uint32_t max_slots = 1;
     for (const Transform &t : transforms) max_slots = std::max(max_slots, t.string_slots());
-    const size_t max_lines = std::max<size_t>(1, std::min<size_t>(1u << 20, (1u << 27) / max_slots));
+    size_t max_lines = std::max<size_t>(1, std::min<size_t>(1u << 20, (1u << 27) / max_slots));
+    if (max_lines >= 1000) max_lines -= max_lines % 1000; // batches end where the reference's batches of 1000 end (strict mode's cut-off)
     bool more = true;
     while (more) {
         b.clear();
@@ -201,7 +218,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                         if (!ss.hits_dropped) break;
                         o.hits.resize(o.hits.size() + (size_t)ss.hits_dropped + 1024);
                     }
-                    o.warning = vk_last_error(eng);
+                    o.warning = last_warning(eng);
                     o.nkeys = (size_t)ss.keys;
                     o.hits.resize((size_t)ss.matches);
                     std::sort(o.hits.begin(), o.hits.end(), [](const vk_hit &x, const vk_hit &y) {
@@ -217,7 +234,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                 }
                 std::vector<uint8_t> keys(cnt * k * 32), valid(cnt * k);
                 check_rc(eng, vk_transform_strings(eng, &t.spec(), b.data.data() + b.offs[first], offs.data(), cnt, keys.data(), valid.data()));
-                o.warning = vk_last_error(eng);
+                o.warning = last_warning(eng);
                 for (size_t s = 0; s < cnt * k; s++)
                     if (valid[s]) {
                         o.flat.insert(o.flat.end(), keys.begin() + 32 * s, keys.begin() + 32 * s + 32);
@@ -293,6 +310,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
     }
     if (matcher)
         for (vk_engine *e : engines_) check_rc(e, vk_targets_set(e, nullptr, nullptr, 0));
+    if (reader.failed()) throw std::runtime_error("stream did not contain valid UTF-8"); // io::Error of BufRead::lines(), src/source/stdin.rs:46
     return st;
 }
 

@@ -441,4 +441,12 @@ void check_rc(vk_engine *e, int rc)
     if (rc != VK_OK) throw EngineError(rc, vk_last_error(e));
 }
 
+std::string last_warning(vk_engine *e)
+{
+    char buf[512];
+    buf[0] = 0;
+    vk_last_warning(e, buf, sizeof buf);
+    return buf;
+}
+
 } // namespace vuke

@@ -456,5 +456,6 @@ struct EngineError : std::runtime_error {
     EngineError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
 };
 void check_rc(vk_engine *e, int rc);
+std::string last_warning(vk_engine *e); // vk_last_warning of the last successful string call (empty = nothing to report)
 
 } // namespace vuke
