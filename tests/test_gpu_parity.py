@@ -436,6 +436,32 @@ def test_multibit_chain_stage_by_stage_against_hashlib(eng):
     assert all(k is not None for r in eng.transform_strings(spec, ms[:3]) for k in r)
 
 
+def test_chain_ring_under_stress(vko, monkeypatch):
+    """The ring of vk_chain.cuh away from its comfortable operating point: far more workers than groups (most pops wait for a push,
+    the spin path), one-iteration chunks (2 047 laps per stretch, every hand-over through the release / acquire fences), and groups
+    that do not fill a wave -- results must not depend on any of it.  Electrum with a short stretch would not exercise more."""
+    import vuke_amd
+    from tests.test_oracle_multibit import synthetic_wordlist
+    from vuke_amd import _ffi as ffi
+    words = synthetic_wordlist()
+    wl = vko.Wordlist(words)
+    rnd = random.Random(99)
+    ms = [" ".join(rnd.choice(words) for _ in range(12)) for _ in range(150)]
+    want = {i: [k for _, k in vko.multibit_keys(wl, ms[i], count=3)[2]] for i in (0, 1, 63, 64, 65, 127, 128, 149)}
+    spec = ffi.spec(ffi.T_MULTIBIT, 0, 0, 3)
+    e = vuke_amd.Engine(0, window_bits=16)
+    try:
+        e.bip39_wordlist_set(words)
+        for workers, chunk in (("512", "64"), ("3", "1"), ("2", "7"), ("1", "2047"), ("64", "300")):
+            monkeypatch.setenv("VUKE_RING_WORKERS", workers)
+            monkeypatch.setenv("VUKE_RING_CHUNK", chunk)
+            rows = e.transform_strings(spec, [m.encode() for m in ms])
+            for i, w in want.items():
+                assert rows[i] == w, (workers, chunk, i)
+    finally:
+        e.close()
+
+
 def test_multibit_issue_445_vector_through_the_device(eng):
     """The reference's own MultiBit-HD vector (src/multibit.rs:404-417) on the HIP path: mnemonic -> 20 keys -> address
     1LQ8XnNK... for index 0.  The word list is the committed sparse fixture (real words at the 58 touched positions)."""

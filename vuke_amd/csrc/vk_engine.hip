@@ -40,6 +40,7 @@ struct vk_engine {
     u32 mb_salt_nblk = 0;
     int ring_waves_per_simd = 0;   // resident worker waves per SIMD of the chain ring (occupancy query, once)
     int chain_stop = 99;           // vk_debug_chain_stop
+    double clk_cycles = 0.0, clk_ticks = 0.0; // shader-clock samples of the sweep launches of the call in progress
     vk_win_desc *d_wins = nullptr; // device copy of wins (kernels that take the layout by pointer)
     double table_build_seconds = 0.0;
     u32 batch = 128;
@@ -569,9 +570,12 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     st->digest[1] ^= hs[4];
     st->digest[2] ^= hs[5];
     st->digest[3] += hs[6];
-    if (hs[9]) { // shader clock over the launches of this call, weighted by their length (s_memrealtime ticks at 100 MHz)
-        const double ghz = (double)hs[8] / ((double)hs[9] / 100e6) / 1e9, w = (double)ms * 1e-3;
-        st->shader_clock_ghz = (st->shader_clock_ghz * st->kernel_seconds + ghz * w) / (st->kernel_seconds + w);
+    if (hs[9]) { // shader clock over the sweep launches of this call: total shader cycles / total s_memrealtime ticks (100 MHz) of
+                 // workgroup 0 -- launches without a sample (other kernels of the call) carry no weight
+        if (st->launches == 0 || st->shader_clock_ghz == 0.0) e->clk_cycles = e->clk_ticks = 0.0;
+        e->clk_cycles += (double)hs[8];
+        e->clk_ticks += (double)hs[9];
+        st->shader_clock_ghz = e->clk_cycles / (e->clk_ticks / 100e6) / 1e9;
     }
     st->kernel_seconds += (double)ms * 1e-3;
     st->launches += 1;

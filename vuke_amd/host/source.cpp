@@ -211,7 +211,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                 for (size_t i = 0; i <= cnt; i++) offs[i] = b.offs[first + i] - b.offs[first];
                 if (matcher) {
                     // scan: strings in, hits out -- the keys stay on the device (vk_scan_strings)
-                    o.hits.resize(4096);
+                    o.hits.resize(1u << 16); // a retry re-runs the whole transform (the KDF chains included): start generous
                     vk_sweep_stats ss;
                     for (;;) {
                         check_rc(eng, vk_scan_strings(eng, &t.spec(), b.data.data() + b.offs[first], offs.data(), cnt, flags, o.hits.data(), o.hits.size(), &ss));
