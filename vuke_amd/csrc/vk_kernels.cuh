@@ -12,9 +12,10 @@
 //   pass 2  walk the items backwards: w_b = inv * c_{b-1} = 1 / e_b; inv *= e_b; y = Y * w, x = (X*ZZ^2) * w^2;
 //           SHA-256 + RIPEMD-160 of the SEC1 encoding(s); digest fold; open-address probe of the target table; hit
 //           record / generate-mode record.  e and c of the next item are requested one item ahead.
-// LDS: the tile index and one 4 160-byte landing slot per wave.  No MFMA: the path is integer-VALU bound; the memory
+// LDS: the tile index, one 4 160-byte landing slot per wave and the per-lane digest accumulators (8 KB).  No MFMA: the path is integer-VALU bound; the memory
 // streams are the table gathers (64 B per window, random over the whole HBM table), the workspace (128 B written,
-// 160 B read per key) and one 32-byte probe slot per hash160.  No scratch: every field element lives in VGPRs.
+// 160 B read per key) and one 32-byte probe slot per hash160.  Every field element lives in VGPRs; the 16 bytes of scratch
+// the code object reports are the argument frame of the rare exact-product calls (fe_mul_exact / fe_sqr_exact).
 //
 // Replaces the closure body of RangeSource::process (reference src/source/range.rs:42-70):
 // Transform::apply_batch -> KeyDeriver::derive -> Matcher::check -> counters.
