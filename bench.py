@@ -83,13 +83,18 @@ def self_launch(args, argv):
 
 
 def csrc_hash():
-    """SHA-256 over the kernel sources: PMC-derived numbers are only valid for the exact sources they were taken from."""
+    """SHA-256 over the kernel sources with comments and white space removed: PMC-derived numbers are only valid for the exact CODE
+    they were taken from (a reworded comment does not re-key the profiles, any token change does)."""
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "vuke_amd", "csrc")
+    strip = re.compile(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\])*"', re.S)
     for f in sorted(os.listdir(d)):
         if f.endswith((".cuh", ".hip", ".h")):
+            txt = open(os.path.join(d, f), encoding="utf-8", errors="replace").read()
+            txt = strip.sub(lambda m: m.group(0) if m.group(0).startswith('"') else " ", txt)   # string literals are code
             h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+            h.update(" ".join(txt.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -211,6 +211,7 @@ extern "C" {
                         out: *mut VkSweepStats) -> c_int;
     pub fn vk_scan_strings(e: *mut VkEngine, t: *const VkTransformSpec, data: *const u8, offsets: *const u32, n: usize, flags: u32,
                            hits: *mut VkHit, hit_cap: usize, out: *mut VkSweepStats) -> c_int;
+    pub fn vk_rescan_strings(e: *mut VkEngine, flags: u32, hits: *mut VkHit, hit_cap: usize, out: *mut VkSweepStats) -> c_int;
     pub fn vk_search(e: *mut VkEngine, t: *const VkTransformSpec, seed_lo: u64, seed_hi_inclusive: u64, target: *const VkSearchTarget,
                      out: *mut VkSearchResult) -> c_int;
     pub fn vk_slots_per_input(t: *const VkTransformSpec) -> u32;

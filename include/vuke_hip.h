@@ -257,6 +257,10 @@ int vk_scan_keys(vk_engine *e, const uint8_t *keys /* n*32 */, size_t n, uint32_
  * Same length rule and warning as vk_transform_strings. */
 int vk_scan_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n, uint32_t flags,
                     vk_hit *hits, size_t hit_cap, vk_sweep_stats *out);
+/* vk_scan_strings once more over the keys its last call on this engine left on the device (flags may differ): only the
+ * derive + probe sweep runs, not the transform -- for a caller whose hit buffer was too small (out->hits_dropped > 0): the KDF
+ * chains cost seconds per batch, the sweep milliseconds.  VK_E_INVALID_ARG once any other call has reused the buffers. */
+int vk_rescan_strings(vk_engine *e, uint32_t flags, vk_hit *hits, size_t hit_cap, vk_sweep_stats *out);
 
 /* ---- analyzer brute force (reference src/analyze/{milksad,lcg,mt64,xorshift,sha256_chain}.rs)
  * Smallest seed in [seed_lo, seed_hi] whose generated key(s) satisfy the target.  Kinds: VK_T_MILKSAD, VK_T_MT64,

@@ -517,7 +517,20 @@ def test_scan_strings_fused_path(eng, vko):
     for i in (0, 2, 3, 4, 7, 8, 9):
         assert rows[i] == [k for _, k in vko.electrum_keys(seeds[i], count=2)[1]], i
     st, _ = eng.scan_strings(es, seeds)
-    assert (st["inputs"], st["keys"]) == (10, 14) and st["warning"].startswith("warning: 1 ")
+    assert (st["inputs"], st["keys"], st["inputs_skipped"]) == (10, 14, 1) and st["warning"].startswith("warning: 1 ")
+    # a hit buffer that was too small: vk_rescan_strings runs only the probe sweep again, over the keys still on the device
+    flat = [k for r in rows for k in r if k is not None]
+    eng.targets_set([bytes(vko.derive(k).h160_u) for k in flat], [ffi.TARGET_P2PKH] * len(flat))
+    st1, h1 = eng.scan_strings(es, seeds, hit_cap=3)
+    assert (st1["matches"], st1["hits_dropped"], len(h1)) == (14, 11, 3)
+    st2, h2 = eng.rescan_strings(hit_cap=64)
+    assert (st2["matches"], st2["hits_dropped"], st2["inputs"], st2["digest"]) == (14, 0, 10, st1["digest"])
+    assert [(h["index"], h["sub_index"]) for h in h2] == [(i, s) for i, r in enumerate(rows) for s, k in enumerate(r) if k is not None]
+    assert [h["privkey"] for h in h2] == [vko.normalize_key(k) for k in flat]
+    eng.targets_set([], [])
+    eng.derive_batch(flat[:2])                      # any other call reuses the buffers ...
+    with pytest.raises(Exception):
+        eng.rescan_strings()                        # ... and the keys are gone: said, not guessed
     rows = eng.transform_strings(es, seeds[:1])
     assert eng.last_warning() == ""
 

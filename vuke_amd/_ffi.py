@@ -62,7 +62,7 @@ SEARCH_EXACT, SEARCH_MASKED, SEARCH_CASCADE = 0, 1, 2
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
     "vk_last_error", "vk_last_warning", "vk_targets_set", "vk_sweep", "vk_generate", "vk_generate_lines", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
-    "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_scan_strings", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
+    "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_scan_strings", "vk_rescan_strings", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
     "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop",
 ]
 
@@ -97,6 +97,7 @@ def load():
     L.vk_derive_batch_pub.argtypes = [vp, cp, sz, vp, vp, vp, vp]
     L.vk_transform_batch.argtypes = [vp, C.POINTER(TransformSpec), C.POINTER(u64), sz, vp, vp]
     L.vk_transform_strings.argtypes = [vp, C.POINTER(TransformSpec), cp, C.POINTER(u32), sz, vp, vp]
+    L.vk_rescan_strings.argtypes = [vp, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_bip39_wordlist_set.argtypes = [vp, cp]
     L.vk_bitimage_keys.argtypes = [vp, cp, sz, cp, C.POINTER(u32), sz, C.POINTER(u32), u32, u32, cp, cp]
     L.vk_search.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, C.POINTER(SearchTarget), C.POINTER(SearchResult)]
@@ -306,6 +307,16 @@ class Engine:
         warn = self.last_warning()
         return dict(inputs=st.inputs, inputs_skipped=st.inputs_skipped, keys=st.keys, matches=st.matches, hits_dropped=st.hits_dropped, digest=tuple(st.digest),
                     kernel_seconds=st.kernel_seconds, launches=st.launches, shader_clock_ghz=st.shader_clock_ghz, warning=warn), hl
+
+    def rescan_strings(self, flags=F_COMPRESSED | F_UNCOMPRESSED, hit_cap=4096):
+        """The probe sweep of the last scan_strings call again (its keys are still on the device), with another hit buffer."""
+        hits = (Hit * max(hit_cap, 1))()
+        st = SweepStats()
+        self._chk(self._L.vk_rescan_strings(self._e, flags, hits, hit_cap, C.byref(st)))
+        m = min(st.matches, hit_cap)
+        hl = sorted((dict(index=h.seed, sub_index=h.sub_index, addr_kind=h.addr_kind, privkey=bytes(h.privkey), h160=bytes(h.h160))
+                     for h in hits[:m]), key=lambda h: (h["index"], h["sub_index"]))
+        return dict(inputs=st.inputs, keys=st.keys, matches=st.matches, hits_dropped=st.hits_dropped, digest=tuple(st.digest)), hl
 
     def last_warning(self):
         buf = C.create_string_buffer(512)

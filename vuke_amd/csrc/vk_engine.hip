@@ -41,6 +41,9 @@ struct vk_engine {
     int ring_waves_per_simd = 0;   // resident worker waves per SIMD of the chain ring (occupancy query, once)
     int chain_stop = 99;           // vk_debug_chain_stop
     double clk_cycles = 0.0, clk_ticks = 0.0; // shader-clock samples of the sweep launches of the call in progress
+    u64 rescan_items = 0;          // vk_rescan_strings: keys of the last vk_scan_strings call still in scratch slots 1 / 4 (0 = gone)
+    u32 rescan_slots = 0;
+    u64 rescan_inputs = 0, rescan_skipped = 0;
     vk_win_desc *d_wins = nullptr; // device copy of wins (kernels that take the layout by pointer)
     double table_build_seconds = 0.0;
     u32 batch = 128;
@@ -67,6 +70,7 @@ struct vk_engine {
 // slot `i` of the engine's scratch, at least `bytes` long (contents undefined); nullptr + e->err on failure
 static void *scratch(vk_engine *e, int i, size_t bytes)
 {
+    if (i == 1 || i == 4) e->rescan_items = 0; // the keys / validity flags of the last vk_scan_strings call are about to be overwritten
     if (bytes == 0) bytes = 1;
     if (e->scr_cap[i] >= bytes) return e->scr[i];
     if (e->scr[i]) {
@@ -1167,6 +1171,42 @@ extern "C" int vk_scan_strings(vk_engine *e, const vk_transform_spec *t, const u
     }
     note_overlong(e, t, overlong);
     out->inputs_skipped = (uint32_t)std::min<size_t>(overlong, 0xFFFFFFFFu);
+    e->rescan_items = (u64)n * slots;
+    e->rescan_slots = slots;
+    e->rescan_inputs = n;
+    e->rescan_skipped = out->inputs_skipped;
+    return VK_OK;
+}
+
+// vk_scan_strings again over the keys its last call left on the device: only the derive + probe sweep runs, not the transform
+// (for a caller whose hit buffer was too small: the KDF chains cost seconds per batch, the sweep milliseconds).
+extern "C" int vk_rescan_strings(vk_engine *e, uint32_t flags, vk_hit *hits, size_t hit_cap, vk_sweep_stats *out)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!out) return fail(e, VK_E_INVALID_ARG, "stats out pointer is NULL");
+    if (!(flags & (VK_F_COMPRESSED | VK_F_UNCOMPRESSED)) || (flags & ~(VK_F_COMPRESSED | VK_F_UNCOMPRESSED)))
+        return fail(e, VK_E_INVALID_ARG, "flags must be a non-empty subset of VK_F_COMPRESSED | VK_F_UNCOMPRESSED");
+    if (!e->rescan_items || !e->scr[1] || !e->scr[4])
+        return fail(e, VK_E_INVALID_ARG, "vk_rescan_strings: the keys of the last vk_scan_strings call are no longer on the device (another call has run since)");
+    memset(out, 0, sizeof *out);
+    launch_io io;
+    io.in_keys = (const u32 *)e->scr[1];
+    io.in_valid = (const unsigned char *)e->scr[4];
+    io.hits = hits;
+    io.hit_cap = hits ? hit_cap : 0;
+    vk_spec_dev spec = {VK_T_RAWKEYS, 0, 0, 0};
+    const int rc = run_range(e, spec, VK_T_RAWKEYS, 1, 0, e->rescan_items - 1, flags, io, out);
+    if (rc) return rc;
+    out->inputs = e->rescan_inputs;
+    out->inputs_skipped = (uint32_t)e->rescan_skipped;
+    out->hits_dropped = out->matches > io.hit_cap ? out->matches - io.hit_cap : 0;
+    const size_t got = (size_t)std::min<u64>(out->matches, io.hit_cap);
+    for (size_t i = 0; i < got; i++) { // key index -> (input, slot)
+        const u64 idx = hits[i].seed;
+        hits[i].seed = idx / e->rescan_slots;
+        hits[i].sub_index = (u32)(idx % e->rescan_slots);
+    }
     return VK_OK;
 }
 
@@ -1198,19 +1238,11 @@ extern "C" int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy, size_t n_f
         nblk[j] = vk_salt_blocks(&salts[j * VK_SALT_WORDS], pl ? pass_data + pass_offsets[j] : nullptr, pl);
     }
     HIPCHK(e, hipSetDevice(e->device));
-    const size_t pbytes = pass_offsets[n_pass], outs = (size_t)(items * count);
-    SCRATCH(e, d_pass, unsigned char *, 0, pbytes + 1);
-    SCRATCH(e, d_offs, u32 *, 2, (n_pass + 1) * 4);
+    const size_t outs = (size_t)(items * count); // the passphrases travel as their salt blocks (d_salts below)
     SCRATCH(e, d_ent, unsigned char *, 3, n_files * 32);
     SCRATCH(e, d_keys, u32 *, 1, outs * 32);
     SCRATCH(e, d_valid, unsigned char *, 4, outs);
-    hipError_t c = hipSuccess;
-    if (pbytes) {
-        if (!pass_data) return fail(e, VK_E_INVALID_ARG, "pass_data is NULL");
-        c = hipMemcpy(d_pass, pass_data, pbytes, hipMemcpyHostToDevice);
-    }
-    if (c == hipSuccess) c = hipMemcpy(d_offs, pass_offsets, (n_pass + 1) * 4, hipMemcpyHostToDevice);
-    if (c == hipSuccess) c = hipMemcpy(d_ent, entropy, n_files * 32, hipMemcpyHostToDevice);
+    hipError_t c = hipMemcpy(d_ent, entropy, n_files * 32, hipMemcpyHostToDevice);
     if (c == hipSuccess) c = hipMemsetAsync(d_keys, 0, outs * 32, e->stream);
     if (c == hipSuccess) c = hipMemsetAsync(d_valid, 0, outs, e->stream);
     if (c != hipSuccess) {

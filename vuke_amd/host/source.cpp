@@ -211,14 +211,15 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                 for (size_t i = 0; i <= cnt; i++) offs[i] = b.offs[first + i] - b.offs[first];
                 if (matcher) {
                     // scan: strings in, hits out -- the keys stay on the device (vk_scan_strings)
-                    o.hits.resize(1u << 16); // a retry re-runs the whole transform (the KDF chains included): start generous
+                    o.hits.resize(1u << 16);
                     vk_sweep_stats ss;
-                    for (;;) {
-                        check_rc(eng, vk_scan_strings(eng, &t.spec(), b.data.data() + b.offs[first], offs.data(), cnt, flags, o.hits.data(), o.hits.size(), &ss));
-                        if (!ss.hits_dropped) break;
+                    check_rc(eng, vk_scan_strings(eng, &t.spec(), b.data.data() + b.offs[first], offs.data(), cnt, flags, o.hits.data(), o.hits.size(), &ss));
+                    const std::string warned = last_warning(eng);
+                    while (ss.hits_dropped) { // more hits than the buffer holds: only the probe sweep runs again, the keys are still on the device
                         o.hits.resize(o.hits.size() + (size_t)ss.hits_dropped + 1024);
+                        check_rc(eng, vk_rescan_strings(eng, flags, o.hits.data(), o.hits.size(), &ss));
                     }
-                    o.warning = last_warning(eng);
+                    o.warning = warned;
                     o.nkeys = (size_t)ss.keys;
                     o.hits.resize((size_t)ss.matches);
                     std::sort(o.hits.begin(), o.hits.end(), [](const vk_hit &x, const vk_hit &y) {
