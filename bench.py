@@ -79,7 +79,13 @@ def self_launch(args, argv):
         return 0
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    return subprocess.run(cmd, env=env).returncode
+    # rank 0's JSON line goes to stdout; anything else a rank or a library writes there (gloo announces its connections on
+    # stdout) is passed on to stderr, so that stdout carries exactly the one line the contract promises
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in p.stdout:
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        (sys.stdout if line.startswith("{") else sys.stderr).flush()
+    return p.wait()
 
 
 def csrc_hash():
