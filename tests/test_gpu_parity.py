@@ -836,6 +836,39 @@ def test_generate_lines_on_the_device_equal_the_oracles_text(eng, vko):
         eng.generate_lines(ffi.spec(ffi.T_SHA256), 0, 1, "x" * 32, [""] * 3)          # name longer than 31 bytes
 
 
+def fold_digests(parts):
+    import bench_workloads as wl
+    return wl.fold_digests(parts)
+
+
+def test_staged_sweep_of_chained_transforms_across_a_stage_boundary(eng, vko):
+    """sha256_chain (and armory) are swept in stages of 2^26 keys: keys to HBM, then the raw-key sweep (run_range_staged).  Planted
+    keys on both sides of the first stage boundary (80 slots -> 838 860 inputs per stage), which here lies 10 inputs below the
+    2^32 ceiling of the 4-byte seed form: hit records carry the right input, slot, key and hash160 (all from the oracle), the
+    counters follow the ceiling, and the digest of the whole equals the fold of three unevenly cut parts."""
+    from vuke_amd import _ffi as ffi
+    gs, osp = ffi.spec(ffi.T_SHA256_CHAIN), vko.spec(vko.T_SHA256_CHAIN)
+    stage = (1 << 26) // 80
+    lo = 2**32 - stage - 10
+    hi = lo + 900_000 - 1
+    planted = [(lo, 0), (lo + stage - 1, 79), (lo + stage, 0), (lo + stage, 45), (lo + stage + 1, 39), (2**32 - 1, 40), (2**32 - 1, 79), (2**32, 39), (hi, 13)]
+    recs = []
+    for seed, sub in planted:
+        k = vko.transform_key(osp, seed, sub)
+        d = vko.derive(k)
+        recs.append((seed, sub, 0, bytes(d.raw), bytes(d.h160_c)))
+    assert vko.transform_key(osp, 2**32, 40) is None        # the 4-byte seed form stops at u32::MAX
+    eng.targets_set([r[4] for r in recs], [ffi.TARGET_P2PKH] * len(recs))
+    st, hits = eng.sweep(gs, lo, hi, flags=1)
+    eng.targets_set([], [])
+    below = 2**32 - lo
+    assert (st["inputs"], st["keys"], st["matches"]) == (900_000, 80 * below + 40 * (900_000 - below), len(recs))
+    assert sorted((h["seed"], h["sub_index"], h["addr_kind"], h["privkey"], h["h160"]) for h in hits) == sorted(recs)
+    cuts = [lo, lo + 123_457, lo + stage + 5, hi + 1]
+    parts = [eng.sweep(gs, a, b - 1, flags=1)[0]["digest"] for a, b in zip(cuts, cuts[1:])]
+    assert fold_digests(parts) == st["digest"]
+
+
 def test_removed_tree_algo_is_rejected():
     """vk_engine_opts.algo = 1 (the tree summation of rounds 1-2, removed in round 3) fails loudly instead of running something else."""
     import vuke_amd
