@@ -150,8 +150,9 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_transform_kernel(vk_spec_dev spec
     const u64 seed = seeds ? seeds[i] : base + i;
     u32 kw[8];
     bool ok = KIND == VK_T_ARMORY ? transform_armory(kw, seed, sub, ec) : transform_key<KIND>(kw, spec, seed, sub);
-#pragma unroll
-    for (int j = 0; j < 8; j++) keys_out[idx * 8 + j] = ok ? bswap32(kw[j]) : 0u;
+    uint4 *dst = reinterpret_cast<uint4 *>(keys_out) + idx * 2; // two 16-byte stores per key
+    dst[0] = ok ? make_uint4(bswap32(kw[0]), bswap32(kw[1]), bswap32(kw[2]), bswap32(kw[3])) : make_uint4(0, 0, 0, 0);
+    dst[1] = ok ? make_uint4(bswap32(kw[4]), bswap32(kw[5]), bswap32(kw[6]), bswap32(kw[7])) : make_uint4(0, 0, 0, 0);
     valid[idx] = ok ? 1 : 0;
 }
 
@@ -163,8 +164,11 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_sha256_chain_range_kernel(vk_spec
     const u32 nv = spec.variant == VK_VARIANT_ALL ? 4u : 1u, depth = spec.chain_depth, chains = 2u * nv;
     const u64 t = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
     if (t >= n * chains) return;
-    const u64 i = t / chains;
-    const u32 c = (u32)(t - i * chains), form = c / nv, vi = c - form * nv, v = spec.variant == VK_VARIANT_ALL ? vi : spec.variant;
+    // chain-major lane order: the lanes of a wave walk the same (seed form, variant) for consecutive inputs -- no divergence
+    // between the iterated, indexed and counter code paths
+    const u32 c = (u32)(t / n);
+    const u64 i = t - (u64)c * n;
+    const u32 form = c / nv, vi = c - form * nv, v = spec.variant == VK_VARIANT_ALL ? vi : spec.variant;
     const u64 seed = base + i, first = (i * chains + c) * depth; // key index of this chain's idx 0
     u32 kw[8];
     bool ok = true;
@@ -178,8 +182,10 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_sha256_chain_range_kernel(vk_spec
         } else {
             ok = transform_sha256_chain(kw, seed, form * nv * depth + vi * depth + idx, spec.variant, depth);
         }
-#pragma unroll
-        for (int j = 0; j < 8; j++) keys_out[(first + idx) * 8 + j] = ok ? bswap32(kw[j]) : 0u;
+        // two 16-byte stores per key (the lanes of a wave write keys 32 * depth bytes apart: fewer, wider requests)
+        uint4 *dst = reinterpret_cast<uint4 *>(keys_out) + (first + idx) * 2;
+        dst[0] = ok ? make_uint4(bswap32(kw[0]), bswap32(kw[1]), bswap32(kw[2]), bswap32(kw[3])) : make_uint4(0, 0, 0, 0);
+        dst[1] = ok ? make_uint4(bswap32(kw[4]), bswap32(kw[5]), bswap32(kw[6]), bswap32(kw[7])) : make_uint4(0, 0, 0, 0);
         valid[first + idx] = ok ? 1 : 0;
     }
 }
@@ -196,8 +202,9 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_strings_kernel(vk_spec_dev spec, 
     const unsigned char *str = data + offsets[i];
     const u32 len = offsets[i + 1] - offsets[i];
     bool ok = spec.kind == VK_T_ARMORY ? transform_armory_string(kw, str, len, sub, ec) : transform_string(kw, spec, str, len, sub);
-#pragma unroll
-    for (int j = 0; j < 8; j++) keys_out[idx * 8 + j] = ok ? bswap32(kw[j]) : 0u;
+    uint4 *dst = reinterpret_cast<uint4 *>(keys_out) + idx * 2; // two 16-byte stores per key
+    dst[0] = ok ? make_uint4(bswap32(kw[0]), bswap32(kw[1]), bswap32(kw[2]), bswap32(kw[3])) : make_uint4(0, 0, 0, 0);
+    dst[1] = ok ? make_uint4(bswap32(kw[4]), bswap32(kw[5]), bswap32(kw[6]), bswap32(kw[7])) : make_uint4(0, 0, 0, 0);
     valid[idx] = ok ? 1 : 0;
 }
 
