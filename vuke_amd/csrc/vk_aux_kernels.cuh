@@ -190,6 +190,69 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_sha256_chain_range_kernel(vk_spec
     }
 }
 
+// armory over a range in a sweep, batched: the four chained public keys of a key (src/transform/armory.rs:84-101) come from the
+// sweep kernel itself (raw keys in, affine X || Y out: table reads through LDS, one field inversion per 256 keys) instead of a
+// k*G and an inversion per lane and step.  vk_armory_begin_kernel: seed -> (key, chaincode); four times { raw-key sweep with
+// out_pub; vk_armory_step_kernel: s = dSHA256(04 || X || Y) xor chaincode, key = key * s mod n }.
+__global__ void __launch_bounds__(VK_BLOCK) vk_armory_begin_kernel(u64 base, u64 n, u32 *keys, u32 *chaincodes, unsigned char *valid)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    if (idx >= n * 2) return;
+    const u64 seed = base + (idx >> 1);
+    const u32 sub = (u32)(idx & 1);
+    u32 s[8];
+    bool ok = true;
+    if (sub == 0) {
+        ok = transform_sha256(s, seed, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) s[i] = 0;
+        s[6] = (u32)(seed >> 32);
+        s[7] = (u32)seed;
+    }
+    u32 h1[8], h2[8], cc[8], k[8];
+    sha256_of_digest(h1, s);
+    sha256_of_digest(h2, h1);
+    armory_chaincode(cc, h2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = s[7 - i];
+    ok = ok && scalar_is_key(k);
+    uint4 *kd = reinterpret_cast<uint4 *>(keys) + idx * 2, *cd = reinterpret_cast<uint4 *>(chaincodes) + idx * 2;
+    kd[0] = ok ? make_uint4(bswap32(s[0]), bswap32(s[1]), bswap32(s[2]), bswap32(s[3])) : make_uint4(0, 0, 0, 0);
+    kd[1] = ok ? make_uint4(bswap32(s[4]), bswap32(s[5]), bswap32(s[6]), bswap32(s[7])) : make_uint4(0, 0, 0, 0);
+    cd[0] = make_uint4(cc[0], cc[1], cc[2], cc[3]);
+    cd[1] = make_uint4(cc[4], cc[5], cc[6], cc[7]);
+    valid[idx] = ok ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(VK_BLOCK) vk_armory_step_kernel(u64 items, const u32 *__restrict__ pub /* X || Y, raw bytes */, u32 *keys,
+                                                                  const u32 *__restrict__ chaincodes, unsigned char *valid)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    if (idx >= items || !valid[idx]) return;
+    fe ax, ay;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { // FE_BE(f, j) = big-endian word j
+        FE_BE(ax, i) = bswap32(pub[idx * 16 + i]);
+        FE_BE(ay, i) = bswap32(pub[idx * 16 + 8 + i]);
+    }
+    u32 d1[8], d2[8], s[8], k[8], nk[8];
+    sha256_pub65(d1, ax, ay);
+    sha256_of_digest(d2, d1);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        s[i] = d2[7 - i] ^ chaincodes[idx * 8 + 7 - i];
+        k[i] = bswap32(keys[idx * 8 + 7 - i]);
+    }
+    if (!scalar_is_key(s)) { // Scalar::from_be_bytes rejects >= n, mul_tweak rejects zero
+        valid[idx] = 0;
+        return;
+    }
+    scalar_mul_mod_n(nk, k, s);
+#pragma unroll
+    for (int i = 0; i < 8; i++) keys[idx * 8 + i] = bswap32(nk[7 - i]);
+}
+
 // Transform::apply_batch for Input::from_string inputs of the hash transforms: one lane per (string, slot)
 __global__ void __launch_bounds__(VK_BLOCK) vk_strings_kernel(vk_spec_dev spec, const unsigned char *data, const u32 *offsets, u64 n, u32 slots,
                                                               u32 *keys_out, unsigned char *valid, vk_ec_ctx ec)

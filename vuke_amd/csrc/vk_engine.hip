@@ -415,28 +415,58 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
 static int run_range_staged(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots, u64 lo, u64 span, u32 flags, const launch_io &io,
                             vk_sweep_stats *st)
 {
-    const u64 max_items = 1ull << 26; // 2 GB of keys per stage
+    // 2 GB of keys per stage; armory also parks a chain code and a public key per item (128 B + 1): 2^24 items = 2.2 GB
+    const u64 max_items = kind == VK_T_ARMORY ? 1ull << 24 : 1ull << 26;
     const u64 step_inputs = std::max<u64>(1, max_items / slots);
     u64 done = 0; // inputs
     for (;;) {
         const u64 left = span - done; // inclusive
         const u64 n = std::min<u64>(left, step_inputs - 1) + 1, items = n * slots;
-        SCRATCH(e, d_keys, u32 *, 5, items * 32 + items);
+        const size_t extra = kind == VK_T_ARMORY ? items * (32 + 64) : 0;
+        SCRATCH(e, d_keys, u32 *, 5, items * 32 + items + 64 + extra);
         unsigned char *d_valid = (unsigned char *)d_keys + items * 32;
+        double pre_seconds = 0.0; // kernel time of the staging work that is not a run_range of the caller's statistics
+        u32 pre_launches = 0;
         HIPCHK(e, hipEventRecord(e->ev0, e->stream));
         if (kind == VK_T_SHA256_CHAIN) {
             const u64 lanes = n * 2 * (spec.variant == VK_VARIANT_ALL ? 4 : 1);
             hipLaunchKernelGGL(vk_sha256_chain_range_kernel, dim3((u32)((lanes + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, spec, lo + done, n,
                                d_keys, d_valid);
         } else {
-            hipLaunchKernelGGL(vk_transform_kernel<VK_T_ARMORY>, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, spec,
-                               (const u64 *)nullptr, lo + done, n, slots, d_keys, d_valid, vk_ec_ctx{e->table, e->d_wins, e->nwin});
+            hipLaunchKernelGGL(vk_armory_begin_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, lo + done, n, d_keys,
+                               (u32 *)((unsigned char *)d_keys + ((items * 33 + 63) / 64) * 64), d_valid);
         }
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipEventRecord(e->ev1, e->stream));
         HIPCHK(e, hipStreamSynchronize(e->stream));
         float ms = 0.f;
         HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        pre_seconds += (double)ms * 1e-3;
+        pre_launches += 1;
+        if (kind == VK_T_ARMORY) {
+            // four times: public keys of the current keys from the sweep kernel (raw keys in, X || Y out), then the tweak
+            u32 *d_cc = (u32 *)((unsigned char *)d_keys + ((items * 33 + 63) / 64) * 64), *d_pub = d_cc + items * 8;
+            const vk_spec_dev rawspec = {VK_T_RAWKEYS, 0, 0, 0};
+            for (int step = 0; step < 4; step++) {
+                launch_io pio;
+                pio.in_keys = d_keys;
+                pio.in_valid = d_valid;
+                pio.out_pub = d_pub;
+                vk_sweep_stats tmp;
+                memset(&tmp, 0, sizeof tmp);
+                const int prc = run_range(e, rawspec, VK_T_RAWKEYS, 1, 0, items - 1, VK_F_COMPRESSED | VK_F_EMIT, pio, &tmp);
+                if (prc) return prc;
+                HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+                hipLaunchKernelGGL(vk_armory_step_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, items, d_pub, d_keys, d_cc,
+                                   d_valid);
+                HIPCHK(e, hipGetLastError());
+                HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+                HIPCHK(e, hipStreamSynchronize(e->stream));
+                HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+                pre_seconds += tmp.kernel_seconds + (double)ms * 1e-3;
+                pre_launches += tmp.launches + 1;
+            }
+        }
         launch_io sub = io;
         sub.in_keys = d_keys;
         sub.in_valid = d_valid;
@@ -450,8 +480,8 @@ static int run_range_staged(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32
         const vk_spec_dev raw = {VK_T_RAWKEYS, 0, 0, 0};
         const int rc = run_range(e, raw, VK_T_RAWKEYS, 1, 0, items - 1, flags, sub, st);
         if (rc) return rc;
-        st->kernel_seconds += (double)ms * 1e-3;
-        st->launches += 1;
+        st->kernel_seconds += pre_seconds;
+        st->launches += pre_launches;
         const u64 got = std::min<u64>(st->matches, io.hit_cap);
         for (u64 i = had; io.hits && i < got; i++) { // key index of this stage -> (input, slot)
             const u64 idx = io.hits[i].seed;
