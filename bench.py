@@ -543,6 +543,7 @@ def main():
             roof.update({"achieved": per_key * rate / 1e12, "frac": per_key * rate / PEAK_INT32,
                          "valu_insts_per_key": per_key, "pmc_source": pmc["source"], "pmc_csrc_hash": pmc["csrc_hash"], "pmc_git": pmc.get("git"),
                          "cycles_per_valu_inst_per_simd": pmc.get("cycles_per_valu_inst_per_simd"),
+                         "valu_busy_pct_in_profile": pmc.get("valu_busy_pct"),
                          "effective_clock_ghz_in_profile": pmc.get("effective_clock_ghz"),
                          "traffic": pmc.get("hbm_bytes_per_launch_calibrated", pmc.get("hbm_bytes_per_launch")),
                          "vgpr": pmc.get("dispatch", {}).get("VGPR_Count"), "scratch": pmc.get("dispatch", {}).get("Scratch_Size")})

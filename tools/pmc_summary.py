@@ -95,6 +95,10 @@ if "GRBM_GUI_ACTIVE" in counters and "SQ_INSTS_VALU" in counters and kstats:
     if kernel_s:
         out["effective_clock_ghz"] = cycles / kernel_s / 1e9
     out["cycles_per_valu_inst_per_simd"] = cycles * 1024 / counters["SQ_INSTS_VALU"]
+    # rocprof's derived metric VALUBusy = 100 * SQ_ACTIVE_INST_VALU * 4 / SIMD_NUM / GRBM_GUI_ACTIVE (per XCD): the share of
+    # cycles in which a SIMD's VALU is executing, at 4 cycles per wave-instruction
+    if "SQ_ACTIVE_INST_VALU" in counters:
+        out["valu_busy_pct"] = 100.0 * counters["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cycles
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters and keys_total:
     fetch, write = counters["FETCH_SIZE"] * 1024, counters["WRITE_SIZE"] * 1024
     out["hbm_fetch_bytes_raw"] = fetch
