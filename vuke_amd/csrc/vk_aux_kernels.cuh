@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_table_seed_kernel(uint4 *win, u32
     table_store(dst, x, y);
 }
 
-#define VK_TBL_K 8
+#define VK_TBL_K 16
 // combine phase for one window: one lane = one high digit i >= 1 and VK_TBL_K consecutive low digits
 __global__ void __launch_bounds__(VK_BLOCK) vk_table_combine_kernel(uint4 *win, u32 off, u32 tb, u32 h)
 {

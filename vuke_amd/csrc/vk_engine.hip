@@ -289,7 +289,7 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     for (u32 i = 0; i < e->nwin; i++) {
         const vk_win_desc &w = e->wins[i];
         u32 h = w.tb / 2;
-        if (h < 3) h = 3; // the combine kernel walks VK_TBL_K = 8 low digits per lane
+        if (h < 4) h = 4; // the combine kernel walks VK_TBL_K = 16 low digits per lane
         const u32 with_max = e->layout == VK_LAYOUT_SIGNED9 ? 1u : 0u;
         const u64 seeds = (1ull << h) + (1ull << (w.tb - h)) + with_max;
         const u64 runs = (1ull << (w.tb - h)) * ((1ull << h) / VK_TBL_K);
