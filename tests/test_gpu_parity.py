@@ -711,6 +711,14 @@ def test_armory_chain(eng, vko):
         want = [pyref.armory_key(hashlib.sha256(str(v).encode()).digest()), pyref.armory_key(bytes(24) + v.to_bytes(8, "big")) if v else None]
         assert row == want, v
     assert eng.transform_strings(gs, [b"armory", b""])[0] == [pyref.armory_key(hashlib.sha256(b"armory").digest())]
+    # string inputs take the batched chain too (root seed = SHA256(string), public keys from the sweep kernel): a few thousand against the oracle
+    rnd = random.Random(1234)
+    strs = [bytes(rnd.randrange(32, 127) for _ in range(rnd.randrange(0, 90))) for _ in range(3000)]
+    rows = eng.transform_strings(gs, strs)
+    for i in list(range(40)) + [999, 2047, 2048, 2999]:
+        assert rows[i] == [vko.transform_string(os_, strs[i], 0)], i
+    st, _ = eng.scan_strings(gs, strs)
+    assert (st["inputs"], st["keys"]) == (3000, sum(1 for r in rows if r[0] is not None))
     # sweep: counters, digest and planted hits against the oracle
     lo, hi = 1000, 1400
     planted = [(1003, 0, 0), (1111, 1, 1), (1400, 0, 2), (1000, 1, 0)]

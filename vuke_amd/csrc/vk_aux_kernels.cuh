@@ -194,17 +194,22 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_sha256_chain_range_kernel(vk_spec
 // sweep kernel itself (raw keys in, affine X || Y out: table reads through LDS, one field inversion per 256 keys) instead of a
 // k*G and an inversion per lane and step.  vk_armory_begin_kernel: seed -> (key, chaincode); four times { raw-key sweep with
 // out_pub; vk_armory_step_kernel: s = dSHA256(04 || X || Y) xor chaincode, key = key * s mod n }.
-__global__ void __launch_bounds__(VK_BLOCK) vk_armory_begin_kernel(u64 base, u64 n, u32 *keys, u32 *chaincodes, unsigned char *valid)
+// seeds32 != nullptr: one item per 32-byte root seed already in `keys` (string inputs: SHA256(string)); else the range form:
+// item = (input, slot), slot 0 seed = SHA256(decimal string), slot 1 seed = 24 zero bytes || 8 BE bytes
+__global__ void __launch_bounds__(VK_BLOCK) vk_armory_begin_kernel(u64 base, u64 n_items, const u32 *seeds32, u32 *keys, u32 *chaincodes, unsigned char *valid)
 {
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
-    if (idx >= n * 2) return;
-    const u64 seed = base + (idx >> 1);
-    const u32 sub = (u32)(idx & 1);
+    if (idx >= n_items) return;
     u32 s[8];
     bool ok = true;
-    if (sub == 0) {
-        ok = transform_sha256(s, seed, 0);
+    if (seeds32) {
+        ok = valid[idx] != 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[i] = bswap32(seeds32[idx * 8 + i]);
+    } else if ((idx & 1) == 0) {
+        ok = transform_sha256(s, base + (idx >> 1), 0);
     } else {
+        const u64 seed = base + (idx >> 1);
 #pragma unroll
         for (int i = 0; i < 6; i++) s[i] = 0;
         s[6] = (u32)(seed >> 32);
@@ -251,6 +256,14 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_armory_step_kernel(u64 items, con
     scalar_mul_mod_n(nk, k, s);
 #pragma unroll
     for (int i = 0; i < 8; i++) keys[idx * 8 + i] = bswap32(nk[7 - i]);
+}
+
+__global__ void __launch_bounds__(VK_BLOCK) vk_zero_invalid_keys_kernel(u64 items, u32 *keys, const unsigned char *valid)
+{
+    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
+    if (idx >= items || valid[idx]) return;
+    uint4 *d = reinterpret_cast<uint4 *>(keys) + idx * 2;
+    d[0] = d[1] = make_uint4(0, 0, 0, 0);
 }
 
 // Transform::apply_batch for Input::from_string inputs of the hash transforms: one lane per (string, slot)

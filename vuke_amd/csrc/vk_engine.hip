@@ -408,6 +408,33 @@ struct launch_io {
 
 static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots, u64 lo, u64 span, u32 flags, const launch_io &io, vk_sweep_stats *st);
 
+// armory's four chained steps over `items` keys that vk_armory_begin_kernel has prepared (keys, chain codes, validity flags):
+// public keys of the current keys from the sweep kernel (raw keys in, affine X || Y out), then the tweak
+static int armory_steps(vk_engine *e, u64 items, u32 *d_keys, unsigned char *d_valid, u32 *d_cc, u32 *d_pub, double *seconds, u32 *launches)
+{
+    const vk_spec_dev rawspec = {VK_T_RAWKEYS, 0, 0, 0};
+    for (int step = 0; step < 4; step++) {
+        launch_io pio;
+        pio.in_keys = d_keys;
+        pio.in_valid = d_valid;
+        pio.out_pub = d_pub;
+        vk_sweep_stats tmp;
+        memset(&tmp, 0, sizeof tmp);
+        const int prc = run_range(e, rawspec, VK_T_RAWKEYS, 1, 0, items - 1, VK_F_COMPRESSED | VK_F_EMIT, pio, &tmp);
+        if (prc) return prc;
+        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+        hipLaunchKernelGGL(vk_armory_step_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, items, d_pub, d_keys, d_cc, d_valid);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        *seconds += tmp.kernel_seconds + (double)ms * 1e-3;
+        *launches += tmp.launches + 1;
+    }
+    return VK_OK;
+}
+
 // The chained transforms (sha256_chain: up to `depth` dependent hashes per key; armory: four chained k*G per key) are swept in
 // two kernels: their keys go to HBM first (64 bytes of traffic per key next to ~900 for the sweep itself), then the raw-key
 // instantiation of the sweep kernel reads them back.  Fused, their state sat on top of the sweep kernel's 250 registers
@@ -433,8 +460,8 @@ static int run_range_staged(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32
             hipLaunchKernelGGL(vk_sha256_chain_range_kernel, dim3((u32)((lanes + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, spec, lo + done, n,
                                d_keys, d_valid);
         } else {
-            hipLaunchKernelGGL(vk_armory_begin_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, lo + done, n, d_keys,
-                               (u32 *)((unsigned char *)d_keys + ((items * 33 + 63) / 64) * 64), d_valid);
+            hipLaunchKernelGGL(vk_armory_begin_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, lo + done, items,
+                               (const u32 *)nullptr, d_keys, (u32 *)((unsigned char *)d_keys + ((items * 33 + 63) / 64) * 64), d_valid);
         }
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipEventRecord(e->ev1, e->stream));
@@ -444,28 +471,9 @@ static int run_range_staged(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32
         pre_seconds += (double)ms * 1e-3;
         pre_launches += 1;
         if (kind == VK_T_ARMORY) {
-            // four times: public keys of the current keys from the sweep kernel (raw keys in, X || Y out), then the tweak
             u32 *d_cc = (u32 *)((unsigned char *)d_keys + ((items * 33 + 63) / 64) * 64), *d_pub = d_cc + items * 8;
-            const vk_spec_dev rawspec = {VK_T_RAWKEYS, 0, 0, 0};
-            for (int step = 0; step < 4; step++) {
-                launch_io pio;
-                pio.in_keys = d_keys;
-                pio.in_valid = d_valid;
-                pio.out_pub = d_pub;
-                vk_sweep_stats tmp;
-                memset(&tmp, 0, sizeof tmp);
-                const int prc = run_range(e, rawspec, VK_T_RAWKEYS, 1, 0, items - 1, VK_F_COMPRESSED | VK_F_EMIT, pio, &tmp);
-                if (prc) return prc;
-                HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-                hipLaunchKernelGGL(vk_armory_step_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, items, d_pub, d_keys, d_cc,
-                                   d_valid);
-                HIPCHK(e, hipGetLastError());
-                HIPCHK(e, hipEventRecord(e->ev1, e->stream));
-                HIPCHK(e, hipStreamSynchronize(e->stream));
-                HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
-                pre_seconds += tmp.kernel_seconds + (double)ms * 1e-3;
-                pre_launches += tmp.launches + 1;
-            }
+            const int prc = armory_steps(e, items, d_keys, d_valid, d_cc, d_pub, &pre_seconds, &pre_launches);
+            if (prc) return prc;
         }
         launch_io sub = io;
         sub.in_keys = d_keys;
@@ -1053,7 +1061,24 @@ static int strings_to_device_keys(vk_engine *e, const vk_transform_spec *t, cons
     }
     const dim3 grid((u32)((n + VK_BLOCK - 1) / VK_BLOCK)), block(VK_BLOCK);
     const u32 groups = (u32)((n + 63) / 64);
-    if (!kdf) {
+    double extra_seconds = 0.0; // kernel time of sub-steps that record the engine's events themselves
+    if (t->kind == VK_T_ARMORY) {
+        // root seed = SHA256(string) from the strings kernel, then the batched chain of the range sweep (run_range_staged)
+        vk_spec_dev sha = to_dev(t);
+        sha.kind = VK_T_SHA256;
+        SCRATCH(e, d_cc, u32 *, 5, items * (32 + 64));
+        hipLaunchKernelGGL(vk_strings_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), block, 0, e->stream, sha, d_data, d_offs, (u64)n, slots, d_keys,
+                           d_valid, vk_ec_ctx{e->table, e->d_wins, e->nwin});
+        hipLaunchKernelGGL(vk_armory_begin_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), block, 0, e->stream, (u64)0, (u64)items, (const u32 *)d_keys,
+                           d_keys, d_cc, d_valid);
+        HIPCHK(e, hipGetLastError());
+        u32 nl = 0;
+        const int rc = armory_steps(e, items, d_keys, d_valid, d_cc, d_cc + items * 8, &extra_seconds, &nl); // records its own events
+        if (rc) return rc;
+        HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+        // a key the chain rejected (a tweak >= n or zero) is invalid and must read as zeros like every other invalid slot
+        hipLaunchKernelGGL(vk_zero_invalid_keys_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), block, 0, e->stream, (u64)items, d_keys, d_valid);
+    } else if (!kdf) {
         hipLaunchKernelGGL(vk_strings_kernel, dim3((u32)((items + VK_BLOCK - 1) / VK_BLOCK)), block, 0, e->stream, to_dev(t), d_data, d_offs, (u64)n, slots,
                            d_keys, d_valid, vk_ec_ctx{e->table, e->d_wins, e->nwin});
     } else if (t->kind == VK_T_MULTIBIT) {
@@ -1103,7 +1128,7 @@ chain_done:
         e->err = std::string("string transform on the device: ") + hipGetErrorString(c);
         return VK_E_HIP;
     }
-    if (kernel_seconds) *kernel_seconds = (double)ms * 1e-3;
+    if (kernel_seconds) *kernel_seconds = (double)ms * 1e-3 + extra_seconds;
     *d_keys_out = d_keys;
     *d_valid_out = d_valid;
     return VK_OK;
