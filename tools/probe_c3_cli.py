@@ -21,5 +21,6 @@ for i in range(3):
     r = subprocess.run([exe, "scan", "--transform", "sha256", "--targets", path, "range", "--start", "0", "--end", str(wl.C3_INPUTS - 1)],
                        capture_output=True, text=True, env=dict(os.environ, VUKE_HIP_TIMING="1"))
     dt = time.perf_counter() - t
-    print(f"cli run {i}: {dt:.3f} s  hits {r.stdout.count('========== HIT')}  stderr: {r.stderr.strip().splitlines()[-4:]}", flush=True)
+    tl = [l for l in r.stderr.strip().splitlines() if l.startswith('[timing]') or l.startswith('Done')]
+    print(f"cli run {i}: {dt:.3f} s  hits {r.stdout.count('========== HIT')}  stderr: {tl}", flush=True)
 os.remove(path)

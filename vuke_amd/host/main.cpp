@@ -369,11 +369,31 @@ int main(int argc, char **argv)
         if (devs.empty()) devs.push_back(device);
         vk_engine_opts opts{};
         opts.window_bits = window_bits;
-        // a sweep long enough to repay building (0.35 s) and holding the 120 GB table takes the faster geometry on its own
-        if (layout_auto && window_bits == 0 && have_range && end - start >= (1ull << 30) - 1) layout = VK_LAYOUT_SIGNED9;
+        // The table geometry follows the size of the job (keys = inputs x slots of every transform), by measured END-TO-END time
+        // (profiles/r02_strong_geometry.txt, profiles/r03_probe_c2_cli.txt): the 120 GB signed-window table sweeps a 2^32-key scan in
+        // 2.6 s instead of 3.4 s, but allocating and releasing 120 GB costs 0.4 s on a quiet box and 2 - 6 s when the memory has just
+        // been freed by another process (the driver scrubs VRAM), so it only pays from several sweeps' worth of keys on; in between
+        // the 43 GB W = 26 table (built in 0.1 s) is the fastest whole run; small jobs keep the 11.8 GB default.
+        if (layout_auto && window_bits == 0 && have_range) {
+            long double keys = 0;
+            for (const Transform &t : transforms) keys += (long double)(end - start) * (t.takes_strings() ? t.string_slots() : t.slots());
+            if (keys >= 0x1p34L) layout = VK_LAYOUT_SIGNED9;
+            else if (keys >= 0x1p31L) opts.window_bits = 26;
+        }
         opts.layout = layout;
         std::vector<vk_engine *> engines(devs.size(), nullptr);
-        struct Guard { std::vector<vk_engine *> &v; ~Guard() { for (vk_engine *e : v) vk_engine_destroy(e); } } guard{engines};
+        const bool timing_env = getenv("VUKE_HIP_TIMING") != nullptr;
+        const auto t_create = std::chrono::steady_clock::now();
+        struct Guard {
+            std::vector<vk_engine *> &v;
+            bool timing;
+            ~Guard()
+            {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (vk_engine *e : v) vk_engine_destroy(e);
+                if (timing) fprintf(stderr, "[timing] engines destroyed in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            }
+        } guard{engines, timing_env};
         for (int attempt = 0;; attempt++) {
             std::vector<int> rcs(devs.size(), VK_OK);
             std::vector<std::string> msgs(devs.size());
@@ -403,7 +423,8 @@ int main(int argc, char **argv)
             return 1;
         }
         vk_engine *engine = engines[0];
-        const bool timing = getenv("VUKE_HIP_TIMING") != nullptr; // stage times on stderr
+        const bool timing = timing_env; // stage times on stderr
+        if (timing) fprintf(stderr, "[timing] engines created in %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_create).count());
         const auto t_start = std::chrono::steady_clock::now();
         auto stamp = [&](const char *what) {
             if (timing) fprintf(stderr, "[timing] %s at %.3f s after engine creation\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
