@@ -83,3 +83,20 @@ def test_coalescer_lint_record_covers_the_kernel_sources_in_the_tree():
     rec = json.load(open(os.path.join(ROOT, "profiles", "lint_coalescer.json")))
     assert rec["dropped_outputs"] == 0 and rec.get("not_comparable", 0) == 0 and rec["asm_statements"] > 10000
     assert rec["csrc_hash"] == bench.csrc_hash(), "kernel sources changed: re-run tools/lint_coalescer.py (about 4 minutes)"
+
+
+def test_kernel_source_hash_ignores_comments_but_not_code(tmp_path, monkeypatch):
+    """bench.csrc_hash keys the committed PMC profiles / lint record on the kernel CODE: rewording a comment must not void them, a
+    changed token must (string literals count as code)."""
+    import bench
+    d = tmp_path / "vuke_amd" / "csrc"
+    d.mkdir(parents=True)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (d / "a.cuh").write_text('// one\nint f(int x) { return x + 1; } /* two */\nconst char *s = "// not a comment";\n')
+    h0 = bench.csrc_hash()
+    (d / "a.cuh").write_text('// a different remark\n\nint f(int x)   { return x + 1; }   /* gone\n over lines */\nconst char *s = "// not a comment";\n')
+    assert bench.csrc_hash() == h0
+    (d / "a.cuh").write_text('// one\nint f(int x) { return x + 2; } /* two */\nconst char *s = "// not a comment";\n')
+    assert bench.csrc_hash() != h0
+    (d / "a.cuh").write_text('// one\nint f(int x) { return x + 1; } /* two */\nconst char *s = "// not a comment!";\n')
+    assert bench.csrc_hash() != h0
