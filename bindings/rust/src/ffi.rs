@@ -3,7 +3,7 @@
 use core::mem::{offset_of, size_of};
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const VK_ABI_VERSION: c_int = 3;
+pub const VK_ABI_VERSION: c_int = 4;
 pub const VK_OK: c_int = 0;
 pub const VK_E_NO_DEVICE: c_int = -1;
 pub const VK_E_HIP: c_int = -2;
@@ -32,6 +32,22 @@ pub const VK_TARGET_P2WPKH: u8 = 1;
 pub const VK_ADDR_P2PKH_C: u32 = 0;
 pub const VK_ADDR_P2PKH_U: u32 = 1;
 pub const VK_ADDR_P2WPKH: u32 = 2;
+pub const VK_RC_SOURCE: usize = 0;
+pub const VK_RC_KEY_RAW: usize = 1;
+pub const VK_RC_KEY_HEX: usize = 2;
+pub const VK_RC_KEY_DECIMAL: usize = 3;
+pub const VK_RC_KEY_BINARY: usize = 4;
+pub const VK_RC_BIT_LENGTH: usize = 5;
+pub const VK_RC_HAMMING_WEIGHT: usize = 6;
+pub const VK_RC_LEADING_ZEROS: usize = 7;
+pub const VK_RC_PUBKEY_C: usize = 8;
+pub const VK_RC_PUBKEY_U: usize = 9;
+pub const VK_RC_P2PKH_C: usize = 10;
+pub const VK_RC_P2PKH_U: usize = 11;
+pub const VK_RC_P2WPKH: usize = 12;
+pub const VK_RC_WIF_C: usize = 13;
+pub const VK_RC_WIF_U: usize = 14;
+pub const VK_RC_COLUMNS: usize = 15;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -177,6 +193,20 @@ const _: () = assert!(offset_of!(VkSearchResult, keys) == 32);
 const _: () = assert!(offset_of!(VkSearchResult, variant) == 288);
 const _: () = assert!(offset_of!(VkSearchResult, index) == 292);
 
+/// vk_record_columns: the value columns of generate mode's full record as Parquet PLAIN page bytes (vk_generate_columns)
+#[repr(C)]
+pub struct VkRecordColumns {
+    pub data: [*mut u8; VK_RC_COLUMNS],
+    pub cap: [usize; VK_RC_COLUMNS],
+    pub len: [usize; VK_RC_COLUMNS],
+    pub rows: u64,
+}
+const _: () = assert!(size_of::<VkRecordColumns>() == 368);
+const _: () = assert!(offset_of!(VkRecordColumns, data) == 0);
+const _: () = assert!(offset_of!(VkRecordColumns, cap) == 120);
+const _: () = assert!(offset_of!(VkRecordColumns, len) == 240);
+const _: () = assert!(offset_of!(VkRecordColumns, rows) == 360);
+
 pub enum VkEngine {}
 
 extern "C" {
@@ -196,6 +226,13 @@ extern "C" {
     pub fn vk_generate_lines(e: *mut VkEngine, t: *const VkTransformSpec, seed_lo: u64, seed_hi_inclusive: u64, transform_name: *const c_char,
                              slot_suffix: *const *const c_char, text: *mut u8, text_cap: usize, text_len: *mut usize,
                              out: *mut VkSweepStats) -> c_int;
+    pub fn vk_generate_lines_strings(e: *mut VkEngine, t: *const VkTransformSpec, data: *const u8, offsets: *const u32, n: usize,
+                                     transform_name: *const c_char, slot_suffix: *const *const c_char, text: *mut u8, text_cap: usize,
+                                     text_len: *mut usize, out: *mut VkSweepStats) -> c_int;
+    pub fn vk_record_column_stride(column: c_int) -> usize;
+    pub fn vk_generate_columns(e: *mut VkEngine, t: *const VkTransformSpec, seed_lo: u64, seed_hi_inclusive: u64,
+                               slot_suffix: *const *const c_char, cols: *mut VkRecordColumns, out: *mut VkSweepStats) -> c_int;
+    pub fn vk_derive_columns(e: *mut VkEngine, keys: *const u8, n: usize, cols: *mut VkRecordColumns) -> c_int;
     pub fn vk_derive_batch(e: *mut VkEngine, keys: *const u8, n: usize, normalised: *mut u8, h160_c: *mut u8, h160_u: *mut u8) -> c_int;
     pub fn vk_derive_batch_pub(e: *mut VkEngine, keys: *const u8, n: usize, normalised: *mut u8, h160_c: *mut u8, h160_u: *mut u8,
                                pub_xy: *mut u8) -> c_int;

@@ -37,8 +37,9 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 3 /* 2: vk_sweep_stats.shader_clock_ghz, vk_scan_strings; 3: vk_generate_lines, vk_last_warning,
-                           vk_sweep_stats.inputs_skipped (was padding), string limits 448 bytes, vk_engine_opts.algo must be 0 */
+#define VK_ABI_VERSION 4 /* 2: vk_sweep_stats.shader_clock_ghz, vk_scan_strings; 3: vk_generate_lines, vk_last_warning,
+                           vk_sweep_stats.inputs_skipped (was padding), string limits 448 bytes, vk_engine_opts.algo must be 0;
+                           4: vk_generate_lines_strings, vk_generate_columns + vk_record_columns */
 
 /* error codes */
 #define VK_OK 0
@@ -192,6 +193,53 @@ int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint
  * transform_name are at most 31 bytes.  At most 2^21 (input, slot) pairs per call; text_cap >= 192 bytes per pair. */
 int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_t seed_hi_inclusive, const char *transform_name,
                       const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out);
+/* The same for WordlistSource / StdinSource in generate mode (src/source/wordlist.rs:24-77, src/output/console.rs:77-81): one
+ * line per (input string, slot) the reference emits,
+ *     {input string}{slot_suffix[slot]},{transform_name},{private key hex},{P2PKH address of the compressed key}\n
+ * slot_suffix = vk_slots_per_string(t) strings.  For the transforms whose label is the input itself plus a suffix (sha256,
+ * double_sha256, md5, direct, armory, sha256_chain); electrum and multibit labels are shortened forms of the input:
+ * VK_E_UNSUPPORTED (format those on the host).  At most 2^21 (input, slot) pairs and 4 GB of text per call;
+ * text_cap >= slots x the input bytes + 192 bytes per pair. */
+int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
+                              const char *transform_name, const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len,
+                              vk_sweep_stats *out);
+
+/* Generate mode's FULL record (DerivedKey, src/derive.rs:12-41, as src/storage/schema.rs:137-262 lays it out for the 19-column
+ * record batch) made on the device, column by column, for the inputs [seed_lo, seed_hi_inclusive]: one row per (input, slot) the
+ * reference emits, in input order.  Every column arrives as the bytes of a Parquet PLAIN page: string columns as a 4-byte
+ * little-endian length followed by the characters, VK_RC_KEY_RAW as 32 bytes per row, the three integer columns as 4-byte
+ * little-endian values.  Mainnet encodings (Network::Bitcoin).  The columns a writer still has to add are constant per call
+ * (transform, chain, timestamp, matched_target = null).  At most 2^20 (input, slot) pairs per call; every data[c] must hold
+ * vk_record_column_stride(c) bytes per pair.  slot_suffix as for vk_generate_lines. */
+#define VK_RC_SOURCE 0         /* "{input}{slot_suffix[slot]}" */
+#define VK_RC_KEY_RAW 1        /* private_key_raw, FixedSizeBinary(32) */
+#define VK_RC_KEY_HEX 2        /* 64 characters */
+#define VK_RC_KEY_DECIMAL 3    /* src/derive.rs:121 */
+#define VK_RC_KEY_BINARY 4     /* 256 characters, src/derive.rs:124-131 */
+#define VK_RC_BIT_LENGTH 5     /* INT32, src/derive.rs:134-141 */
+#define VK_RC_HAMMING_WEIGHT 6 /* INT32, src/derive.rs:144 */
+#define VK_RC_LEADING_ZEROS 7  /* INT32: leading '0' characters of the hex form, src/derive.rs:148 */
+#define VK_RC_PUBKEY_C 8       /* SEC1 compressed as hex, 66 characters */
+#define VK_RC_PUBKEY_U 9       /* SEC1 uncompressed as hex, 130 characters */
+#define VK_RC_P2PKH_C 10
+#define VK_RC_P2PKH_U 11
+#define VK_RC_P2WPKH 12
+#define VK_RC_WIF_C 13
+#define VK_RC_WIF_U 14
+#define VK_RC_COLUMNS 15
+typedef struct vk_record_columns {
+    uint8_t *data[VK_RC_COLUMNS]; /* caller's buffers */
+    size_t cap[VK_RC_COLUMNS];    /* their sizes */
+    size_t len[VK_RC_COLUMNS];    /* out: bytes written */
+    uint64_t rows;                /* out: records */
+} vk_record_columns;
+size_t vk_record_column_stride(int column); /* most bytes one row can take in that column (0 for an unknown column) */
+int vk_generate_columns(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_t seed_hi_inclusive, const char *const *slot_suffix,
+                        vk_record_columns *cols, vk_sweep_stats *out);
+/* KeyDeriver::derive (src/derive.rs:78-165) for n <= 2^20 raw keys, the whole record as the same columns, one row per key in
+ * input order (a key outside [1, n) is normalised like vk_derive_batch does).  The source column is the caller's:
+ * data[VK_RC_SOURCE] is not touched and len[VK_RC_SOURCE] = 0. */
+int vk_derive_columns(vk_engine *e, const uint8_t *keys, size_t n, vk_record_columns *cols);
 
 /* KeyDeriver::derive for callers that already hold keys (wordlist / stdin sources): raw 32-byte
  * keys in, normalised keys and hash160s out.  Any output pointer may be NULL. */

@@ -24,6 +24,7 @@ int main(void)
     F(vk_search_target, _pad); F(vk_search_target, bits); F(vk_search_target, targets);
     S(vk_search_result); F(vk_search_result, found); F(vk_search_result, n_keys); F(vk_search_result, seed); F(vk_search_result, seeds_checked);
     F(vk_search_result, kernel_seconds); F(vk_search_result, keys); F(vk_search_result, variant); F(vk_search_result, index);
+    S(vk_record_columns); F(vk_record_columns, data); F(vk_record_columns, cap); F(vk_record_columns, len); F(vk_record_columns, rows);
     printf("VK_ABI_VERSION . %d\n", VK_ABI_VERSION);
     return 0;
 }

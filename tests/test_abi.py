@@ -28,7 +28,7 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/vuke_hip.h but not exported"
     assert sorted(_ffi.EXPORTS) == names
-    assert L.vk_abi_version() == 3
+    assert L.vk_abi_version() == 4
 
 
 def test_struct_layouts_match_header():

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RS = open(os.path.join(ROOT, "bindings", "rust", "src", "ffi.rs")).read()
 HDR = open(os.path.join(ROOT, "include", "vuke_hip.h")).read()
 NAMES = {"vk_transform_spec": "VkTransformSpec", "vk_hit": "VkHit", "vk_sweep_stats": "VkSweepStats", "vk_engine_opts": "VkEngineOpts",
-         "vk_engine_info_t": "VkEngineInfo", "vk_search_target": "VkSearchTarget", "vk_search_result": "VkSearchResult"}
+         "vk_engine_info_t": "VkEngineInfo", "vk_search_target": "VkSearchTarget", "vk_search_result": "VkSearchResult",
+         "vk_record_columns": "VkRecordColumns"}
 
 
 def c_layout(tmp_path):
@@ -69,7 +70,8 @@ def test_ctypes_mirrors_equal_the_c_header(tmp_path):
     from vuke_amd import _ffi as ffi
     c = c_layout(tmp_path)
     for cname, cls in (("vk_transform_spec", ffi.TransformSpec), ("vk_hit", ffi.Hit), ("vk_sweep_stats", ffi.SweepStats), ("vk_engine_opts", ffi.EngineOpts),
-                       ("vk_engine_info_t", ffi.EngineInfo), ("vk_search_target", ffi.SearchTarget), ("vk_search_result", ffi.SearchResult)):
+                       ("vk_engine_info_t", ffi.EngineInfo), ("vk_search_target", ffi.SearchTarget), ("vk_search_result", ffi.SearchResult),
+                       ("vk_record_columns", ffi.RecordColumns)):
         assert ctypes.sizeof(cls) == c[(cname, ".")], cname
         for fname, _ in cls._fields_:
             assert getattr(cls, fname).offset == c[(cname, fname)], (cname, fname)

@@ -844,6 +844,129 @@ def test_generate_lines_on_the_device_equal_the_oracles_text(eng, vko):
         eng.generate_lines(ffi.spec(ffi.T_SHA256), 0, 1, "x" * 32, [""] * 3)          # name longer than 31 bytes
 
 
+def test_generate_lines_for_string_inputs_equal_the_oracles_text(eng, vko):
+    """vk_generate_lines_strings (wordlist / stdin source in generate mode, compact console format): the label is the input string
+    itself -- taken from the input buffer by the compaction kernel, any bytes, any length -- plus the slot's suffix
+    (src/transform/sha256_chain.rs:67); a line is missing where the reference emits nothing (direct with more than 32 bytes,
+    a zero key).  Against the oracle's keys and records."""
+    from vuke_amd import _ffi as ffi
+    CH = ("iterated", "indexed:be", "indexed:le", "counter")
+    rnd = random.Random(77)
+    strings = [b"a", b"abc", b"password", b"correct horse battery staple", "zażółć gęślą jaźń".encode(), b"x" * 32, b"y" * 33, b"," * 5]
+    strings += [bytes(rnd.randrange(1, 256) for _ in range(n)) for n in (1, 31, 55, 56, 63, 64, 65, 191, 192, 193, 1000, 5000)]
+    strings += [bytes(rnd.randrange(33, 127) for _ in range(rnd.randrange(1, 120))) for _ in range(700)]
+    strings += [bytes(32)]            # direct: the zero key, no line
+    cases = [(ffi.spec(k), vko.spec(k), nm, [""]) for k, nm in ((ffi.T_SHA256, "sha256"), (ffi.T_DOUBLE_SHA256, "double_sha256"), (ffi.T_MD5, "md5"),
+                                                               (ffi.T_DIRECT, "direct"), (ffi.T_ARMORY, "armory"))]
+    cases.append((ffi.spec(ffi.T_SHA256_CHAIN, ffi.VARIANT_ALL, 0, 3), vko.spec(vko.T_SHA256_CHAIN, vko.VARIANT_ALL, 0, 3), "sha256_chain",
+                  [f"[{v}:{i}]" for v in CH for i in range(3)]))
+    cases.append((ffi.spec(ffi.T_SHA256_CHAIN, 1, 0, 5), vko.spec(vko.T_SHA256_CHAIN, 1, 0, 5), "sha256_chain[indexed:be]", [f"[indexed:be:{i}]" for i in range(5)]))
+    for gs, osp, name, suffix in cases:
+        slots = vko.slots_per_string(osp)
+        assert slots == len(suffix)
+        text, st = eng.generate_lines_strings(gs, strings, name, suffix)
+        want = []
+        for s in strings:
+            for sub in range(slots):
+                k = vko.transform_string(osp, s, sub)
+                if k is None:
+                    continue
+                d = vko.derive(k)
+                want.append(s + suffix[sub].encode() + b"," + name.encode() + b"," + d.private_key_hex + b"," + d.p2pkh_compressed + b"\n")
+        assert text == b"".join(want), name
+        assert st["keys"] == len(want) and st["inputs"] == len(strings)
+    assert eng.generate_lines_strings(ffi.spec(ffi.T_SHA256), [], "sha256", [""])[0] == b""
+    text, _ = eng.generate_lines_strings(ffi.spec(ffi.T_SHA256), [b"", b"q", b""], "sha256", None)   # empty strings are inputs too; no suffix table
+    assert text.count(b"\n") == 3 and text.startswith(b",sha256,e3b0c442")
+    for kind in (ffi.T_ELECTRUM, ffi.T_MULTIBIT, ffi.T_MILKSAD):
+        with pytest.raises(Exception):
+            eng.generate_lines_strings(ffi.spec(kind), [b"00112233445566778899aabbccddeeff"], "x", None)
+
+
+def _plain_strings(values):
+    import struct
+    return b"".join(struct.pack("<I", len(v)) + v for v in values)
+
+
+def _columns_of(records, sources=None):
+    """The fifteen value columns as Parquet PLAIN page bytes from the oracle's records (vko.Derived)."""
+    import struct
+    cols = {
+        "private_key_raw": b"".join(bytes(d.raw) for d in records),
+        "private_key_hex": _plain_strings([d.private_key_hex for d in records]),
+        "private_key_decimal": _plain_strings([d.private_key_decimal for d in records]),
+        "private_key_binary": _plain_strings([d.private_key_binary for d in records]),
+        "private_key_bit_length": b"".join(struct.pack("<I", d.bit_length) for d in records),
+        "private_key_hamming_weight": b"".join(struct.pack("<I", d.hamming_weight) for d in records),
+        "private_key_leading_zeros": b"".join(struct.pack("<I", d.leading_zeros) for d in records),
+        "pubkey_compressed": _plain_strings([d.pubkey_compressed for d in records]),
+        "pubkey_uncompressed": _plain_strings([d.pubkey_uncompressed for d in records]),
+        "address_p2pkh_compressed": _plain_strings([d.p2pkh_compressed for d in records]),
+        "address_p2pkh_uncompressed": _plain_strings([d.p2pkh_uncompressed for d in records]),
+        "address_p2wpkh": _plain_strings([d.p2wpkh for d in records]),
+        "wif_compressed": _plain_strings([d.wif_compressed for d in records]),
+        "wif_uncompressed": _plain_strings([d.wif_uncompressed for d in records]),
+    }
+    cols["source"] = _plain_strings(sources) if sources is not None else b""
+    return cols
+
+
+def test_record_columns_on_the_device_equal_the_oracles_records(eng, vko):
+    """vk_derive_columns / vk_generate_columns: every field of DerivedKey (src/derive.rs:94-165) formatted on the device -- hex,
+    decimal, binary, bit length, Hamming weight, leading zeros, SEC1 keys as hex, both WIFs, both P2PKH addresses, P2WPKH -- and
+    laid out as Parquet PLAIN pages, against the oracle's records: edge keys (0 -> 1, 1, n - 1, n, 2^256 - 1, keys with leading
+    zero bytes and nibbles, the reference's pinned c4bb...), random keys, and ranges of every label shape with inputs that emit
+    nothing in between."""
+    from vuke_amd import _ffi as ffi
+    rnd = random.Random(2024)
+    keys = [bytes(32), (1).to_bytes(32, "big"), (N - 1).to_bytes(32, "big"), N.to_bytes(32, "big"), (N + 1).to_bytes(32, "big"), b"\xff" * 32, CHBS, bytes([1]) * 32]
+    keys += [(1 << b).to_bytes(32, "big") for b in (0, 3, 4, 7, 8, 31, 32, 63, 64, 127, 128, 200, 251, 252, 255)]
+    keys += [(rnd.getrandbits(rnd.randrange(1, 257)) or 1).to_bytes(32, "big") for _ in range(300)]
+    keys += [rnd.getrandbits(256).to_bytes(32, "big") for _ in range(700)]
+    got, rows = eng.derive_columns(keys)
+    want = _columns_of([vko.derive(k) for k in keys])
+    assert rows == len(keys)
+    for name in ffi.RC_NAMES:
+        assert got[name] == want[name], name
+    # hash160s with leading zero bytes (extra '1's in the address): keys found with the device, checked against the oracle
+    g = eng.generate(ffi.spec(ffi.T_SHA256), 0, 3999, flags=3)
+    zs = [g["privkeys"][32 * i:32 * i + 32] for i in range(g["n"]) if g["h160_c"][20 * i] == 0 or g["h160_u"][20 * i] == 0]
+    assert len(zs) >= 20
+    got, rows = eng.derive_columns(zs)
+    want = _columns_of([vko.derive(k) for k in zs])
+    assert b"\x00\x00\x0011" in got["address_p2pkh_compressed"] + got["address_p2pkh_uncompressed"]
+    for name in ffi.RC_NAMES:
+        assert got[name] == want[name], name
+    assert eng.derive_columns([])[1] == 0
+    # ranges: the source column too, and rows missing where the reference emits nothing
+    LCG, CH = ("glibc", "minstd", "msvc", "borland"), ("iterated", "indexed:be", "indexed:le", "counter")
+    cases = [
+        (ffi.spec(ffi.T_SHA256), vko.spec(vko.T_SHA256), [""] * 3, [(0, 200), (2**64 - 30, 2**64 - 1)]),
+        (ffi.spec(ffi.T_MILKSAD), vko.spec(vko.T_MILKSAD), [""], [(2**32 - 50, 2**32 + 20)]),
+        (ffi.spec(ffi.T_LCG), vko.spec(vko.T_LCG), [":" + n for n in LCG], [(2**31 - 40, 2**31 + 40)]),
+        (ffi.spec(ffi.T_SHA256_CHAIN, ffi.VARIANT_ALL, 0, 2), vko.spec(vko.T_SHA256_CHAIN, vko.VARIANT_ALL, 0, 2),
+         [f"[{v}:{i}]" for _ in range(2) for v in CH for i in range(2)], [(2**32 - 10, 2**32 + 10)]),
+    ]
+    for gs, osp, suffix, ranges in cases:
+        slots = vko.slots_per_input(osp)
+        assert slots == len(suffix)
+        for lo, hi in ranges:
+            got, rows, st = eng.generate_columns(gs, lo, hi, suffix)
+            recs, srcs = [], []
+            for seed in range(lo, hi + 1):
+                for sub in range(slots):
+                    k = vko.transform_key(osp, seed, sub)
+                    if k is not None:
+                        recs.append(vko.derive(k))
+                        srcs.append(f"{seed}{suffix[sub]}".encode())
+            want = _columns_of(recs, srcs)
+            assert rows == len(recs) == st["keys"]
+            for name in ffi.RC_NAMES:
+                assert got[name] == want[name], (gs.kind, lo, name)
+    with pytest.raises(Exception):
+        eng.generate_columns(ffi.spec(ffi.T_SHA256), 0, 2**19, [""] * 3)       # more than 2^20 (input, slot) pairs
+
+
 def fold_digests(parts):
     import bench_workloads as wl
     return wl.fold_digests(parts)

@@ -57,11 +57,21 @@ class SearchResult(C.Structure):
                 ("kernel_seconds", C.c_double), ("keys", (C.c_uint8 * 32) * 8), ("variant", C.c_uint32), ("index", C.c_uint32)]
 
 
+RC_COLUMNS = 15
+RC_NAMES = ("source", "private_key_raw", "private_key_hex", "private_key_decimal", "private_key_binary", "private_key_bit_length",
+            "private_key_hamming_weight", "private_key_leading_zeros", "pubkey_compressed", "pubkey_uncompressed", "address_p2pkh_compressed",
+            "address_p2pkh_uncompressed", "address_p2wpkh", "wif_compressed", "wif_uncompressed")   # VK_RC_* in order
+
+
+class RecordColumns(C.Structure):
+    _fields_ = [("data", C.c_void_p * RC_COLUMNS), ("cap", C.c_size_t * RC_COLUMNS), ("len", C.c_size_t * RC_COLUMNS), ("rows", C.c_uint64)]
+
+
 SEARCH_EXACT, SEARCH_MASKED, SEARCH_CASCADE = 0, 1, 2
 
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
-    "vk_last_error", "vk_last_warning", "vk_targets_set", "vk_sweep", "vk_generate", "vk_generate_lines", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
+    "vk_last_error", "vk_last_warning", "vk_targets_set", "vk_sweep", "vk_generate", "vk_generate_lines", "vk_generate_lines_strings", "vk_generate_columns", "vk_derive_columns", "vk_record_column_stride", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
     "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_scan_strings", "vk_rescan_strings", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
     "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop",
 ]
@@ -93,6 +103,11 @@ def load():
     L.vk_sweep.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_generate.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, vp, vp, vp, vp, C.POINTER(SweepStats)]
     L.vk_generate_lines.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, cp, C.POINTER(C.c_char_p), vp, sz, C.POINTER(sz), C.POINTER(SweepStats)]
+    L.vk_generate_lines_strings.argtypes = [vp, C.POINTER(TransformSpec), cp, C.POINTER(u32), sz, cp, C.POINTER(C.c_char_p), vp, sz, C.POINTER(sz), C.POINTER(SweepStats)]
+    L.vk_derive_columns.argtypes = [vp, cp, sz, C.POINTER(RecordColumns)]
+    L.vk_record_column_stride.restype = sz
+    L.vk_record_column_stride.argtypes = [C.c_int]
+    L.vk_generate_columns.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, C.POINTER(C.c_char_p), C.POINTER(RecordColumns), C.POINTER(SweepStats)]
     L.vk_derive_batch.argtypes = [vp, cp, sz, vp, vp, vp]
     L.vk_derive_batch_pub.argtypes = [vp, cp, sz, vp, vp, vp, vp]
     L.vk_transform_batch.argtypes = [vp, C.POINTER(TransformSpec), C.POINTER(u64), sz, vp, vp]
@@ -189,6 +204,48 @@ class Engine:
         if suffixes is not None:
             arr = (C.c_char_p * slots)(*[s if isinstance(s, bytes) else s.encode() for s in suffixes])
         self._chk(self._L.vk_generate_lines(self._e, C.byref(spec), lo, hi, name if isinstance(name, bytes) else name.encode(), arr, buf, len(buf), C.byref(ln), C.byref(st)))
+        return buf.raw[:ln.value], dict(keys=st.keys, inputs=st.inputs, kernel_seconds=st.kernel_seconds)
+
+    def _column_buffers(self, items):
+        rc = RecordColumns()
+        bufs = []
+        for c in range(RC_COLUMNS):
+            b = C.create_string_buffer(max(1, items * self._L.vk_record_column_stride(c)))
+            bufs.append(b)
+            rc.data[c] = C.cast(b, C.c_void_p)
+            rc.cap[c] = len(b)
+        return rc, bufs
+
+    def derive_columns(self, keys):
+        """KeyDeriver::derive as columns (vk_derive_columns): ({column name: PLAIN page bytes}, rows)."""
+        rc, bufs = self._column_buffers(len(keys))
+        self._chk(self._L.vk_derive_columns(self._e, b"".join(keys), len(keys), C.byref(rc)))
+        return {RC_NAMES[c]: bufs[c].raw[:rc.len[c]] for c in range(RC_COLUMNS)}, rc.rows
+
+    def generate_columns(self, spec, lo, hi, suffixes=None):
+        """The value columns of the full record (vk_generate_columns): ({column name: PLAIN page bytes}, rows, stats)."""
+        slots = self._L.vk_slots_per_input(C.byref(spec))
+        rc, bufs = self._column_buffers((hi - lo + 1) * slots)
+        arr = None
+        if suffixes is not None:
+            arr = (C.c_char_p * slots)(*[s if isinstance(s, bytes) else s.encode() for s in suffixes])
+        st = SweepStats()
+        self._chk(self._L.vk_generate_columns(self._e, C.byref(spec), lo, hi, arr, C.byref(rc), C.byref(st)))
+        return ({RC_NAMES[c]: bufs[c].raw[:rc.len[c]] for c in range(RC_COLUMNS)}, rc.rows,
+                dict(keys=st.keys, inputs=st.inputs, kernel_seconds=st.kernel_seconds))
+
+    def generate_lines_strings(self, spec, strings, name, suffixes=None):
+        """Compact CSV text of generate mode for string inputs (vk_generate_lines_strings): (bytes, stats)."""
+        blob, offs, n = pack_strings(strings)
+        slots = self._L.vk_slots_per_string(C.byref(spec))
+        buf = C.create_string_buffer(max(1, len(blob) * slots + n * slots * 192))
+        ln = C.c_size_t(0)
+        st = SweepStats()
+        arr = None
+        if suffixes is not None:
+            arr = (C.c_char_p * slots)(*[s if isinstance(s, bytes) else s.encode() for s in suffixes])
+        self._chk(self._L.vk_generate_lines_strings(self._e, C.byref(spec), blob, offs, n, name if isinstance(name, bytes) else name.encode(), arr, buf,
+                                                     len(buf), C.byref(ln), C.byref(st)))
         return buf.raw[:ln.value], dict(keys=st.keys, inputs=st.inputs, kernel_seconds=st.kernel_seconds)
 
     def derive_batch(self, keys):

@@ -10,6 +10,7 @@
 #include "vk_chain_keys.cuh"
 #include "vk_search.cuh"
 #include "vk_lines.cuh"
+#include "vk_records.cuh"
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -784,10 +785,12 @@ extern "C" int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint6
     if (rc) return rc;
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
     const u32 grid = (u32)((items + 255) / 256);
-    hipLaunchKernelGGL(vk_lines_kernel, dim3(grid), dim3(256), 0, e->stream, (u64)lo, items, slots, d_priv, d_hc, d_valid, d_texts, d_slots, d_lens);
+    hipLaunchKernelGGL(vk_lines_kernel, dim3(grid), dim3(256), 0, e->stream, (u64)lo, items, slots, d_priv, d_hc, d_valid, d_texts, (const u32 *)nullptr, d_slots,
+                       d_lens);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(d_scan + off_temp, temp_bytes, d_lens, d_offs32, (int)items, e->stream));
-    hipLaunchKernelGGL(vk_lines_compact_kernel, dim3((u32)((items + 63) / 64 * 64 + 255) / 256), dim3(256), 0, e->stream, items, d_slots, d_lens, d_offs32, d_text);
+    hipLaunchKernelGGL(vk_lines_compact_kernel, dim3((u32)((items + 63) / 64 * 64 + 255) / 256), dim3(256), 0, e->stream, items, slots, VK_LINE_STRIDE, d_slots, d_lens, d_offs32,
+                       (const unsigned char *)nullptr, (const u32 *)nullptr, d_text);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     u32 tail[2] = {0, 0};
@@ -804,6 +807,163 @@ extern "C" int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint6
     local.launches += 2;
     if (out) *out = local;
     return VK_OK;
+}
+
+extern "C" size_t vk_record_column_stride(int column) { return column >= 0 && column < VK_RC_COLUMNS ? vk_rc_stride(column) : 0; }
+
+// the device side of the record columns after the sweep has left keys, hash160s and public keys in the scratch slots 1-5:
+// slots per column -> lengths -> offsets -> packed pages -> the caller's buffers
+static int records_pack(vk_engine *e, u64 items, u32 slots, u64 lo, const unsigned char *d_texts /* nullptr: no source column */, vk_record_columns *cols,
+                        double *seconds)
+{
+    const u32 *d_priv = (const u32 *)e->scr[1], *d_hc = (const u32 *)e->scr[2], *d_hu = (const u32 *)e->scr[3], *d_pub = (const u32 *)e->scr[5];
+    const unsigned char *d_valid = (const unsigned char *)e->scr[4];
+    size_t base[VK_RC_COLUMNS + 1];
+    base[0] = 0;
+    for (int c = 0; c < VK_RC_COLUMNS; c++) base[c + 1] = base[c] + (size_t)items * vk_rc_stride(c);
+    SCRATCH(e, d_slots, unsigned char *, 6, base[VK_RC_COLUMNS]);
+    size_t temp_bytes = 0;
+    u32 *null32 = nullptr;
+    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, null32, null32, (int)items, e->stream));
+    // per column: items lengths; then one array of offsets (reused column after column) and hipcub's workspace
+    const size_t off_offs = (size_t)VK_RC_COLUMNS * items * 4, off_temp = ((off_offs + (items + 1) * 4 + 255) / 256) * 256;
+    SCRATCH(e, d_scan, unsigned char *, 7, off_temp + temp_bytes);
+    SCRATCH(e, d_packed, unsigned char *, 8, base[VK_RC_COLUMNS]);
+    u32 *d_offs32 = (u32 *)(d_scan + off_offs);
+    vk_record_slots rs;
+    for (int c = 0; c < VK_RC_COLUMNS; c++) {
+        rs.slot[c] = (u64 *)(d_slots + base[c]);
+        rs.lens[c] = (u32 *)d_scan + (size_t)c * items;
+    }
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    const u32 grid = (u32)((items + 255) / 256);
+    hipLaunchKernelGGL(vk_records_key_kernel, dim3(grid), dim3(256), 0, e->stream, lo, items, slots, d_priv, d_valid, d_texts, rs);
+    HIPCHK(e, hipGetLastError());
+    hipLaunchKernelGGL(vk_records_addr_kernel, dim3(grid), dim3(256), 0, e->stream, items, d_hc, d_hu, d_pub, d_valid, rs);
+    HIPCHK(e, hipGetLastError());
+    u32 tails[2 * VK_RC_COLUMNS]; // per column: offset and length of the last item
+    for (int c = 0; c < VK_RC_COLUMNS; c++) {
+        HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(d_scan + off_temp, temp_bytes, rs.lens[c], d_offs32, (int)items, e->stream));
+        hipLaunchKernelGGL(vk_lines_compact_kernel, dim3((u32)((items + 63) / 64 * 64 + 255) / 256), dim3(256), 0, e->stream, items, slots, vk_rc_stride(c),
+                           rs.slot[c], rs.lens[c], d_offs32, (const unsigned char *)nullptr, (const u32 *)nullptr, d_packed + base[c]);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipMemcpyAsync(&tails[2 * c], d_offs32 + (items - 1), 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(&tails[2 * c + 1], rs.lens[c] + (items - 1), 4, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    for (int c = 0; c < VK_RC_COLUMNS; c++) {
+        const size_t total = (size_t)tails[2 * c] + tails[2 * c + 1];
+        if (total) HIPCHK(e, hipMemcpyAsync(cols->data[c], d_packed + base[c], total, hipMemcpyDeviceToHost, e->stream));
+        cols->len[c] = total;
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    cols->rows = cols->len[VK_RC_KEY_RAW] / 32;
+    *seconds = (double)ms * 1e-3;
+    return VK_OK;
+}
+
+static int check_columns(vk_engine *e, vk_record_columns *cols, u64 items, bool with_source, const char *who)
+{
+    if (!cols) return fail(e, VK_E_INVALID_ARG, (std::string(who) + ": cols is NULL").c_str());
+    for (int c = 0; c < VK_RC_COLUMNS; c++) {
+        cols->len[c] = 0;
+        if (c == VK_RC_SOURCE && !with_source) continue;
+        if (!cols->data[c] || cols->cap[c] < items * vk_rc_stride(c))
+            return fail(e, VK_E_INVALID_ARG, (std::string(who) + ": every column buffer must hold vk_record_column_stride(column) bytes per row").c_str());
+    }
+    cols->rows = 0;
+    return VK_OK;
+}
+
+// RangeSource::process in generate mode into a sink that stores the full record (StorageOutput): the value columns of the record
+// made on the device (vk_records.cuh), each as the bytes of a Parquet PLAIN page.
+extern "C" int vk_generate_columns(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const char *const *slot_suffix,
+                                   vk_record_columns *cols, vk_sweep_stats *out)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int rc = validate_spec(e, t);
+    if (rc) return rc;
+    if (hi < lo) return fail(e, VK_E_INVALID_ARG, "seed_hi < seed_lo");
+    const u32 slots = vk_slots_per_input(t);
+    if (slots == 0) return fail(e, VK_E_UNSUPPORTED, "the transform emits nothing for numeric inputs");
+    if (hi - lo >= VK_RECORDS_MAX_ITEMS / slots) return fail(e, VK_E_INVALID_ARG, "vk_generate_columns: at most 2^20 (input, slot) pairs per call");
+    const u64 items = (hi - lo + 1) * slots;
+    rc = check_columns(e, cols, items, true, "vk_generate_columns");
+    if (rc) return rc;
+    std::vector<unsigned char> texts((size_t)slots * VK_LINE_SUFFIX_BYTES, 0);
+    for (u32 i = 0; i < slots; i++) {
+        const char *src = slot_suffix ? slot_suffix[i] : "";
+        const size_t n = src ? strlen(src) : 0;
+        if (n >= VK_LINE_SUFFIX_BYTES) return fail(e, VK_E_INVALID_ARG, "vk_generate_columns: label suffix longer than 31 bytes");
+        texts[(size_t)i * VK_LINE_SUFFIX_BYTES] = (unsigned char)n;
+        if (n) memcpy(&texts[(size_t)i * VK_LINE_SUFFIX_BYTES + 1], src, n);
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    SCRATCH(e, d_texts, unsigned char *, 0, texts.size());
+    SCRATCH(e, d_priv, u32 *, 1, items * 32);
+    SCRATCH(e, d_hc, u32 *, 2, items * 20);
+    SCRATCH(e, d_hu, u32 *, 3, items * 20);
+    SCRATCH(e, d_valid, unsigned char *, 4, items);
+    SCRATCH(e, d_pub, u32 *, 5, items * 64);
+    HIPCHK(e, hipMemcpy(d_texts, texts.data(), texts.size(), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemsetAsync(d_valid, 0, items, e->stream));
+    vk_sweep_stats local;
+    memset(&local, 0, sizeof local);
+    launch_io io;
+    io.out_priv = d_priv;
+    io.out_h160c = d_hc;
+    io.out_h160u = d_hu;
+    io.out_pub = d_pub;
+    io.out_valid = d_valid;
+    rc = run_range(e, to_dev(t), t->kind, slots, lo, hi - lo, VK_F_COMPRESSED | VK_F_UNCOMPRESSED | VK_F_EMIT, io, &local);
+    if (rc) return rc;
+    double sec = 0.0;
+    rc = records_pack(e, items, slots, lo, d_texts, cols, &sec);
+    if (rc) return rc;
+    local.inputs = hi - lo + 1;
+    local.kernel_seconds += sec;
+    local.launches += 2 + 2 * VK_RC_COLUMNS;
+    if (out) *out = local;
+    return VK_OK;
+}
+
+// KeyDeriver::derive (src/derive.rs:78-165) for n raw keys, the whole record as columns: what a source that already holds keys
+// (wordlist, stdin, files) hands to a storing sink.  The source column is the caller's (len[VK_RC_SOURCE] = 0).
+extern "C" int vk_derive_columns(vk_engine *e, const uint8_t *keys, size_t n, vk_record_columns *cols)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    int rc = check_columns(e, cols, n, false, "vk_derive_columns");
+    if (rc) return rc;
+    if (n == 0) return VK_OK;
+    if (!keys) return fail(e, VK_E_INVALID_ARG, "keys is NULL");
+    if (n > VK_RECORDS_MAX_ITEMS) return fail(e, VK_E_INVALID_ARG, "vk_derive_columns: at most 2^20 keys per call");
+    HIPCHK(e, hipSetDevice(e->device));
+    SCRATCH(e, d_in, u32 *, 0, n * 32);
+    SCRATCH(e, d_priv, u32 *, 1, n * 32);
+    SCRATCH(e, d_hc, u32 *, 2, n * 20);
+    SCRATCH(e, d_hu, u32 *, 3, n * 20);
+    SCRATCH(e, d_valid, unsigned char *, 4, n);
+    SCRATCH(e, d_pub, u32 *, 5, n * 64);
+    HIPCHK(e, hipMemcpy(d_in, keys, n * 32, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemsetAsync(d_valid, 1, n, e->stream)); // KeyDeriver::derive has a record for every key (0 -> 1, k >= n -> k mod n)
+    vk_sweep_stats local;
+    memset(&local, 0, sizeof local);
+    launch_io io;
+    io.in_keys = d_in;
+    io.out_priv = d_priv;
+    io.out_h160c = d_hc;
+    io.out_h160u = d_hu;
+    io.out_pub = d_pub;
+    const vk_spec_dev raw = {VK_T_RAWKEYS, 0, 0, 0};
+    rc = run_range(e, raw, VK_T_RAWKEYS, 1, 0, n - 1, VK_F_COMPRESSED | VK_F_UNCOMPRESSED | VK_F_EMIT, io, &local);
+    if (rc) return rc;
+    double sec = 0.0;
+    return records_pack(e, n, 1, 0, nullptr, cols, &sec);
 }
 
 extern "C" int vk_derive_batch_pub(vk_engine *e, const uint8_t *keys, size_t n, uint8_t *normalised, uint8_t *h160_c, uint8_t *h160_u,
@@ -1262,6 +1422,96 @@ extern "C" int vk_rescan_strings(vk_engine *e, uint32_t flags, vk_hit *hits, siz
         hits[i].seed = idx / e->rescan_slots;
         hits[i].sub_index = (u32)(idx % e->rescan_slots);
     }
+    return VK_OK;
+}
+
+// WordlistSource / StdinSource in generate mode with ConsoleOutput's compact format: the label of a line is the input string (plus
+// the slot's suffix), which the compaction kernel takes straight from the input buffer.
+extern "C" int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
+                                         const char *transform_name, const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len,
+                                         vk_sweep_stats *out)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->warn.clear();
+    int rc = validate_spec(e, t, true);
+    if (rc) return rc;
+    if (t->kind == VK_T_ELECTRUM || t->kind == VK_T_MULTIBIT)
+        return fail(e, VK_E_UNSUPPORTED, "vk_generate_lines_strings: electrum / multibit labels are shortened forms of the input; format those records on the host");
+    if (!transform_name || !text || !text_len) return fail(e, VK_E_INVALID_ARG, "transform_name / text / text_len is NULL");
+    *text_len = 0;
+    if (out) memset(out, 0, sizeof *out);
+    if (n == 0) return VK_OK;
+    if (!data || !offsets) return fail(e, VK_E_INVALID_ARG, "data / offsets is NULL");
+    const u32 slots = vk_slots_per_string(t);
+    if (slots == 0) return fail(e, VK_E_UNSUPPORTED, "the transform emits nothing for string inputs");
+    if ((u64)n * slots > VK_LINES_MAX_ITEMS) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines_strings: at most 2^21 (input, slot) pairs per call");
+    const u64 items = (u64)n * slots;
+    const u64 need = (u64)offsets[n] * slots + items * VK_LINE_STRIDE;
+    if (need >= (1ull << 32)) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines_strings: more than 4 GB of text in one call; pass fewer lines");
+    if (text_cap < need) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines_strings: text_cap must be at least slots x the input bytes + 192 bytes per (input, slot) pair");
+    std::vector<unsigned char> texts((size_t)(slots + 1) * VK_LINE_SUFFIX_BYTES, 0);
+    for (u32 i = 0; i <= slots; i++) {
+        const char *src = i < slots ? (slot_suffix ? slot_suffix[i] : "") : transform_name;
+        const size_t len = src ? strlen(src) : 0;
+        if (len >= VK_LINE_SUFFIX_BYTES) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines_strings: label suffix / transform name longer than 31 bytes");
+        texts[(size_t)i * VK_LINE_SUFFIX_BYTES] = (unsigned char)len;
+        if (len) memcpy(&texts[(size_t)i * VK_LINE_SUFFIX_BYTES + 1], src, len);
+    }
+    u32 *d_keys = nullptr;
+    unsigned char *d_valid = nullptr;
+    size_t overlong = 0;
+    double tsec = 0.0;
+    rc = strings_to_device_keys(e, t, data, offsets, n, slots, &d_keys, &d_valid, &overlong, &tsec); // strings -> slot 0, offsets -> slot 2
+    if (rc) return rc;
+    const unsigned char *d_data = (const unsigned char *)e->scr[0];
+    const u32 *d_offs = (const u32 *)e->scr[2];
+    SCRATCH(e, d_texts, unsigned char *, 9, texts.size());
+    SCRATCH(e, d_priv, u32 *, 3, items * 32);
+    SCRATCH(e, d_hc, u32 *, 5, items * 20);
+    SCRATCH(e, d_slots, u64 *, 6, items * VK_LINE_STRIDE);
+    size_t temp_bytes = 0;
+    u32 *null32 = nullptr;
+    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, null32, null32, (int)items, e->stream));
+    const size_t off_offs = (items + 1) * 4, off_temp = ((off_offs + (items + 1) * 4 + 255) / 256) * 256;
+    SCRATCH(e, d_scan, unsigned char *, 7, off_temp + temp_bytes);
+    u32 *d_lens = (u32 *)d_scan, *d_offs32 = (u32 *)(d_scan + off_offs);
+    SCRATCH(e, d_text, unsigned char *, 8, (size_t)need);
+    HIPCHK(e, hipMemcpy(d_texts, texts.data(), texts.size(), hipMemcpyHostToDevice));
+    vk_sweep_stats local;
+    memset(&local, 0, sizeof local);
+    launch_io io;
+    io.in_keys = d_keys;
+    io.in_valid = d_valid;
+    io.out_priv = d_priv;
+    io.out_h160c = d_hc;
+    const vk_spec_dev raw = {VK_T_RAWKEYS, 0, 0, 0};
+    rc = run_range(e, raw, VK_T_RAWKEYS, 1, 0, items - 1, VK_F_COMPRESSED | VK_F_EMIT, io, &local);
+    if (rc) return rc;
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    hipLaunchKernelGGL(vk_lines_kernel, dim3((u32)((items + 255) / 256)), dim3(256), 0, e->stream, (u64)0, items, slots, d_priv, d_hc, d_valid, d_texts, d_offs, d_slots,
+                       d_lens);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(d_scan + off_temp, temp_bytes, d_lens, d_offs32, (int)items, e->stream));
+    hipLaunchKernelGGL(vk_lines_compact_kernel, dim3((u32)((items + 63) / 64 * 64 + 255) / 256), dim3(256), 0, e->stream, items, slots, VK_LINE_STRIDE, d_slots, d_lens, d_offs32, d_data,
+                       d_offs, d_text);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+    u32 tail[2] = {0, 0};
+    HIPCHK(e, hipMemcpyAsync(&tail[0], d_offs32 + (items - 1), 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(&tail[1], d_lens + (items - 1), 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    float ms = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    const size_t total = (size_t)tail[0] + tail[1];
+    if (total) HIPCHK(e, hipMemcpy(text, d_text, total, hipMemcpyDeviceToHost));
+    *text_len = total;
+    local.inputs = n;
+    local.kernel_seconds += tsec + (double)ms * 1e-3;
+    local.launches += 3;
+    note_overlong(e, t, overlong);
+    local.inputs_skipped = (uint32_t)std::min<size_t>(overlong, 0xFFFFFFFFu);
+    if (out) *out = local;
     return VK_OK;
 }
 

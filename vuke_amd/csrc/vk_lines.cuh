@@ -117,11 +117,13 @@ VK_DEV void lines_put_text(vk_stage_writer &wr, const unsigned char *__restrict_
     for (u32 i = 0; i < n; i++) wr.put(entry[1 + i], 1);
 }
 
-// one lane per item of a vk_generate chunk: item = input * slots + slot, input = lo + item / slots
+// one lane per item of a vk_generate chunk: item = input * slots + slot, input = lo + item / slots.  String sources
+// (str_offs != nullptr): the label's first part is the input string itself -- it is not copied into the slot, the compaction
+// kernel takes it from the input buffer; the slot holds what follows it.
 __global__ void __launch_bounds__(256) vk_lines_kernel(u64 lo, u64 items, u32 slots, const u32 *__restrict__ priv, const u32 *__restrict__ h160c,
                                                       const unsigned char *__restrict__ valid,
                                                       const unsigned char *__restrict__ texts /* slots suffix entries, then the transform name */,
-                                                      u64 *__restrict__ line_slots, u32 *__restrict__ lens)
+                                                      const u32 *__restrict__ str_offs, u64 *__restrict__ line_slots, u32 *__restrict__ lens)
 {
     const u64 item = (u64)blockIdx.x * 256 + threadIdx.x;
     if (item >= items) return;
@@ -133,7 +135,9 @@ __global__ void __launch_bounds__(256) vk_lines_kernel(u64 lo, u64 items, u32 sl
     const u32 sub = (u32)(item - input * slots);
     vk_stage_writer wr;
     wr.init(line_slots + item * (VK_LINE_STRIDE / 8));
-    lines_put_decimal(wr, lo + input);
+    u32 label_len = 0;
+    if (str_offs) label_len = str_offs[input + 1] - str_offs[input];
+    else lines_put_decimal(wr, lo + input);
     lines_put_text(wr, texts + (u64)sub * VK_LINE_SUFFIX_BYTES);
     wr.put(',', 1);
     lines_put_text(wr, texts + (u64)slots * VK_LINE_SUFFIX_BYTES);
@@ -146,14 +150,16 @@ __global__ void __launch_bounds__(256) vk_lines_kernel(u64 lo, u64 items, u32 sl
     for (int i = 0; i < 5; i++) h[i] = h160c[item * 5 + i];
     lines_put_p2pkh(wr, h);
     wr.put('\n', 1);
-    lens[item] = wr.finish(0);
+    lens[item] = label_len + wr.finish(0);
 }
 
 // one wave per 64 consecutive lines: offs[] = exclusive scan of lens[]; the wave's output region is contiguous, every lane
 // stores the bytes lane, lane + 64, ... of it (64 consecutive bytes per store), finding the line of a byte by a search over
 // the 64 offsets of the group held one per lane
-__global__ void __launch_bounds__(256) vk_lines_compact_kernel(u64 items, const u64 *__restrict__ line_slots, const u32 *__restrict__ lens,
-                                                              const u32 *__restrict__ offs, unsigned char *__restrict__ text)
+__global__ void __launch_bounds__(256) vk_lines_compact_kernel(u64 items, u32 slots, u32 stride /* bytes per slot */, const u64 *__restrict__ line_slots,
+                                                              const u32 *__restrict__ lens,
+                                                              const u32 *__restrict__ offs, const unsigned char *__restrict__ str_data,
+                                                              const u32 *__restrict__ str_offs, unsigned char *__restrict__ text)
 {
     const u32 lane = threadIdx.x & 63u;
     const u64 group = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6, first = group * 64;
@@ -177,6 +183,18 @@ __global__ void __launch_bounds__(256) vk_lines_compact_kernel(u64 items, const 
             if (cand <= last && o <= pos) l = cand;
         }
         const u32 lo_off = __shfl(my_off, l, 64);
-        if (pos < end) text[pos] = src[(first + l) * VK_LINE_STRIDE + (pos - lo_off)];
+        if (pos < end) {
+            u32 k = pos - lo_off;
+            const u64 item = first + l;
+            unsigned char byte;
+            if (str_offs) { // a string source's line = the input string, then the slot
+                const u64 input = item / slots;
+                const u32 so = str_offs[input], ll = str_offs[input + 1] - so;
+                byte = k < ll ? str_data[so + k] : src[item * stride + (k - ll)];
+            } else {
+                byte = src[item * stride + k];
+            }
+            text[pos] = byte;
+        }
     }
 }

@@ -11,6 +11,8 @@
 #include "vuke_host.hpp"
 
 #include <algorithm>
+#include <array>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <ctime>
@@ -353,12 +355,40 @@ struct StorageOutput::Impl {
         if (fwrite(s.data(), 1, s.size(), fp) != s.size()) throw std::runtime_error("write failed: " + path);
         file_pos += s.size();
     }
+    // one row group: the nineteen column chunks (one PLAIN data page each) in schema order
+    void emit_group(uint64_t rows, const std::string (&body)[19], const std::string (&packed)[19])
+    {
+        RowGroupMeta g;
+        g.rows = (int64_t)rows;
+        g.bytes = 0;
+        for (int c = 0; c < 19; c++) {
+            Thrift h; // PageHeader
+            h.begin();
+            h.i32(1, 0); // DATA_PAGE
+            h.i32(2, (int32_t)body[c].size());
+            h.i32(3, (int32_t)packed[c].size());
+            h.struct_field(5); // DataPageHeader
+            h.i32(1, (int32_t)rows);
+            h.i32(2, 0); // PLAIN
+            h.i32(3, 3); // RLE
+            h.i32(4, 3);
+            h.end();
+            h.end();
+            ChunkMeta m;
+            m.data_page_offset = (int64_t)file_pos;
+            m.size = (int64_t)(h.out.size() + packed[c].size());
+            m.raw_size = (int64_t)(h.out.size() + body[c].size());
+            m.num_values = (int64_t)rows;
+            write(h.out);
+            write(packed[c]);
+            g.bytes += m.raw_size;
+            g.cols.push_back(m);
+        }
+        groups.push_back(g);
+    }
     void flush_group()
     {
         if (group_rows == 0) return;
-        RowGroupMeta g;
-        g.rows = (int64_t)group_rows;
-        g.bytes = 0;
         // page bodies are built and compressed column by column on their own threads, then written in schema order
         std::string body[19], packed[19];
         std::exception_ptr err[19];
@@ -382,32 +412,11 @@ struct StorageOutput::Impl {
         }
         for (int c = 0; c < 19; c++)
             if (err[c]) std::rethrow_exception(err[c]);
+        emit_group(group_rows, body, packed);
         for (int c = 0; c < 19; c++) {
-            Thrift h; // PageHeader
-            h.begin();
-            h.i32(1, 0); // DATA_PAGE
-            h.i32(2, (int32_t)body[c].size());
-            h.i32(3, (int32_t)packed[c].size());
-            h.struct_field(5); // DataPageHeader
-            h.i32(1, (int32_t)group_rows);
-            h.i32(2, 0); // PLAIN
-            h.i32(3, 3); // RLE
-            h.i32(4, 3);
-            h.end();
-            h.end();
-            ChunkMeta m;
-            m.data_page_offset = (int64_t)file_pos;
-            m.size = (int64_t)(h.out.size() + packed[c].size());
-            m.raw_size = (int64_t)(h.out.size() + body[c].size());
-            m.num_values = (int64_t)group_rows;
-            write(h.out);
-            write(packed[c]);
-            g.bytes += m.raw_size;
-            g.cols.push_back(m);
             cols[c].values.clear();
             cols[c].defs.clear();
         }
-        groups.push_back(g);
         group_rows = 0;
     }
     void close_chunk()
@@ -494,6 +503,145 @@ struct StorageOutput::Impl {
         fp = nullptr;
         completed.push_back(path);
     }
+    // A run of records whose value columns were made on the device (vk_generate_columns / vk_derive_columns: Parquet PLAIN bytes per
+    // column).  Same rotation rules as add(), applied row by row on the lengths; the pages of a row group are only framed,
+    // compressed and written here, many at a time on the host's threads.
+    void add_columns(const vk_record_columns &b, const std::string &tf, const uint8_t *source_col, size_t source_len)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        const uint64_t R = b.rows;
+        if (R == 0) return;
+        flush_group(); // records added one by one so far form their own row group
+        // device column -> schema column; bytes per row of the fixed-width ones (0 = variable: walk the length prefixes)
+        static const int SCHEMA_OF[VK_RC_COLUMNS] = {0, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18};
+        static const uint32_t WIDTH[VK_RC_COLUMNS] = {0, 32, 68, 0, 260, 4, 4, 4, 70, 134, 0, 0, 46, 56, 55};
+        const uint8_t *data[VK_RC_COLUMNS];
+        size_t len[VK_RC_COLUMNS];
+        for (int c = 0; c < VK_RC_COLUMNS; c++) {
+            data[c] = b.data[c];
+            len[c] = b.len[c];
+        }
+        if (source_col) { // the caller's labels (vk_derive_columns leaves the column to it)
+            data[VK_RC_SOURCE] = source_col;
+            len[VK_RC_SOURCE] = source_len;
+        }
+        uint64_t fixed = 0;
+        for (int c = 0; c < VK_RC_COLUMNS; c++) {
+            fixed += WIDTH[c];
+            if (WIDTH[c] && len[c] != R * WIDTH[c]) throw std::runtime_error("add_columns: a fixed-width column does not hold rows x width bytes");
+        }
+        fixed += 4 + tf.size() + 4 + 7 + 8; // transform, chain = "bitcoin", timestamp
+        struct Piece {
+            uint64_t row0, row1;
+            size_t v0[VK_RC_COLUMNS], v1[VK_RC_COLUMNS];
+            uint64_t records_after, bytes_after;
+            bool close_after;
+        };
+        std::vector<Piece> pieces;
+        size_t cur[VK_RC_COLUMNS] = {0};
+        Piece pc;
+        pc.row0 = 0;
+        memset(pc.v0, 0, sizeof pc.v0);
+        uint64_t sim_records = fp ? chunk_records : 0, sim_bytes = fp ? chunk_bytes : 0, grows = 0;
+        for (uint64_t r = 0; r < R; r++) {
+            uint64_t sz = fixed;
+            for (int c = 0; c < VK_RC_COLUMNS; c++) {
+                if (WIDTH[c]) continue;
+                if (cur[c] + 4 > len[c]) throw std::runtime_error("add_columns: a string column ends inside a value");
+                const uint32_t l = load32(data[c] + cur[c]);
+                cur[c] += 4 + (size_t)l;
+                sz += 4 + l;
+            }
+            sim_bytes += sz;
+            sim_records++;
+            grows++;
+            const bool rotate = (max_chunk_records && sim_records >= max_chunk_records) || (max_chunk_bytes && sim_bytes >= max_chunk_bytes);
+            if (grows == 65536 || rotate || r + 1 == R) {
+                pc.row1 = r + 1;
+                for (int c = 0; c < VK_RC_COLUMNS; c++) pc.v1[c] = WIDTH[c] ? (size_t)(r + 1) * WIDTH[c] : cur[c];
+                pc.close_after = rotate;
+                pc.records_after = sim_records;
+                pc.bytes_after = sim_bytes;
+                pieces.push_back(pc);
+                pc.row0 = r + 1;
+                memcpy(pc.v0, pc.v1, sizeof pc.v0);
+                grows = 0;
+                if (rotate) sim_records = sim_bytes = 0;
+            }
+        }
+        for (int c = 0; c < VK_RC_COLUMNS; c++)
+            if (!WIDTH[c] && cur[c] != len[c]) throw std::runtime_error("add_columns: a string column holds more values than rows");
+        const int64_t now_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+        // pages of up to WAVE row groups at a time: built and compressed on the host's threads, written in order
+        const size_t WAVE = 8;
+        const unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+        for (size_t w0 = 0; w0 < pieces.size(); w0 += WAVE) {
+            const size_t wn = std::min(WAVE, pieces.size() - w0);
+            std::vector<std::array<std::string, 19>> body(wn), packed(wn);
+            std::atomic<size_t> next{0};
+            std::exception_ptr err;
+            std::mutex err_mu;
+            auto work = [&]() {
+                for (;;) {
+                    const size_t task = next.fetch_add(1);
+                    if (task >= wn * 19) return;
+                    const size_t pi = task / 19;
+                    const int col = (int)(task % 19);
+                    const Piece &q = pieces[w0 + pi];
+                    const uint64_t n = q.row1 - q.row0;
+                    try {
+                        std::string &out = body[pi][col];
+                        if (COLS[col].optional) { // definition levels: one RLE run
+                            Thrift t;
+                            t.varint(n << 1);
+                            t.out.push_back(col == 4 ? 0 : 1);
+                            put_le32(out, (uint32_t)t.out.size());
+                            out += t.out;
+                        }
+                        if (col == 1 || col == 2) {
+                            std::string one;
+                            const std::string &v = col == 1 ? tf : std::string("bitcoin");
+                            put_le32(one, (uint32_t)v.size());
+                            one += v;
+                            out.reserve(out.size() + n * one.size());
+                            for (uint64_t i = 0; i < n; i++) out += one;
+                        } else if (col == 3) {
+                            std::string one;
+                            put_le64(one, (uint64_t)now_ms);
+                            out.reserve(n * 8);
+                            for (uint64_t i = 0; i < n; i++) out += one;
+                        } else if (col != 4) {
+                            int dc = 0;
+                            while (SCHEMA_OF[dc] != col) dc++;
+                            out.append((const char *)data[dc] + q.v0[dc], q.v1[dc] - q.v0[dc]);
+                        }
+                        packed[pi][col] = compress_page(codec, level, out);
+                    } catch (...) {
+                        std::lock_guard<std::mutex> g(err_mu);
+                        if (!err) err = std::current_exception();
+                    }
+                }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++) th.emplace_back(work);
+            for (auto &t : th) t.join();
+            if (err) std::rethrow_exception(err);
+            for (size_t pi = 0; pi < wn; pi++) {
+                const Piece &q = pieces[w0 + pi];
+                if (!fp) open_chunk();
+                std::string bs[19], ps[19];
+                for (int c = 0; c < 19; c++) {
+                    bs[c].swap(body[pi][c]);
+                    ps[c].swap(packed[pi][c]);
+                }
+                emit_group(q.row1 - q.row0, bs, ps);
+                chunk_records = q.records_after; // what add() would have counted up to this row
+                chunk_bytes = q.bytes_after;
+                total_records += q.row1 - q.row0;
+                if (q.close_after) close_chunk();
+            }
+        }
+    }
     void add(const std::string &source, const std::string &tf, const DerivedKey &d, const std::string *matched)
     {
         std::lock_guard<std::mutex> lk(mu);
@@ -569,6 +717,11 @@ void StorageOutput::hit(const std::string &source, const std::string &transform,
     impl_->add(source, transform, d, &m.address);
 }
 void StorageOutput::flush() {}
+bool StorageOutput::write_columns(const vk_record_columns &cols, const std::string &transform, const uint8_t *source_col, size_t source_len)
+{
+    impl_->add_columns(cols, transform, source_col, source_len);
+    return true;
+}
 std::vector<std::string> StorageOutput::finish()
 {
     std::lock_guard<std::mutex> lk(impl_->mu);

@@ -190,6 +190,8 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
         std::string warning;           // over-long inputs the device skipped (vk_last_warning after VK_OK)
         std::vector<vk_hit> hits;
         std::vector<DerivedKey> hit_derived;
+        std::vector<uint8_t> text;     // generate, compact console format: the lines as the device wrote them
+        bool as_text = false;
     };
     // one vk_transform_strings / vk_scan_strings call carries at most 2^28 keys: size the batch by keys, not by lines
     uint32_t max_slots = 1;
@@ -206,6 +208,11 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
         for (const Transform &t : transforms) {
             const uint32_t k = t.string_slots();
             if (k == 0) continue; // a transform that needs Input::u64_val pushes nothing for a passphrase
+            // generate mode into a sink that takes text, from a transform whose label is the input plus a per-slot suffix
+            auto text_ok = [&](const Transform &tr) {
+                return !matcher && !full && !want_pub && output.accepts_text() && !getenv("VUKE_HIP_RECORD_PATH") && tr.spec().kind != VK_T_ELECTRUM && tr.spec().kind != VK_T_MULTIBIT &&
+                       strlen(tr.name()) < 32 && tr.string_slots() <= (1u << 16);
+            };
             auto run_slice = [&](vk_engine *eng, size_t first, size_t cnt, SliceOut &o) {
                 std::vector<uint32_t> offs(cnt + 1);
                 for (size_t i = 0; i <= cnt; i++) offs[i] = b.offs[first + i] - b.offs[first];
@@ -231,6 +238,35 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                         o.slot_of.push_back((uint32_t)((first + (size_t)o.hits[i].seed) * k + o.hits[i].sub_index));
                     }
                     if (!hk.empty()) o.hit_derived = KeyDeriver(eng).derive(hk);
+                    return;
+                }
+                if (text_ok(t)) {
+                    // compact console output: the lines come back as text (vk_generate_lines_strings: the label is the input
+                    // string plus the slot's suffix), 2^21 (input, slot) pairs per call
+                    std::vector<std::string> suffix(k);
+                    std::vector<const char *> sp(k);
+                    for (uint32_t s = 0; s < k; s++) {
+                        suffix[s] = t.label(std::string(), s);
+                        sp[s] = suffix[s].c_str();
+                    }
+                    o.as_text = true;
+                    const size_t per = std::max<size_t>(1, (1u << 21) / k);
+                    std::vector<uint32_t> sub;
+                    for (size_t a = 0; a < cnt; a += per) {
+                        const size_t c = std::min(per, cnt - a);
+                        sub.resize(c + 1);
+                        for (size_t i = 0; i <= c; i++) sub[i] = offs[a + i] - offs[a];
+                        const size_t at = o.text.size(), cap = (size_t)sub[c] * k + c * k * 192;
+                        o.text.resize(at + cap);
+                        size_t len = 0;
+                        vk_sweep_stats ss;
+                        check_rc(eng, vk_generate_lines_strings(eng, &t.spec(), b.data.data() + b.offs[first] + offs[a], sub.data(), c, t.name(), sp.data(),
+                                                                o.text.data() + at, cap, &len, &ss));
+                        const std::string w = last_warning(eng);
+                        if (!w.empty()) o.warning = w;
+                        o.text.resize(at + len);
+                        o.nkeys += (size_t)ss.keys;
+                    }
                     return;
                 }
                 std::vector<uint8_t> keys(cnt * k * 32), valid(cnt * k);
@@ -278,6 +314,10 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                 const size_t m = o.slot_of.size();
                 st.keys_generated += o.nkeys;
                 if (o.warning.rfind("warning:", 0) == 0) fprintf(stderr, "%s (%s)\n", o.warning.c_str(), t.name());
+                if (o.as_text) {
+                    if (!o.text.empty()) output.write_text((const char *)o.text.data(), o.text.size());
+                    continue;
+                }
                 if (m == 0) continue;
                 auto label_of = [&](size_t j) { return t.label(b.str(o.slot_of[j] / k), o.slot_of[j] % k); };
                 if (matcher) {
@@ -462,11 +502,16 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
         for (const Transform &t : transforms) max_slots = std::max(max_slots, t.takes_strings() ? t.string_slots() : t.slots());
         // Compact console output of numeric transforms: the lines come back from the device as text (vk_generate_lines: decimal
         // label, hex, Base58Check and line assembly in HIP), 2^21 keys per call; anything else takes the record path below.
-        bool text_path = !full && !want_pub && output.accepts_text() && max_slots <= (1u << 16);
+        // A sink that stores the full record (StorageOutput) takes the record's value columns the same way (vk_generate_columns, 2^20
+        // keys per call); a MultiOutput of such sinks gets both.
+        const unsigned fmt = getenv("VUKE_HIP_RECORD_PATH") ? 0u : output.device_formats(); // (the variable: A/B knob of tools/probe_*)
+        bool text_path = fmt != 0 && max_slots <= (1u << 16);
         for (const Transform &t : transforms) text_path = text_path && !t.takes_strings() && strlen(t.name()) < 32;
-        const uint64_t chunk = text_path ? std::max<uint64_t>(1, (1ull << 21) / max_slots)
+        const bool want_text = (fmt & Output::DEVICE_TEXT) != 0, want_cols = (fmt & Output::DEVICE_COLUMNS) != 0;
+        const uint64_t chunk = text_path ? std::max<uint64_t>(1, (want_cols ? 1ull << 20 : 1ull << 21) / max_slots)
                                          : std::max<uint64_t>(1, std::min<uint64_t>(1ull << 16, (1ull << 18) / max_slots));
         std::vector<uint8_t> text;
+        std::vector<uint8_t> colbuf[VK_RC_COLUMNS];
         for (uint64_t lo = start;; lo += chunk) {
             const uint64_t hi = (end - lo < chunk - 1) ? end : lo + chunk - 1;
             for (const Transform &t : transforms) {
@@ -480,12 +525,25 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
                         sp[s] = suffix[s].c_str();
                     }
                     const size_t n = (size_t)(hi - lo + 1) * k;
-                    if (text.size() < n * 192) text.resize(n * 192);
-                    size_t len = 0;
                     vk_sweep_stats ss;
-                    check_rc(engine_, vk_generate_lines(engine_, &t.spec(), lo, hi, t.name(), sp.data(), text.data(), text.size(), &len, &ss));
+                    if (want_text) {
+                        if (text.size() < n * 192) text.resize(n * 192);
+                        size_t len = 0;
+                        check_rc(engine_, vk_generate_lines(engine_, &t.spec(), lo, hi, t.name(), sp.data(), text.data(), text.size(), &len, &ss));
+                        output.write_text((const char *)text.data(), len);
+                    }
+                    if (want_cols) {
+                        vk_record_columns rc;
+                        for (int c = 0; c < VK_RC_COLUMNS; c++) {
+                            const size_t need = n * vk_record_column_stride(c);
+                            if (colbuf[c].size() < need) colbuf[c].resize(need);
+                            rc.data[c] = colbuf[c].data();
+                            rc.cap[c] = colbuf[c].size();
+                        }
+                        check_rc(engine_, vk_generate_columns(engine_, &t.spec(), lo, hi, sp.data(), &rc, &ss));
+                        output.write_columns(rc, t.name());
+                    }
                     st.keys_generated += ss.keys;
-                    output.write_text((const char *)text.data(), len);
                     continue;
                 }
                 if (t.takes_strings()) {

@@ -171,6 +171,12 @@ public:
     // compact lines made on the device, vk_generate_lines).  false = this sink wants records: the caller then goes through key().
     virtual bool write_text(const char *, size_t) { return false; }
     virtual bool accepts_text() const { return false; }
+    // The same for sinks that store the full record: a run of records as the value columns the device made (vk_generate_columns /
+    // vk_derive_columns; source_col != nullptr replaces the source column with the caller's labels, same encoding).
+    virtual bool write_columns(const vk_record_columns &, const std::string & /*transform*/, const uint8_t * /*source_col*/ = nullptr, size_t = 0) { return false; }
+    // which of the two ready-made forms this sink takes INSTEAD of key() calls (0: it wants records)
+    enum : unsigned { DEVICE_TEXT = 1, DEVICE_COLUMNS = 2 };
+    virtual unsigned device_formats() const { return accepts_text() ? DEVICE_TEXT : 0u; }
 };
 
 // MultiOutput (src/output/multi.rs): the same record to every sink, in order
@@ -201,6 +207,29 @@ public:
             if (o->needs_pubkeys()) return true;
         return false;
     }
+    // every sink must be servable without records; each then gets the form it takes
+    unsigned device_formats() const override
+    {
+        unsigned all = 0;
+        for (Output *o : sinks_) {
+            const unsigned f = o->device_formats();
+            if (!f) return 0;
+            all |= f;
+        }
+        return all;
+    }
+    bool write_text(const char *text, size_t len) override
+    {
+        for (Output *o : sinks_)
+            if (o->device_formats() & DEVICE_TEXT) o->write_text(text, len);
+        return true;
+    }
+    bool write_columns(const vk_record_columns &cols, const std::string &transform, const uint8_t *source_col = nullptr, size_t source_len = 0) override
+    {
+        for (Output *o : sinks_)
+            if (o->device_formats() & DEVICE_COLUMNS) o->write_columns(cols, transform, source_col, source_len);
+        return true;
+    }
 
 private:
     std::vector<Output *> sinks_;
@@ -220,6 +249,8 @@ public:
     void hit(const std::string &source, const std::string &transform, const DerivedKey &d, const MatchInfo &m) override;
     void flush() override;
     bool needs_pubkeys() const override { return true; }
+    unsigned device_formats() const override { return DEVICE_COLUMNS; }
+    bool write_columns(const vk_record_columns &cols, const std::string &transform, const uint8_t *source_col = nullptr, size_t source_len = 0) override;
     std::vector<std::string> finish(); // closes the open chunk; paths of every file written
     uint64_t records() const;
 
