@@ -39,7 +39,8 @@ extern "C" {
 
 #define VK_ABI_VERSION 4 /* 2: vk_sweep_stats.shader_clock_ghz, vk_scan_strings; 3: vk_generate_lines, vk_last_warning,
                            vk_sweep_stats.inputs_skipped (was padding), string limits 448 bytes, vk_engine_opts.algo must be 0;
-                           4: vk_generate_lines_strings, vk_generate_columns + vk_record_columns */
+                           4: vk_generate_lines_strings, vk_generate_verbose,
+                           vk_generate_columns / vk_derive_columns + vk_record_columns */
 
 /* error codes */
 #define VK_OK 0
@@ -193,6 +194,13 @@ int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint
  * transform_name are at most 31 bytes.  At most 2^21 (input, slot) pairs per call; text_cap >= 192 bytes per pair. */
 int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_t seed_hi_inclusive, const char *transform_name,
                       const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out);
+/* The same inputs in ConsoleOutput's verbose format (src/output/console.rs:62-76): per key the block
+ *     ---\nsource: ..\ntransform: ..\nprivate_key: ..\nwif_compressed: ..\nwif_uncompressed: ..\n
+ *     p2pkh_compressed: ..\np2pkh_uncompressed: ..\np2wpkh: ..\n
+ * (mainnet encodings).  text_cap >= 512 bytes per (input, slot) pair; otherwise as vk_generate_lines. */
+int vk_generate_verbose(vk_engine *e, const vk_transform_spec *t, uint64_t seed_lo, uint64_t seed_hi_inclusive, const char *transform_name,
+                        const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out);
+
 /* The same for WordlistSource / StdinSource in generate mode (src/source/wordlist.rs:24-77, src/output/console.rs:77-81): one
  * line per (input string, slot) the reference emits,
  *     {input string}{slot_suffix[slot]},{transform_name},{private key hex},{P2PKH address of the compressed key}\n

@@ -883,6 +883,36 @@ def test_generate_lines_for_string_inputs_equal_the_oracles_text(eng, vko):
             eng.generate_lines_strings(ffi.spec(kind), [b"00112233445566778899aabbccddeeff"], "x", None)
 
 
+def test_verbose_blocks_on_the_device_equal_the_oracles_text(eng, vko):
+    """vk_generate_verbose: ConsoleOutput's verbose block (src/output/console.rs:62-76) for every key of a range, made on the device
+    (both WIFs, both P2PKH addresses, P2WPKH), against the oracle's records; blocks missing where the reference emits nothing."""
+    from vuke_amd import _ffi as ffi
+    LCG = ("glibc", "minstd", "msvc", "borland")
+    cases = [(ffi.spec(ffi.T_SHA256), vko.spec(vko.T_SHA256), "sha256", [""] * 3, [(0, 300), (2**64 - 20, 2**64 - 1)]),
+             (ffi.spec(ffi.T_LCG), vko.spec(vko.T_LCG), "lcg", [":" + n for n in LCG], [(2**31 - 50, 2**31 + 50)]),
+             (ffi.spec(ffi.T_MILKSAD), vko.spec(vko.T_MILKSAD), "milksad", [""], [(2**32 - 30, 2**32 + 30)])]
+    for gs, osp, name, suffix, ranges in cases:
+        slots = vko.slots_per_input(osp)
+        for lo, hi in ranges:
+            text, st = eng.generate_lines(gs, lo, hi, name, suffix, verbose=True)
+            want = []
+            for seed in range(lo, hi + 1):
+                for sub in range(slots):
+                    k = vko.transform_key(osp, seed, sub)
+                    if k is None:
+                        continue
+                    d = vko.derive(k)
+                    want.append(f"---\nsource: {seed}{suffix[sub]}\ntransform: {name}\nprivate_key: {d.private_key_hex.decode()}\n"
+                                f"wif_compressed: {d.wif_compressed.decode()}\nwif_uncompressed: {d.wif_uncompressed.decode()}\n"
+                                f"p2pkh_compressed: {d.p2pkh_compressed.decode()}\np2pkh_uncompressed: {d.p2pkh_uncompressed.decode()}\n"
+                                f"p2wpkh: {d.p2wpkh.decode()}\n")
+            assert text.decode() == "".join(want), (name, lo)
+            assert st["keys"] == len(want)
+    # the longest block: 20-digit input, 31-character suffix and name
+    text, _ = eng.generate_lines(ffi.spec(ffi.T_MD5), 2**64 - 1, 2**64 - 1, "n" * 31, ["s" * 31], verbose=True)
+    assert text.startswith(b"---\nsource: 18446744073709551615" + b"s" * 31 + b"\ntransform: " + b"n" * 31 + b"\n") and len(text) <= 483
+
+
 def _plain_strings(values):
     import struct
     return b"".join(struct.pack("<I", len(v)) + v for v in values)

@@ -71,7 +71,7 @@ SEARCH_EXACT, SEARCH_MASKED, SEARCH_CASCADE = 0, 1, 2
 
 EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
-    "vk_last_error", "vk_last_warning", "vk_targets_set", "vk_sweep", "vk_generate", "vk_generate_lines", "vk_generate_lines_strings", "vk_generate_columns", "vk_derive_columns", "vk_record_column_stride", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
+    "vk_last_error", "vk_last_warning", "vk_targets_set", "vk_sweep", "vk_generate", "vk_generate_lines", "vk_generate_verbose", "vk_generate_lines_strings", "vk_generate_columns", "vk_derive_columns", "vk_record_column_stride", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
     "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_scan_strings", "vk_rescan_strings", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
     "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop",
 ]
@@ -103,6 +103,7 @@ def load():
     L.vk_sweep.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, C.POINTER(Hit), sz, C.POINTER(SweepStats)]
     L.vk_generate.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, vp, vp, vp, vp, C.POINTER(SweepStats)]
     L.vk_generate_lines.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, cp, C.POINTER(C.c_char_p), vp, sz, C.POINTER(sz), C.POINTER(SweepStats)]
+    L.vk_generate_verbose.argtypes = L.vk_generate_lines.argtypes
     L.vk_generate_lines_strings.argtypes = [vp, C.POINTER(TransformSpec), cp, C.POINTER(u32), sz, cp, C.POINTER(C.c_char_p), vp, sz, C.POINTER(sz), C.POINTER(SweepStats)]
     L.vk_derive_columns.argtypes = [vp, cp, sz, C.POINTER(RecordColumns)]
     L.vk_record_column_stride.restype = sz
@@ -193,17 +194,18 @@ class Engine:
         return dict(slots=slots, n=n, privkeys=priv.raw, h160_c=hc.raw, h160_u=hu.raw, valid=valid.raw,
                     keys=st.keys, inputs=st.inputs, digest=tuple(st.digest), kernel_seconds=st.kernel_seconds)
 
-    def generate_lines(self, spec, lo, hi, name, suffixes=None):
-        """Compact CSV text of generate mode for [lo, hi] (vk_generate_lines): (bytes, stats)."""
+    def generate_lines(self, spec, lo, hi, name, suffixes=None, verbose=False):
+        """Compact CSV text (vk_generate_lines) or verbose blocks (vk_generate_verbose) of generate mode for [lo, hi]: (bytes, stats)."""
         slots = self._L.vk_slots_per_input(C.byref(spec))
         n = (hi - lo + 1) * slots
-        buf = C.create_string_buffer(max(1, n * 192))
+        buf = C.create_string_buffer(max(1, n * (512 if verbose else 192)))
         ln = C.c_size_t(0)
         st = SweepStats()
         arr = None
         if suffixes is not None:
             arr = (C.c_char_p * slots)(*[s if isinstance(s, bytes) else s.encode() for s in suffixes])
-        self._chk(self._L.vk_generate_lines(self._e, C.byref(spec), lo, hi, name if isinstance(name, bytes) else name.encode(), arr, buf, len(buf), C.byref(ln), C.byref(st)))
+        fn = self._L.vk_generate_verbose if verbose else self._L.vk_generate_lines
+        self._chk(fn(self._e, C.byref(spec), lo, hi, name if isinstance(name, bytes) else name.encode(), arr, buf, len(buf), C.byref(ln), C.byref(st)))
         return buf.raw[:ln.value], dict(keys=st.keys, inputs=st.inputs, kernel_seconds=st.kernel_seconds)
 
     def _column_buffers(self, items):

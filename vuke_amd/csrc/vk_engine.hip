@@ -736,12 +736,14 @@ extern "C" int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t lo
     return VK_OK;
 }
 
-// RangeSource::process in generate mode with ConsoleOutput's compact format, text made on the device (vk_lines.cuh).
-extern "C" int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const char *transform_name,
-                                 const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out)
+// RangeSource::process in generate mode with ConsoleOutput's compact or verbose format, text made on the device (vk_lines.cuh,
+// vk_verbose_kernel in vk_records.cuh).
+static int generate_text(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const char *transform_name, const char *const *slot_suffix,
+                         uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out, bool verbose)
 {
     if (!e) return VK_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
+    const u32 stride = verbose ? VK_VERBOSE_STRIDE : VK_LINE_STRIDE;
     int rc = validate_spec(e, t);
     if (rc) return rc;
     if (hi < lo) return fail(e, VK_E_INVALID_ARG, "seed_hi < seed_lo");
@@ -750,7 +752,9 @@ extern "C" int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint6
     if (slots == 0) return fail(e, VK_E_UNSUPPORTED, "the transform emits nothing for numeric inputs");
     if (hi - lo >= VK_LINES_MAX_ITEMS / slots) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines: at most 2^21 (input, slot) pairs per call");
     const u64 items = (hi - lo + 1) * slots;
-    if (text_cap < items * VK_LINE_STRIDE) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines: text_cap must be at least 192 bytes per (input, slot) pair");
+    if (text_cap < items * stride)
+        return fail(e, VK_E_INVALID_ARG, verbose ? "vk_generate_verbose: text_cap must be at least 512 bytes per (input, slot) pair"
+                                                 : "vk_generate_lines: text_cap must be at least 192 bytes per (input, slot) pair");
     // label suffix of every slot and the transform name: one length byte + up to 31 characters each
     std::vector<unsigned char> texts((size_t)(slots + 1) * VK_LINE_SUFFIX_BYTES, 0);
     for (u32 i = 0; i <= slots; i++) {
@@ -764,15 +768,16 @@ extern "C" int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint6
     SCRATCH(e, d_texts, unsigned char *, 0, texts.size());
     SCRATCH(e, d_priv, u32 *, 1, items * 32);
     SCRATCH(e, d_hc, u32 *, 2, items * 20);
+    SCRATCH(e, d_hu, u32 *, 3, verbose ? items * 20 : 4);
     SCRATCH(e, d_valid, unsigned char *, 4, items);
-    SCRATCH(e, d_slots, u64 *, 6, items * VK_LINE_STRIDE);
+    SCRATCH(e, d_slots, u64 *, 6, items * stride);
     size_t temp_bytes = 0;
     u32 *null32 = nullptr;
     HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, null32, null32, (int)items, e->stream));
     const size_t off_lens = 0, off_offs = (items + 1) * 4, off_temp = ((off_offs + (items + 1) * 4 + 255) / 256) * 256;
     SCRATCH(e, d_scan, unsigned char *, 7, off_temp + temp_bytes);
     u32 *d_lens = (u32 *)(d_scan + off_lens), *d_offs32 = (u32 *)(d_scan + off_offs);
-    SCRATCH(e, d_text, unsigned char *, 8, items * VK_LINE_STRIDE);
+    SCRATCH(e, d_text, unsigned char *, 8, items * stride);
     HIPCHK(e, hipMemcpy(d_texts, texts.data(), texts.size(), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemsetAsync(d_valid, 0, items, e->stream));
     vk_sweep_stats local;
@@ -781,15 +786,19 @@ extern "C" int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint6
     io.out_priv = d_priv;
     io.out_h160c = d_hc;
     io.out_valid = d_valid;
-    rc = run_range(e, to_dev(t), t->kind, slots, lo, hi - lo, VK_F_COMPRESSED | VK_F_EMIT, io, &local);
+    if (verbose) io.out_h160u = d_hu;
+    rc = run_range(e, to_dev(t), t->kind, slots, lo, hi - lo, VK_F_COMPRESSED | (verbose ? VK_F_UNCOMPRESSED : 0u) | VK_F_EMIT, io, &local);
     if (rc) return rc;
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
     const u32 grid = (u32)((items + 255) / 256);
-    hipLaunchKernelGGL(vk_lines_kernel, dim3(grid), dim3(256), 0, e->stream, (u64)lo, items, slots, d_priv, d_hc, d_valid, d_texts, (const u32 *)nullptr, d_slots,
-                       d_lens);
+    if (verbose)
+        hipLaunchKernelGGL(vk_verbose_kernel, dim3(grid), dim3(256), 0, e->stream, (u64)lo, items, slots, d_priv, d_hc, d_hu, d_valid, d_texts, d_slots, d_lens);
+    else
+        hipLaunchKernelGGL(vk_lines_kernel, dim3(grid), dim3(256), 0, e->stream, (u64)lo, items, slots, d_priv, d_hc, d_valid, d_texts, (const u32 *)nullptr,
+                           d_slots, d_lens);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(d_scan + off_temp, temp_bytes, d_lens, d_offs32, (int)items, e->stream));
-    hipLaunchKernelGGL(vk_lines_compact_kernel, dim3((u32)((items + 63) / 64 * 64 + 255) / 256), dim3(256), 0, e->stream, items, slots, VK_LINE_STRIDE, d_slots, d_lens, d_offs32,
+    hipLaunchKernelGGL(vk_lines_compact_kernel, dim3((u32)((items + 63) / 64 * 64 + 255) / 256), dim3(256), 0, e->stream, items, slots, stride, d_slots, d_lens, d_offs32,
                        (const unsigned char *)nullptr, (const u32 *)nullptr, d_text);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
@@ -807,6 +816,18 @@ extern "C" int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint6
     local.launches += 2;
     if (out) *out = local;
     return VK_OK;
+}
+
+extern "C" int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const char *transform_name,
+                                 const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out)
+{
+    return generate_text(e, t, lo, hi, transform_name, slot_suffix, text, text_cap, text_len, out, false);
+}
+
+extern "C" int vk_generate_verbose(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const char *transform_name,
+                                   const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out)
+{
+    return generate_text(e, t, lo, hi, transform_name, slot_suffix, text, text_cap, text_len, out, true);
 }
 
 extern "C" size_t vk_record_column_stride(int column) { return column >= 0 && column < VK_RC_COLUMNS ? vk_rc_stride(column) : 0; }

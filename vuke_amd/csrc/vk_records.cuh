@@ -127,7 +127,7 @@ VK_DEV u32 rec_put_p2pkh(u64 *slot, const u32 h[5])
 // [len][WIF]: Base58Check(0x80 || key [|| 0x01]); kb = the key as 8 big-endian words.  52 / 51 characters always (the
 // leading byte 0x80 fixes the magnitude: 'K' / 'L' and '5' first characters).
 template <bool COMPRESSED>
-VK_DEV u32 rec_put_wif(u64 *slot, const u32 kb[8])
+VK_DEV void rec_emit_wif(vk_stage_writer &wr, const u32 kb[8])
 {
     u32 w[16], d1[8], d2[8];
     w[0] = 0x80000000u | (kb[0] >> 8);
@@ -154,17 +154,22 @@ VK_DEV u32 rec_put_wif(u64 *slot, const u32 kb[8])
     u32 dig[55];
     base58_digits<10, 11>(L, dig);
     constexpr int N = COMPRESSED ? 52 : 51;
-    vk_stage_writer wr;
-    wr.init(slot);
-    wr.put(N, 4);
 #pragma unroll
     for (int pos = N - 1; pos >= 0; pos--) wr.put(base58_char(dig[pos]), 1);
+}
+template <bool COMPRESSED>
+VK_DEV u32 rec_put_wif(u64 *slot, const u32 kb[8])
+{
+    vk_stage_writer wr;
+    wr.init(slot);
+    wr.put(COMPRESSED ? 52 : 51, 4);
+    rec_emit_wif<COMPRESSED>(wr, kb);
     return rec_finish(wr);
 }
 
 // [42]["bc1" + bech32 data of (witness version 0, hash160) + checksum]  (BIP-173; src/derive.rs:116-118)
 static __device__ const char VK_BECH32_CHARSET[33] = "qpzry9x8gf2tvdw0s3jn54khce6mua7l";
-VK_DEV u32 rec_put_p2wpkh(u64 *slot, const u32 h[5])
+VK_DEV void rec_emit_p2wpkh(vk_stage_writer &wr, const u32 h[5])
 {
     u32 hb[6];
 #pragma unroll
@@ -198,12 +203,16 @@ VK_DEV u32 rec_put_p2wpkh(u64 *slot, const u32 h[5])
     chk ^= 1u;
 #pragma unroll
     for (int i = 0; i < 6; i++) data[33 + i] = (chk >> (5 * (5 - i))) & 31u;
-    vk_stage_writer wr;
-    wr.init(slot);
-    wr.put(42, 4);
     wr.put('b' | ('c' << 8) | ('1' << 16), 3);
 #pragma unroll
     for (int i = 0; i < 39; i++) wr.put((u32)(unsigned char)VK_BECH32_CHARSET[data[i]], 1);
+}
+VK_DEV u32 rec_put_p2wpkh(u64 *slot, const u32 h[5])
+{
+    vk_stage_writer wr;
+    wr.init(slot);
+    wr.put(42, 4);
+    rec_emit_p2wpkh(wr, h);
     return rec_finish(wr);
 }
 
@@ -384,4 +393,67 @@ __global__ void __launch_bounds__(256) vk_records_addr_kernel(u64 items, const u
     out.lens[VK_RC_P2PKH_C][item] = rec_put_p2pkh(out.slot[VK_RC_P2PKH_C] + item * (vk_rc_stride(VK_RC_P2PKH_C) / 8), hc);
     out.lens[VK_RC_P2PKH_U][item] = rec_put_p2pkh(out.slot[VK_RC_P2PKH_U] + item * (vk_rc_stride(VK_RC_P2PKH_U) / 8), hu);
     out.lens[VK_RC_P2WPKH][item] = rec_put_p2wpkh(out.slot[VK_RC_P2WPKH] + item * (vk_rc_stride(VK_RC_P2WPKH) / 8), hc);
+}
+
+// ConsoleOutput's verbose block (src/output/console.rs:62-76), one lane per (input, slot) into a 512-byte slot:
+//   ---\nsource: ..\ntransform: ..\nprivate_key: ..\nwif_compressed: ..\nwif_uncompressed: ..\np2pkh_compressed: ..\n
+//   p2pkh_uncompressed: ..\np2wpkh: ..\n                                  (483 bytes at most)
+#define VK_VERBOSE_STRIDE 512u
+VK_DEV void put_literal(vk_stage_writer &wr, const char *s, u32 n) // n = strlen(s), a compile-time string
+{
+    for (u32 i = 0; i < n; i += 8) {
+        u64 v = 0;
+        const u32 m = n - i < 8 ? n - i : 8;
+        for (u32 j = 0; j < m; j++) v |= (u64)(unsigned char)s[i + j] << (8 * j);
+        wr.put(v, m);
+    }
+}
+#define PUT_LIT(wr, s) put_literal(wr, s, sizeof(s) - 1)
+
+__global__ void __launch_bounds__(256) vk_verbose_kernel(u64 lo, u64 items, u32 slots, const u32 *__restrict__ priv, const u32 *__restrict__ h160c,
+                                                        const u32 *__restrict__ h160u, const unsigned char *__restrict__ valid,
+                                                        const unsigned char *__restrict__ texts /* slots suffix entries, then the transform name */,
+                                                        u64 *__restrict__ block_slots, u32 *__restrict__ lens)
+{
+    const u64 item = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (item >= items) return;
+    if (!valid[item]) {
+        lens[item] = 0;
+        return;
+    }
+    const u64 input = item / slots;
+    const u32 sub = (u32)(item - input * slots);
+    u32 raw[8], kb[8], hc[5], hu[5];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        raw[i] = priv[item * 8 + i];
+        kb[i] = __builtin_bswap32(raw[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        hc[i] = h160c[item * 5 + i];
+        hu[i] = h160u[item * 5 + i];
+    }
+    vk_stage_writer wr;
+    wr.init(block_slots + item * (VK_VERBOSE_STRIDE / 8));
+    PUT_LIT(wr, "---\nsource: ");
+    lines_put_decimal(wr, lo + input);
+    lines_put_text(wr, texts + (u64)sub * VK_LINE_SUFFIX_BYTES);
+    PUT_LIT(wr, "\ntransform: ");
+    lines_put_text(wr, texts + (u64)slots * VK_LINE_SUFFIX_BYTES);
+    PUT_LIT(wr, "\nprivate_key: ");
+#pragma unroll
+    for (int i = 0; i < 8; i++) wr.put(lines_hex8(raw[i]), 8);
+    PUT_LIT(wr, "\nwif_compressed: ");
+    rec_emit_wif<true>(wr, kb);
+    PUT_LIT(wr, "\nwif_uncompressed: ");
+    rec_emit_wif<false>(wr, kb);
+    PUT_LIT(wr, "\np2pkh_compressed: ");
+    lines_put_p2pkh(wr, hc);
+    PUT_LIT(wr, "\np2pkh_uncompressed: ");
+    lines_put_p2pkh(wr, hu);
+    PUT_LIT(wr, "\np2wpkh: ");
+    rec_emit_p2wpkh(wr, hc);
+    wr.put('\n', 1);
+    lens[item] = rec_finish(wr);
 }

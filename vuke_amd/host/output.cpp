@@ -51,6 +51,14 @@ bool ConsoleOutput::write_text(const char *text, size_t len)
     return true;
 }
 
+bool ConsoleOutput::write_verbose(const char *text, size_t len)
+{
+    if (!verbose_) return false;
+    std::lock_guard<std::mutex> lk(mu_);
+    fwrite(text, 1, len, fp_);
+    return true;
+}
+
 void ConsoleOutput::flush()
 {
     std::lock_guard<std::mutex> lk(mu_);

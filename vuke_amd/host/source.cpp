@@ -507,8 +507,8 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
         const unsigned fmt = getenv("VUKE_HIP_RECORD_PATH") ? 0u : output.device_formats(); // (the variable: A/B knob of tools/probe_*)
         bool text_path = fmt != 0 && max_slots <= (1u << 16);
         for (const Transform &t : transforms) text_path = text_path && !t.takes_strings() && strlen(t.name()) < 32;
-        const bool want_text = (fmt & Output::DEVICE_TEXT) != 0, want_cols = (fmt & Output::DEVICE_COLUMNS) != 0;
-        const uint64_t chunk = text_path ? std::max<uint64_t>(1, (want_cols ? 1ull << 20 : 1ull << 21) / max_slots)
+        const bool want_text = (fmt & Output::DEVICE_TEXT) != 0, want_cols = (fmt & Output::DEVICE_COLUMNS) != 0, want_verbose = (fmt & Output::DEVICE_VERBOSE) != 0;
+        const uint64_t chunk = text_path ? std::max<uint64_t>(1, (want_cols || want_verbose ? 1ull << 20 : 1ull << 21) / max_slots)
                                          : std::max<uint64_t>(1, std::min<uint64_t>(1ull << 16, (1ull << 18) / max_slots));
         std::vector<uint8_t> text;
         std::vector<uint8_t> colbuf[VK_RC_COLUMNS];
@@ -531,6 +531,12 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
                         size_t len = 0;
                         check_rc(engine_, vk_generate_lines(engine_, &t.spec(), lo, hi, t.name(), sp.data(), text.data(), text.size(), &len, &ss));
                         output.write_text((const char *)text.data(), len);
+                    }
+                    if (want_verbose) {
+                        if (text.size() < n * 512) text.resize(n * 512);
+                        size_t len = 0;
+                        check_rc(engine_, vk_generate_verbose(engine_, &t.spec(), lo, hi, t.name(), sp.data(), text.data(), text.size(), &len, &ss));
+                        output.write_verbose((const char *)text.data(), len);
                     }
                     if (want_cols) {
                         vk_record_columns rc;

@@ -175,7 +175,8 @@ public:
     // vk_derive_columns; source_col != nullptr replaces the source column with the caller's labels, same encoding).
     virtual bool write_columns(const vk_record_columns &, const std::string & /*transform*/, const uint8_t * /*source_col*/ = nullptr, size_t = 0) { return false; }
     // which of the two ready-made forms this sink takes INSTEAD of key() calls (0: it wants records)
-    enum : unsigned { DEVICE_TEXT = 1, DEVICE_COLUMNS = 2 };
+    enum : unsigned { DEVICE_TEXT = 1, DEVICE_COLUMNS = 2, DEVICE_VERBOSE = 4 };
+    virtual bool write_verbose(const char *, size_t) { return false; } // the same with ConsoleOutput's verbose blocks (vk_generate_verbose)
     virtual unsigned device_formats() const { return accepts_text() ? DEVICE_TEXT : 0u; }
 };
 
@@ -224,6 +225,12 @@ public:
             if (o->device_formats() & DEVICE_TEXT) o->write_text(text, len);
         return true;
     }
+    bool write_verbose(const char *text, size_t len) override
+    {
+        for (Output *o : sinks_)
+            if (o->device_formats() & DEVICE_VERBOSE) o->write_verbose(text, len);
+        return true;
+    }
     bool write_columns(const vk_record_columns &cols, const std::string &transform, const uint8_t *source_col = nullptr, size_t source_len = 0) override
     {
         for (Output *o : sinks_)
@@ -270,7 +277,9 @@ public:
     void flush() override;
     bool needs_full_record() const override { return verbose_; }
     bool accepts_text() const override { return !verbose_; } // the compact format is one line per key
+    unsigned device_formats() const override { return verbose_ ? DEVICE_VERBOSE : DEVICE_TEXT; }
     bool write_text(const char *text, size_t len) override;
+    bool write_verbose(const char *text, size_t len) override;
 
 private:
     ConsoleOutput(FILE *fp, bool own, bool verbose) : fp_(fp), own_(own), verbose_(verbose) {}
