@@ -209,9 +209,15 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
             const uint32_t k = t.string_slots();
             if (k == 0) continue; // a transform that needs Input::u64_val pushes nothing for a passphrase
             // generate mode into a sink that takes text, from a transform whose label is the input plus a per-slot suffix
+            // or into one that stores the full record (columns from vk_derive_columns, written slice by slice: one engine only)
+            const size_t g = n < 4096 ? 1 : std::min(engines_.size(), n);
+            const unsigned fmt = (matcher || getenv("VUKE_HIP_RECORD_PATH")) ? 0u : output.device_formats(); // (the variable: A/B knob of tools/probe_*)
             auto text_ok = [&](const Transform &tr) {
-                return !matcher && !full && !want_pub && output.accepts_text() && !getenv("VUKE_HIP_RECORD_PATH") && tr.spec().kind != VK_T_ELECTRUM && tr.spec().kind != VK_T_MULTIBIT &&
-                       strlen(tr.name()) < 32 && tr.string_slots() <= (1u << 16);
+                if (fmt == 0 || (fmt & Output::DEVICE_VERBOSE)) return false;
+                if ((fmt & Output::DEVICE_COLUMNS) && g != 1) return false;
+                if (fmt & Output::DEVICE_TEXT)
+                    return tr.spec().kind != VK_T_ELECTRUM && tr.spec().kind != VK_T_MULTIBIT && strlen(tr.name()) < 32 && tr.string_slots() <= (1u << 16);
+                return true;
             };
             auto run_slice = [&](vk_engine *eng, size_t first, size_t cnt, SliceOut &o) {
                 std::vector<uint32_t> offs(cnt + 1);
@@ -250,6 +256,48 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                         sp[s] = suffix[s].c_str();
                     }
                     o.as_text = true;
+                    if (fmt & Output::DEVICE_COLUMNS) {
+                        // the record's columns: keys from vk_transform_strings, every other value column from vk_derive_columns, the
+                        // source column (the labels) made here in the same encoding; 2^20 keys per call
+                        std::vector<uint8_t> keys(cnt * k * 32), valid(cnt * k);
+                        check_rc(eng, vk_transform_strings(eng, &t.spec(), b.data.data() + b.offs[first], offs.data(), cnt, keys.data(), valid.data()));
+                        o.warning = last_warning(eng);
+                        std::vector<uint8_t> colbuf[VK_RC_COLUMNS], flat, src;
+                        std::vector<size_t> slot_of;
+                        size_t s0 = 0;
+                        while (s0 < cnt * k) {
+                            flat.clear();
+                            slot_of.clear();
+                            size_t s1 = s0;
+                            for (; s1 < cnt * k && slot_of.size() < (1u << 20); s1++)
+                                if (valid[s1]) {
+                                    flat.insert(flat.end(), keys.begin() + 32 * s1, keys.begin() + 32 * s1 + 32);
+                                    slot_of.push_back(s1);
+                                }
+                            s0 = s1;
+                            const size_t m = slot_of.size();
+                            if (m == 0) continue;
+                            vk_record_columns rc;
+                            for (int c = 0; c < VK_RC_COLUMNS; c++) {
+                                const size_t need = m * vk_record_column_stride(c);
+                                if (colbuf[c].size() < need) colbuf[c].resize(need);
+                                rc.data[c] = colbuf[c].data();
+                                rc.cap[c] = colbuf[c].size();
+                            }
+                            check_rc(eng, vk_derive_columns(eng, flat.data(), m, &rc));
+                            src.clear();
+                            for (size_t j = 0; j < m; j++) {
+                                const std::string lab = t.label(b.str(first + slot_of[j] / k), (uint32_t)(slot_of[j] % k));
+                                const uint32_t l = (uint32_t)lab.size();
+                                for (int i = 0; i < 4; i++) src.push_back((uint8_t)(l >> (8 * i)));
+                                src.insert(src.end(), lab.begin(), lab.end());
+                            }
+                            output.write_columns(rc, t.name(), src.data(), src.size());
+                            o.nkeys += m;
+                        }
+                        if (!(fmt & Output::DEVICE_TEXT)) return;
+                        o.nkeys = 0; // counted again below
+                    }
                     const size_t per = std::max<size_t>(1, (1u << 21) / k);
                     std::vector<uint32_t> sub;
                     for (size_t a = 0; a < cnt; a += per) {
@@ -289,7 +337,6 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                 }
             };
             // one contiguous slice of the batch per engine (independent inputs, no exchange); small batches stay on one
-            const size_t g = n < 4096 ? 1 : std::min(engines_.size(), n);
             std::vector<SliceOut> outs(g);
             if (g == 1) {
                 run_slice(engines_[0], 0, n, outs[0]);
