@@ -23,12 +23,13 @@ try:
         for i in range(2):
             shutil.rmtree(sdir, ignore_errors=True)
             t = time.perf_counter()
-            r = subprocess.run([exe] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+            r = subprocess.run([exe] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, VUKE_HIP_TIMING="1", **env))
             dt = time.perf_counter() - t
             best = dt if best is None else min(best, dt)
         size = os.path.getsize(out) if os.path.exists(out) else 0
         store = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(sdir) for f in fs) if os.path.isdir(sdir) else 0
-        print(f"{name:36s}: best of 2 {best:6.3f} s   text {size / 1e6:8.1f} MB   parquet {store / 1e6:8.1f} MB   rc {r.returncode}  [{r.stderr.decode().strip().splitlines()[-1][:80]}]", flush=True)
+        print(f"{name:36s}: best of 2 {best:6.3f} s   text {size / 1e6:8.1f} MB   parquet {store / 1e6:8.1f} MB   rc {r.returncode}", flush=True)
+        print("      " + " | ".join(l for l in r.stderr.decode().splitlines() if l.startswith("[timing]")), flush=True)
 finally:
     shutil.rmtree(sdir, ignore_errors=True)
     if os.path.exists(out):

@@ -5,6 +5,8 @@
 // inputs = end - start + 1, keys = keys the transforms emitted, matches = keys that matched.
 #include "vuke_host.hpp"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -559,6 +561,9 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
                                          : std::max<uint64_t>(1, std::min<uint64_t>(1ull << 16, (1ull << 18) / max_slots));
         std::vector<uint8_t> text;
         std::vector<uint8_t> colbuf[VK_RC_COLUMNS];
+        double t_dev = 0, t_sink = 0; // VUKE_HIP_TIMING: seconds in the device calls / in the sinks
+        auto now = []() { return std::chrono::steady_clock::now(); };
+        auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
         for (uint64_t lo = start;; lo += chunk) {
             const uint64_t hi = (end - lo < chunk - 1) ? end : lo + chunk - 1;
             for (const Transform &t : transforms) {
@@ -576,14 +581,22 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
                     if (want_text) {
                         if (text.size() < n * 192) text.resize(n * 192);
                         size_t len = 0;
+                        auto t0 = now();
                         check_rc(engine_, vk_generate_lines(engine_, &t.spec(), lo, hi, t.name(), sp.data(), text.data(), text.size(), &len, &ss));
+                        t_dev += since(t0);
+                        t0 = now();
                         output.write_text((const char *)text.data(), len);
+                        t_sink += since(t0);
                     }
                     if (want_verbose) {
                         if (text.size() < n * 512) text.resize(n * 512);
                         size_t len = 0;
+                        auto t0 = now();
                         check_rc(engine_, vk_generate_verbose(engine_, &t.spec(), lo, hi, t.name(), sp.data(), text.data(), text.size(), &len, &ss));
+                        t_dev += since(t0);
+                        t0 = now();
                         output.write_verbose((const char *)text.data(), len);
+                        t_sink += since(t0);
                     }
                     if (want_cols) {
                         vk_record_columns rc;
@@ -593,8 +606,12 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
                             rc.data[c] = colbuf[c].data();
                             rc.cap[c] = colbuf[c].size();
                         }
+                        auto t0 = now();
                         check_rc(engine_, vk_generate_columns(engine_, &t.spec(), lo, hi, sp.data(), &rc, &ss));
+                        t_dev += since(t0);
+                        t0 = now();
                         output.write_columns(rc, t.name());
+                        t_sink += since(t0);
                     }
                     st.keys_generated += ss.keys;
                     continue;
@@ -633,6 +650,7 @@ ProcessStats HipRangeSource::process(const std::vector<Transform> &transforms, c
             }
             if (hi == end) break;
         }
+        if (text_path && getenv("VUKE_HIP_TIMING")) fprintf(stderr, "[timing] generate: %.3f s in device calls, %.3f s in the sinks\n", t_dev, t_sink);
     }
     return st;
 }
