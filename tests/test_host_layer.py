@@ -256,6 +256,83 @@ def test_timestamp_source_dates(host):
         assert host.vkh_timestamp_range(bad[0].encode(), bad[1].encode(), C.byref(lo), C.byref(hi)) == -1, bad
 
 
+def test_storage_output_takes_ready_made_columns(host, vko, tmp_path):
+    """StorageOutput::write_columns (what the device's vk_generate_columns / vk_derive_columns hand over: the value columns as
+    Parquet PLAIN bytes) without a GPU: columns built from the oracle's records.  Runs of rows and single records in one sink;
+    the files hold the sequence in order, cut into chunk files by record count (exact) and by byte size (within the bounds the
+    row sizes give; equality with the record path's cut points is what tests/test_golden.py checks through the CLI), across the
+    65 536-row row-group size; malformed columns are refused."""
+    import glob
+    import struct
+    pq = pytest.importorskip("pyarrow.parquet")
+    rnd = random.Random(91)
+    n_runs, run_rows, singles = 3, 70000, 300
+    pool = [vko.derive(rnd.getrandbits(rnd.choice([8, 64, 200, 256])).to_bytes(32, "big") or b"\x01") for _ in range(700)]
+    plain = lambda vals: b"".join(struct.pack("<I", len(v)) + v for v in vals)
+
+    def columns(ds, srcs):
+        return [plain(srcs), b"".join(bytes(d.raw) for d in ds), plain([d.private_key_hex for d in ds]), plain([d.private_key_decimal for d in ds]),
+                plain([d.private_key_binary for d in ds]), b"".join(struct.pack("<I", d.bit_length) for d in ds),
+                b"".join(struct.pack("<I", d.hamming_weight) for d in ds), b"".join(struct.pack("<I", d.leading_zeros) for d in ds),
+                plain([d.pubkey_compressed for d in ds]), plain([d.pubkey_uncompressed for d in ds]), plain([d.p2pkh_compressed for d in ds]),
+                plain([d.p2pkh_uncompressed for d in ds]), plain([d.p2wpkh for d in ds]), plain([d.wif_compressed for d in ds]), plain([d.wif_uncompressed for d in ds])]
+
+    seq, runs = [], []                       # the whole sequence of (source, record) in file order; the runs as column sets
+    single_ds = [pool[rnd.randrange(len(pool))] for _ in range(singles)]
+    single_src = [f"single{i}".encode() for i in range(singles)]
+    nxt = 0
+    for b in range(n_runs):
+        ds = [pool[rnd.randrange(len(pool))] for _ in range(run_rows)]
+        srcs = [f"{b}:{i}".encode() for i in range(run_rows)]
+        runs.append(columns(ds, srcs))
+        seq += list(zip(srcs, ds))
+        upto = singles * (b + 1) // n_runs
+        seq += list(zip(single_src[nxt:upto], single_ds[nxt:upto]))
+        nxt = upto
+    keep = [c for r in runs for c in r]
+    data = (C.c_char_p * len(keep))(*keep)
+    lens = (C.c_size_t * len(keep))(*[len(c) for c in keep])
+    rows = (C.c_uint64 * n_runs)(*[run_rows] * n_runs)
+    raw = b"".join(bytes(d.raw) for d in single_ds)
+    hc, hu = b"".join(bytes(d.h160_c) for d in single_ds), b"".join(bytes(d.h160_u) for d in single_ds)
+    xy = b"".join(bytes(d.pub65)[1:] for d in single_ds)
+    host.vkh_storage_write_columns.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_char_p),
+                                               C.POINTER(C.c_size_t), C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_char_p]
+    host.vkh_storage_write.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_size_t, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                       C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_char_p]
+    for label, chunk_records, chunk_bytes in (("count", 100000, 0), ("bytes", 0, 40 << 20)):
+        d1 = tmp_path / ("cols_" + label)
+        nf = host.vkh_storage_write_columns(str(d1).encode(), b"t", chunk_records, chunk_bytes, n_runs, rows, data, lens, singles, raw, hc, hu, xy,
+                                            (C.c_char_p * singles)(*single_src), b"snappy")
+        assert nf > 1
+        files = sorted(glob.glob(str(d1 / "transform=t" / "date=*" / "chunk_*.parquet")))
+        assert len(files) == nf
+        got_rows = [pq.read_metadata(f).num_rows for f in files]
+        assert sum(got_rows) == len(seq)
+        if chunk_records:
+            assert got_rows == [100000, 100000, len(seq) - 200000]
+            assert pq.read_metadata(files[0]).num_row_groups >= 2
+        else:   # every file but the last closes on the first row that takes it to 40 MiB of record data (~890 B per row)
+            assert all(44000 < r < 49000 for r in got_rows[:-1])
+        t = pq.read_table(files[0]).to_pylist() + pq.read_table(files[-1]).to_pylist()
+        want = seq[:got_rows[0]] + seq[len(seq) - got_rows[-1]:]
+        assert len(t) == len(want)
+        for row, (src, d) in list(zip(t, want))[::97] + list(zip(t, want))[-3:]:
+            assert row["source"] == src.decode() and row["private_key_raw"] == bytes(d.raw) and row["private_key_decimal"] == d.private_key_decimal.decode()
+            assert row["wif_uncompressed"] == d.wif_uncompressed.decode() and row["address_p2wpkh"] == d.p2wpkh.decode() and row["matched_target"] is None
+            assert (row["private_key_bit_length"], row["private_key_hamming_weight"], row["private_key_leading_zeros"]) == (d.bit_length, d.hamming_weight, d.leading_zeros)
+            assert row["transform"] == "t" and row["chain"] == "bitcoin" and row["pubkey_uncompressed"] == d.pubkey_uncompressed.decode()
+    # a string column that ends inside a value, and a fixed-width column of the wrong size
+    bad = list(keep[:15])
+    bad[3] = bad[3][:-2]
+    assert host.vkh_storage_write_columns(str(tmp_path / "bad1").encode(), b"t", 0, 0, 1, rows, (C.c_char_p * 15)(*bad), (C.c_size_t * 15)(*[len(c) for c in bad]),
+                                          0, raw, hc, hu, xy, (C.c_char_p * singles)(*single_src), b"none") == -1
+    bad = list(keep[:15])
+    bad[1] = bad[1] + bytes(32)
+    assert host.vkh_storage_write_columns(str(tmp_path / "bad2").encode(), b"t", 0, 0, 1, rows, (C.c_char_p * 15)(*bad), (C.c_size_t * 15)(*[len(c) for c in bad]),
+                                          0, raw, hc, hu, xy, (C.c_char_p * singles)(*single_src), b"none") == -1
+
+
 @pytest.mark.parametrize("compression", ["zstd", "gzip", "none", "snappy", "lz4"])
 def test_storage_output_writes_the_19_column_parquet_record(host, vko, tmp_path, compression):
     """StorageOutput: files readable by pyarrow, schema = src/storage/schema.rs:78-111 field for field,

@@ -186,6 +186,37 @@ int vkh_storage_write(const char *dir, const char *transform, uint64_t chunk_rec
     }
 }
 
+// The same sink fed with ready-made columns (what vk_generate_columns / vk_derive_columns return): `batches` runs of rows, run b
+// holding rows[b] rows whose column c is data[b * VK_RC_COLUMNS + c] (len[...] bytes).  Between the runs, `singles` records are
+// added through key() (records 0.., taken from the key arrays), so that both ways of filling a chunk meet in one file.
+int vkh_storage_write_columns(const char *dir, const char *transform, uint64_t chunk_records, uint64_t chunk_bytes, size_t batches, const uint64_t *rows,
+                              const uint8_t *const *data, const size_t *len, size_t singles, const uint8_t *keys, const uint8_t *hc, const uint8_t *hu,
+                              const uint8_t *xy, const char *const *sources, const char *compression)
+{
+    try {
+        StorageOutput out(dir, transform, chunk_records, compression, 3, chunk_bytes);
+        size_t next_single = 0;
+        for (size_t b = 0; b < batches; b++) {
+            vk_record_columns rc;
+            for (int c = 0; c < VK_RC_COLUMNS; c++) {
+                rc.data[c] = const_cast<uint8_t *>(data[b * VK_RC_COLUMNS + c]);
+                rc.cap[c] = rc.len[c] = len[b * VK_RC_COLUMNS + c];
+            }
+            rc.rows = rows[b];
+            out.write_columns(rc, transform);
+            const size_t upto = singles * (b + 1) / batches;
+            for (; next_single < upto; next_single++) {
+                DerivedKey d = KeyDeriver::from_device(keys + 32 * next_single, hc + 20 * next_single, hu + 20 * next_single);
+                KeyDeriver::set_pubkeys(d, xy + 64 * next_single);
+                out.key(sources[next_single], transform, d);
+            }
+        }
+        return (int)out.finish().size();
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
+
 int vkh_parse_key(const char *s, uint8_t out[32])
 {
     try {
