@@ -214,7 +214,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
             // or into one that stores the full record (columns from vk_derive_columns, written slice by slice: one engine only)
             const size_t g = n < 4096 ? 1 : std::min(engines_.size(), n);
             const unsigned fmt = (matcher || getenv("VUKE_HIP_RECORD_PATH")) ? 0u : output.device_formats(); // (the variable: A/B knob of tools/probe_*)
-            auto text_ok = [&](const Transform &tr) {
+            auto device_ok = [&](const Transform &tr) {
                 if (fmt == 0 || (fmt & Output::DEVICE_VERBOSE)) return false;
                 if ((fmt & Output::DEVICE_COLUMNS) && g != 1) return false;
                 if (fmt & Output::DEVICE_TEXT)
@@ -248,7 +248,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                     if (!hk.empty()) o.hit_derived = KeyDeriver(eng).derive(hk);
                     return;
                 }
-                if (text_ok(t)) {
+                if (device_ok(t)) {
                     // compact console output: the lines come back as text (vk_generate_lines_strings: the label is the input
                     // string plus the slot's suffix), 2^21 (input, slot) pairs per call
                     std::vector<std::string> suffix(k);

@@ -248,7 +248,7 @@ private:
 // max_chunk_bytes of record data, whichever comes first (0 = no such limit; defaults 1 000 000 and 100 MiB as the reference).
 class StorageOutput : public Output {
 public:
-    // compression: "zstd" (the reference's default, level 3), "gzip", "none"; snappy / lz4 are not available in this build
+    // compression: "zstd" (the reference's default, level 3), "gzip", "snappy", "lz4", "none"
     StorageOutput(const std::string &base_dir, const std::string &transform_name, uint64_t max_chunk_records = 1000000,
                   const std::string &compression = "zstd", int level = 3, uint64_t max_chunk_bytes = 100ull << 20);
     ~StorageOutput() override;
