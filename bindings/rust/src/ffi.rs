@@ -230,7 +230,7 @@ extern "C" {
                                slot_suffix: *const *const c_char, text: *mut u8, text_cap: usize, text_len: *mut usize,
                                out: *mut VkSweepStats) -> c_int;
     pub fn vk_generate_lines_strings(e: *mut VkEngine, t: *const VkTransformSpec, data: *const u8, offsets: *const u32, n: usize,
-                                     transform_name: *const c_char, slot_suffix: *const *const c_char, text: *mut u8, text_cap: usize,
+                                     label_data: *const u8, label_offsets: *const u32, transform_name: *const c_char, slot_suffix: *const *const c_char, text: *mut u8, text_cap: usize,
                                      text_len: *mut usize, out: *mut VkSweepStats) -> c_int;
     pub fn vk_record_column_stride(column: c_int) -> usize;
     pub fn vk_generate_columns(e: *mut VkEngine, t: *const VkTransformSpec, seed_lo: u64, seed_hi_inclusive: u64,

@@ -203,14 +203,15 @@ int vk_generate_verbose(vk_engine *e, const vk_transform_spec *t, uint64_t seed_
 
 /* The same for WordlistSource / StdinSource in generate mode (src/source/wordlist.rs:24-77, src/output/console.rs:77-81): one
  * line per (input string, slot) the reference emits,
- *     {input string}{slot_suffix[slot]},{transform_name},{private key hex},{P2PKH address of the compressed key}\n
- * slot_suffix = vk_slots_per_string(t) strings.  For the transforms whose label is the input itself plus a suffix (sha256,
- * double_sha256, md5, direct, armory, sha256_chain); electrum and multibit labels are shortened forms of the input:
- * VK_E_UNSUPPORTED (format those on the host).  At most 2^21 (input, slot) pairs and 4 GB of text per call;
- * text_cap >= slots x the input bytes + 192 bytes per pair. */
+ *     {label}{slot_suffix[slot]},{transform_name},{private key hex},{P2PKH address of the compressed key}\n
+ * slot_suffix = vk_slots_per_string(t) strings.  label = the input string itself (label_data = label_offsets = NULL: what sha256,
+ * double_sha256, md5, direct, armory and sha256_chain print) or string i of (label_data, label_offsets), laid out like
+ * (data, offsets): electrum and multibit print shortened forms of the input (src/electrum.rs:199-211, src/multibit.rs:352-360),
+ * which the caller makes once per input.  At most 2^21 (input, slot) pairs and 4 GB of text per call;
+ * text_cap >= slots x the label bytes + 192 bytes per pair. */
 int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
-                              const char *transform_name, const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len,
-                              vk_sweep_stats *out);
+                              const uint8_t *label_data, const uint32_t *label_offsets, const char *transform_name,
+                              const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out);
 
 /* Generate mode's FULL record (DerivedKey, src/derive.rs:12-41, as src/storage/schema.rs:137-262 lays it out for the 19-column
  * record batch) made on the device, column by column, for the inputs [seed_lo, seed_hi_inclusive]: one row per (input, slot) the

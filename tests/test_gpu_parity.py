@@ -878,9 +878,22 @@ def test_generate_lines_for_string_inputs_equal_the_oracles_text(eng, vko):
     assert eng.generate_lines_strings(ffi.spec(ffi.T_SHA256), [], "sha256", [""])[0] == b""
     text, _ = eng.generate_lines_strings(ffi.spec(ffi.T_SHA256), [b"", b"q", b""], "sha256", None)   # empty strings are inputs too; no suffix table
     assert text.count(b"\n") == 3 and text.startswith(b",sha256,e3b0c442")
-    for kind in (ffi.T_ELECTRUM, ffi.T_MULTIBIT, ffi.T_MILKSAD):
-        with pytest.raises(Exception):
-            eng.generate_lines_strings(ffi.spec(kind), [b"00112233445566778899aabbccddeeff"], "x", None)
+    with pytest.raises(Exception):
+        eng.generate_lines_strings(ffi.spec(ffi.T_MILKSAD), [b"00112233445566778899aabbccddeeff"], "x", None)   # no keys for string inputs
+    # labels of the caller's making (electrum prints a shortened seed, src/electrum.rs:199-211): "{label}[{chain}/{i}]"; an input that is
+    # not a hex seed has no lines
+    seeds = [b"00112233445566778899aabbccddeeff", b"not hex", b"ab" * 20, b"7f"]
+    labels = [s if len(s) <= 20 else s[:8] + b"..." + s[-8:] for s in seeds]
+    spec = ffi.spec(ffi.T_ELECTRUM, 0, 0, 3)
+    rows = eng.transform_strings(spec, seeds)
+    text, st = eng.generate_lines_strings(spec, seeds, "electrum", [f"[0/{i}]" for i in range(3)], labels=labels)
+    want = []
+    for lab, row in zip(labels, rows):
+        for i, k in enumerate(row):
+            if k is not None:
+                d = vko.derive(k)
+                want.append(lab + f"[0/{i}],electrum,".encode() + d.private_key_hex + b"," + d.p2pkh_compressed + b"\n")
+    assert text == b"".join(want) and len(want) == 9 and st["keys"] == 9
 
 
 def test_verbose_blocks_on_the_device_equal_the_oracles_text(eng, vko):

@@ -104,7 +104,8 @@ def load():
     L.vk_generate.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, u32, vp, vp, vp, vp, C.POINTER(SweepStats)]
     L.vk_generate_lines.argtypes = [vp, C.POINTER(TransformSpec), u64, u64, cp, C.POINTER(C.c_char_p), vp, sz, C.POINTER(sz), C.POINTER(SweepStats)]
     L.vk_generate_verbose.argtypes = L.vk_generate_lines.argtypes
-    L.vk_generate_lines_strings.argtypes = [vp, C.POINTER(TransformSpec), cp, C.POINTER(u32), sz, cp, C.POINTER(C.c_char_p), vp, sz, C.POINTER(sz), C.POINTER(SweepStats)]
+    L.vk_generate_lines_strings.argtypes = [vp, C.POINTER(TransformSpec), cp, C.POINTER(u32), sz, cp, C.POINTER(u32), cp, C.POINTER(C.c_char_p), vp, sz, C.POINTER(sz),
+                                            C.POINTER(SweepStats)]
     L.vk_derive_columns.argtypes = [vp, cp, sz, C.POINTER(RecordColumns)]
     L.vk_record_column_stride.restype = sz
     L.vk_record_column_stride.argtypes = [C.c_int]
@@ -236,17 +237,20 @@ class Engine:
         return ({RC_NAMES[c]: bufs[c].raw[:rc.len[c]] for c in range(RC_COLUMNS)}, rc.rows,
                 dict(keys=st.keys, inputs=st.inputs, kernel_seconds=st.kernel_seconds))
 
-    def generate_lines_strings(self, spec, strings, name, suffixes=None):
+    def generate_lines_strings(self, spec, strings, name, suffixes=None, labels=None):
         """Compact CSV text of generate mode for string inputs (vk_generate_lines_strings): (bytes, stats)."""
         blob, offs, n = pack_strings(strings)
+        lblob, loffs = None, None
+        if labels is not None:
+            lblob, loffs, _ = pack_strings(labels)
         slots = self._L.vk_slots_per_string(C.byref(spec))
-        buf = C.create_string_buffer(max(1, len(blob) * slots + n * slots * 192))
+        buf = C.create_string_buffer(max(1, len(blob if lblob is None else lblob) * slots + n * slots * 192))
         ln = C.c_size_t(0)
         st = SweepStats()
         arr = None
         if suffixes is not None:
             arr = (C.c_char_p * slots)(*[s if isinstance(s, bytes) else s.encode() for s in suffixes])
-        self._chk(self._L.vk_generate_lines_strings(self._e, C.byref(spec), blob, offs, n, name if isinstance(name, bytes) else name.encode(), arr, buf,
+        self._chk(self._L.vk_generate_lines_strings(self._e, C.byref(spec), blob, offs, n, lblob, loffs, name if isinstance(name, bytes) else name.encode(), arr, buf,
                                                      len(buf), C.byref(ln), C.byref(st)))
         return buf.raw[:ln.value], dict(keys=st.keys, inputs=st.inputs, kernel_seconds=st.kernel_seconds)
 

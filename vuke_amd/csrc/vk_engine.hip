@@ -1449,16 +1449,15 @@ extern "C" int vk_rescan_strings(vk_engine *e, uint32_t flags, vk_hit *hits, siz
 // WordlistSource / StdinSource in generate mode with ConsoleOutput's compact format: the label of a line is the input string (plus
 // the slot's suffix), which the compaction kernel takes straight from the input buffer.
 extern "C" int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
-                                         const char *transform_name, const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len,
-                                         vk_sweep_stats *out)
+                                         const uint8_t *label_data, const uint32_t *label_offsets, const char *transform_name,
+                                         const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out)
 {
     if (!e) return VK_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
     e->warn.clear();
     int rc = validate_spec(e, t, true);
     if (rc) return rc;
-    if (t->kind == VK_T_ELECTRUM || t->kind == VK_T_MULTIBIT)
-        return fail(e, VK_E_UNSUPPORTED, "vk_generate_lines_strings: electrum / multibit labels are shortened forms of the input; format those records on the host");
+    if ((label_data == nullptr) != (label_offsets == nullptr)) return fail(e, VK_E_INVALID_ARG, "label_data and label_offsets go together");
     if (!transform_name || !text || !text_len) return fail(e, VK_E_INVALID_ARG, "transform_name / text / text_len is NULL");
     *text_len = 0;
     if (out) memset(out, 0, sizeof *out);
@@ -1468,9 +1467,10 @@ extern "C" int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *
     if (slots == 0) return fail(e, VK_E_UNSUPPORTED, "the transform emits nothing for string inputs");
     if ((u64)n * slots > VK_LINES_MAX_ITEMS) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines_strings: at most 2^21 (input, slot) pairs per call");
     const u64 items = (u64)n * slots;
-    const u64 need = (u64)offsets[n] * slots + items * VK_LINE_STRIDE;
+    const uint32_t *lab_offs = label_offsets ? label_offsets : offsets; // what a line starts with: the caller's label or the input itself
+    const u64 need = (u64)lab_offs[n] * slots + items * VK_LINE_STRIDE;
     if (need >= (1ull << 32)) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines_strings: more than 4 GB of text in one call; pass fewer lines");
-    if (text_cap < need) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines_strings: text_cap must be at least slots x the input bytes + 192 bytes per (input, slot) pair");
+    if (text_cap < need) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines_strings: text_cap must be at least slots x the label bytes + 192 bytes per (input, slot) pair");
     std::vector<unsigned char> texts((size_t)(slots + 1) * VK_LINE_SUFFIX_BYTES, 0);
     for (u32 i = 0; i <= slots; i++) {
         const char *src = i < slots ? (slot_suffix ? slot_suffix[i] : "") : transform_name;
@@ -1485,6 +1485,12 @@ extern "C" int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *
     double tsec = 0.0;
     rc = strings_to_device_keys(e, t, data, offsets, n, slots, &d_keys, &d_valid, &overlong, &tsec); // strings -> slot 0, offsets -> slot 2
     if (rc) return rc;
+    if (label_data) { // the inputs have done their part: their two slots take the labels
+        SCRATCH(e, d_lab, unsigned char *, 0, std::max<size_t>(label_offsets[n], 1));
+        SCRATCH(e, d_lo, u32 *, 2, (n + 1) * 4);
+        if (label_offsets[n]) HIPCHK(e, hipMemcpy(d_lab, label_data, label_offsets[n], hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(d_lo, label_offsets, (n + 1) * 4, hipMemcpyHostToDevice));
+    }
     const unsigned char *d_data = (const unsigned char *)e->scr[0];
     const u32 *d_offs = (const u32 *)e->scr[2];
     SCRATCH(e, d_texts, unsigned char *, 9, texts.size());

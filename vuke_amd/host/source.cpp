@@ -217,8 +217,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
             auto device_ok = [&](const Transform &tr) {
                 if (fmt == 0 || (fmt & Output::DEVICE_VERBOSE)) return false;
                 if ((fmt & Output::DEVICE_COLUMNS) && g != 1) return false;
-                if (fmt & Output::DEVICE_TEXT)
-                    return tr.spec().kind != VK_T_ELECTRUM && tr.spec().kind != VK_T_MULTIBIT && strlen(tr.name()) < 32 && tr.string_slots() <= (1u << 16);
+                if (fmt & Output::DEVICE_TEXT) return strlen(tr.name()) < 32 && tr.string_slots() <= (1u << 16);
                 return true;
             };
             auto run_slice = [&](vk_engine *eng, size_t first, size_t cnt, SliceOut &o) {
@@ -300,17 +299,32 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
                         if (!(fmt & Output::DEVICE_TEXT)) return;
                         o.nkeys = 0; // counted again below
                     }
+                    // electrum / multibit print a shortened form of the input (src/electrum.rs:199-211, src/multibit.rs:352-360): made
+                    // here once per input and handed over as the label; every other transform prints the input itself
+                    const bool own_labels = t.spec().kind == VK_T_ELECTRUM || t.spec().kind == VK_T_MULTIBIT;
                     const size_t per = std::max<size_t>(1, (1u << 21) / k);
-                    std::vector<uint32_t> sub;
+                    std::vector<uint32_t> sub, lab_offs;
+                    std::vector<uint8_t> lab;
+                    lab.reserve(64);
                     for (size_t a = 0; a < cnt; a += per) {
                         const size_t c = std::min(per, cnt - a);
                         sub.resize(c + 1);
                         for (size_t i = 0; i <= c; i++) sub[i] = offs[a + i] - offs[a];
-                        const size_t at = o.text.size(), cap = (size_t)sub[c] * k + c * k * 192;
+                        if (own_labels) {
+                            lab.clear();
+                            lab_offs.assign(1, 0);
+                            for (size_t i = 0; i < c; i++) {
+                                const std::string l0 = t.label(b.str(first + a + i), 0);
+                                lab.insert(lab.end(), l0.begin(), l0.end() - (std::ptrdiff_t)suffix[0].size());
+                                lab_offs.push_back((uint32_t)lab.size());
+                            }
+                        }
+                        const size_t at = o.text.size(), cap = (size_t)(own_labels ? lab_offs[c] : sub[c]) * k + c * k * 192;
                         o.text.resize(at + cap);
                         size_t len = 0;
                         vk_sweep_stats ss;
-                        check_rc(eng, vk_generate_lines_strings(eng, &t.spec(), b.data.data() + b.offs[first] + offs[a], sub.data(), c, t.name(), sp.data(),
+                        check_rc(eng, vk_generate_lines_strings(eng, &t.spec(), b.data.data() + b.offs[first] + offs[a], sub.data(), c, own_labels ? lab.data() : nullptr,
+                                                                own_labels ? lab_offs.data() : nullptr, t.name(), sp.data(),
                                                                 o.text.data() + at, cap, &len, &ss));
                         const std::string w = last_warning(eng);
                         if (!w.empty()) o.warning = w;
