@@ -1,4 +1,4 @@
-//! Bindings to `libvuke_hip.so` (`include/vuke_hip.h`, ABI version 3) and, behind the `vuke-source` feature, the
+//! Bindings to `libvuke_hip.so` (`include/vuke_hip.h`, ABI version 4) and, behind the `vuke-source` feature, the
 //! `HipRangeSource` that plugs the engine into vuke's `Source` seam (`src/source/mod.rs:23-31` of the reference).
 pub mod ffi;
 #[cfg(feature = "vuke-source")]
@@ -32,6 +32,48 @@ impl Engine {
         buf.truncate(n.min(511));
         String::from_utf8_lossy(&buf).into_owned()
     }
+}
+
+/// The value columns of generate mode's full record for `[lo, hi]` (`vk_generate_columns`): buffers sized by
+/// `vk_record_column_stride`, truncated to what the device wrote.  Column `c` holds Parquet PLAIN bytes; `plain_to_arrow`
+/// turns a string column into the (offsets, values) pair an Arrow `StringArray` adopts without copying characters twice.
+pub struct RecordColumns {
+    pub rows: u64,
+    pub data: Vec<Vec<u8>>,
+}
+
+impl Engine {
+    pub fn generate_columns(&self, spec: &ffi::VkTransformSpec, lo: u64, hi: u64, slot_suffix: &[*const std::os::raw::c_char]) -> Result<(RecordColumns, ffi::VkSweepStats), String> {
+        let slots = unsafe { ffi::vk_slots_per_input(spec) } as u64;
+        let items = ((hi - lo + 1) * slots) as usize;
+        let mut data: Vec<Vec<u8>> = (0..ffi::VK_RC_COLUMNS).map(|c| vec![0u8; items * unsafe { ffi::vk_record_column_stride(c as i32) }]).collect();
+        let mut rc = ffi::VkRecordColumns { data: [std::ptr::null_mut(); ffi::VK_RC_COLUMNS], cap: [0; ffi::VK_RC_COLUMNS], len: [0; ffi::VK_RC_COLUMNS], rows: 0 };
+        for c in 0..ffi::VK_RC_COLUMNS {
+            rc.data[c] = data[c].as_mut_ptr();
+            rc.cap[c] = data[c].len();
+        }
+        let mut st = ffi::VkSweepStats::default();
+        check(self.0, unsafe { ffi::vk_generate_columns(self.0, spec, lo, hi, slot_suffix.as_ptr(), &mut rc, &mut st) })?;
+        for c in 0..ffi::VK_RC_COLUMNS {
+            data[c].truncate(rc.len[c]);
+        }
+        Ok((RecordColumns { rows: rc.rows, data }, st))
+    }
+}
+
+/// PLAIN BYTE_ARRAY column (4-byte little-endian length + characters per row) -> Arrow's (i32 offsets, value bytes).
+pub fn plain_to_arrow(plain: &[u8], rows: usize) -> (Vec<i32>, Vec<u8>) {
+    let mut offsets = Vec::with_capacity(rows + 1);
+    let mut values = Vec::with_capacity(plain.len().saturating_sub(4 * rows));
+    let mut at = 0usize;
+    offsets.push(0i32);
+    for _ in 0..rows {
+        let len = u32::from_le_bytes([plain[at], plain[at + 1], plain[at + 2], plain[at + 3]]) as usize;
+        values.extend_from_slice(&plain[at + 4..at + 4 + len]);
+        at += 4 + len;
+        offsets.push(values.len() as i32);
+    }
+    (offsets, values)
 }
 
 impl Drop for Engine {
