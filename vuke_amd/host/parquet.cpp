@@ -17,6 +17,7 @@
 #include <cstring>
 #include <ctime>
 #include <dlfcn.h>
+#include <future>
 #include <stdexcept>
 #include <sys/stat.h>
 #include <thread>
@@ -356,7 +357,7 @@ struct StorageOutput::Impl {
         file_pos += s.size();
     }
     // one row group: the nineteen column chunks (one PLAIN data page each) in schema order
-    void emit_group(uint64_t rows, const std::string (&body)[19], const std::string (&packed)[19])
+    void emit_group(uint64_t rows, const size_t (&raw)[19] /* uncompressed page sizes */, const std::string (&packed)[19])
     {
         RowGroupMeta g;
         g.rows = (int64_t)rows;
@@ -365,7 +366,7 @@ struct StorageOutput::Impl {
             Thrift h; // PageHeader
             h.begin();
             h.i32(1, 0); // DATA_PAGE
-            h.i32(2, (int32_t)body[c].size());
+            h.i32(2, (int32_t)raw[c]);
             h.i32(3, (int32_t)packed[c].size());
             h.struct_field(5); // DataPageHeader
             h.i32(1, (int32_t)rows);
@@ -377,7 +378,7 @@ struct StorageOutput::Impl {
             ChunkMeta m;
             m.data_page_offset = (int64_t)file_pos;
             m.size = (int64_t)(h.out.size() + packed[c].size());
-            m.raw_size = (int64_t)(h.out.size() + body[c].size());
+            m.raw_size = (int64_t)(h.out.size() + raw[c]);
             m.num_values = (int64_t)rows;
             write(h.out);
             write(packed[c]);
@@ -412,7 +413,9 @@ struct StorageOutput::Impl {
         }
         for (int c = 0; c < 19; c++)
             if (err[c]) std::rethrow_exception(err[c]);
-        emit_group(group_rows, body, packed);
+        size_t raw[19];
+        for (int c = 0; c < 19; c++) raw[c] = body[c].size();
+        emit_group(group_rows, raw, packed);
         for (int c = 0; c < 19; c++) {
             cols[c].values.clear();
             cols[c].defs.clear();
@@ -572,74 +575,106 @@ struct StorageOutput::Impl {
         for (int c = 0; c < VK_RC_COLUMNS; c++)
             if (!WIDTH[c] && cur[c] != len[c]) throw std::runtime_error("add_columns: a string column holds more values than rows");
         const int64_t now_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
-        // pages of up to WAVE row groups at a time: built and compressed on the host's threads, written in order
+        // pages of up to WAVE row groups at a time: built and compressed on the host's threads while the previous wave's pages are
+        // being written (one writer at a time, in order)
         const size_t WAVE = 8;
         const unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
-        for (size_t w0 = 0; w0 < pieces.size(); w0 += WAVE) {
-            const size_t wn = std::min(WAVE, pieces.size() - w0);
-            std::vector<std::array<std::string, 19>> body(wn), packed(wn);
-            std::atomic<size_t> next{0};
-            std::exception_ptr err;
-            std::mutex err_mu;
-            auto work = [&]() {
-                for (;;) {
-                    const size_t task = next.fetch_add(1);
-                    if (task >= wn * 19) return;
-                    const size_t pi = task / 19;
-                    const int col = (int)(task % 19);
-                    const Piece &q = pieces[w0 + pi];
-                    const uint64_t n = q.row1 - q.row0;
-                    try {
-                        std::string &out = body[pi][col];
-                        if (COLS[col].optional) { // definition levels: one RLE run
-                            Thrift t;
-                            t.varint(n << 1);
-                            t.out.push_back(col == 4 ? 0 : 1);
-                            put_le32(out, (uint32_t)t.out.size());
-                            out += t.out;
-                        }
-                        if (col == 1 || col == 2) {
-                            std::string one;
-                            const std::string &v = col == 1 ? tf : std::string("bitcoin");
-                            put_le32(one, (uint32_t)v.size());
-                            one += v;
-                            out.reserve(out.size() + n * one.size());
-                            for (uint64_t i = 0; i < n; i++) out += one;
-                        } else if (col == 3) {
-                            std::string one;
-                            put_le64(one, (uint64_t)now_ms);
-                            out.reserve(n * 8);
-                            for (uint64_t i = 0; i < n; i++) out += one;
-                        } else if (col != 4) {
-                            int dc = 0;
-                            while (SCHEMA_OF[dc] != col) dc++;
-                            out.append((const char *)data[dc] + q.v0[dc], q.v1[dc] - q.v0[dc]);
-                        }
-                        packed[pi][col] = compress_page(codec, level, out);
-                    } catch (...) {
-                        std::lock_guard<std::mutex> g(err_mu);
-                        if (!err) err = std::current_exception();
-                    }
-                }
-            };
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; t++) th.emplace_back(work);
-            for (auto &t : th) t.join();
-            if (err) std::rethrow_exception(err);
-            for (size_t pi = 0; pi < wn; pi++) {
-                const Piece &q = pieces[w0 + pi];
+        struct Wave {
+            size_t w0 = 0, wn = 0;
+            std::vector<std::array<std::string, 19>> packed;
+            std::vector<std::array<size_t, 19>> raw;
+        };
+        auto write_wave = [this, &pieces](Wave w) {
+            for (size_t pi = 0; pi < w.wn; pi++) {
+                const Piece &q = pieces[w.w0 + pi];
                 if (!fp) open_chunk();
-                std::string bs[19], ps[19];
+                std::string ps[19];
+                size_t raw[19];
                 for (int c = 0; c < 19; c++) {
-                    bs[c].swap(body[pi][c]);
-                    ps[c].swap(packed[pi][c]);
+                    ps[c].swap(w.packed[pi][c]);
+                    raw[c] = w.raw[pi][c];
                 }
-                emit_group(q.row1 - q.row0, bs, ps);
+                emit_group(q.row1 - q.row0, raw, ps);
                 chunk_records = q.records_after; // what add() would have counted up to this row
                 chunk_bytes = q.bytes_after;
                 total_records += q.row1 - q.row0;
                 if (q.close_after) close_chunk();
             }
+        };
+        std::future<void> writer;
+        auto drain = [&]() {
+            if (writer.valid()) writer.get(); // rethrows what the writer threw
+        };
+        try {
+            for (size_t w0 = 0; w0 < pieces.size(); w0 += WAVE) {
+                Wave w;
+                w.w0 = w0;
+                w.wn = std::min(WAVE, pieces.size() - w0);
+                w.packed.resize(w.wn);
+                w.raw.resize(w.wn);
+                std::atomic<size_t> next{0};
+                std::exception_ptr err;
+                std::mutex err_mu;
+                auto work = [&]() {
+                    for (;;) {
+                        const size_t task = next.fetch_add(1);
+                        if (task >= w.wn * 19) return;
+                        const size_t pi = task / 19;
+                        const int col = (int)(task % 19);
+                        const Piece &q = pieces[w0 + pi];
+                        const uint64_t n = q.row1 - q.row0;
+                        try {
+                            std::string out;
+                            if (COLS[col].optional) { // definition levels: one RLE run
+                                Thrift t;
+                                t.varint(n << 1);
+                                t.out.push_back(col == 4 ? 0 : 1);
+                                put_le32(out, (uint32_t)t.out.size());
+                                out += t.out;
+                            }
+                            if (col == 1 || col == 2) {
+                                std::string one;
+                                const std::string &v = col == 1 ? tf : std::string("bitcoin");
+                                put_le32(one, (uint32_t)v.size());
+                                one += v;
+                                out.reserve(out.size() + n * one.size());
+                                for (uint64_t i = 0; i < n; i++) out += one;
+                            } else if (col == 3) {
+                                std::string one;
+                                put_le64(one, (uint64_t)now_ms);
+                                out.reserve(n * 8);
+                                for (uint64_t i = 0; i < n; i++) out += one;
+                            } else if (col != 4) {
+                                int dc = 0;
+                                while (SCHEMA_OF[dc] != col) dc++;
+                                out.reserve(out.size() + (q.v1[dc] - q.v0[dc]));
+                                out.append((const char *)data[dc] + q.v0[dc], q.v1[dc] - q.v0[dc]);
+                            }
+                            w.raw[pi][col] = out.size();
+                            if (codec == 0) w.packed[pi][col] = std::move(out); // an uncompressed page is its body
+                            else w.packed[pi][col] = compress_page(codec, level, out);
+                        } catch (...) {
+                            std::lock_guard<std::mutex> g(err_mu);
+                            if (!err) err = std::current_exception();
+                        }
+                    }
+                };
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < nt; t++) th.emplace_back(work);
+                for (auto &t : th) t.join();
+                if (err) std::rethrow_exception(err);
+                drain();
+                writer = std::async(std::launch::async, write_wave, std::move(w));
+            }
+            drain();
+        } catch (...) {
+            if (writer.valid()) {
+                try {
+                    writer.get();
+                } catch (...) {
+                }
+            }
+            throw;
         }
     }
     void add(const std::string &source, const std::string &tf, const DerivedKey &d, const std::string *matched)
