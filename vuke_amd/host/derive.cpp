@@ -170,7 +170,23 @@ static bool decode_target(const std::string &s, uint8_t out[20], uint8_t &kind)
     return false;
 }
 
+void Matcher::prepare_device_targets()
+{
+    decode_all(dev_h160_, dev_kind_);
+    dev_ready_ = true;
+}
+
 void Matcher::device_targets(std::vector<uint8_t> &h160, std::vector<uint8_t> &kind) const
+{
+    if (dev_ready_) {
+        h160 = dev_h160_;
+        kind = dev_kind_;
+        return;
+    }
+    decode_all(h160, kind);
+}
+
+void Matcher::decode_all(std::vector<uint8_t> &h160, std::vector<uint8_t> &kind) const
 {
     // a million lines cost two SHA-256 pairs and two base conversions each: decoded on every host core (round 3; one thread took
     // 1.6 of the 3.0 s of BASELINE config 3 through the CLI)

@@ -8,6 +8,8 @@
 // Extras: --device N, --window-bits W.
 #include "vuke_host.hpp"
 
+#include <future>
+
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -381,6 +383,15 @@ int main(int argc, char **argv)
             else if (keys >= 0x1p31L) opts.window_bits = 26;
         }
         opts.layout = layout;
+        // scan: the targets file is read and decoded on its own thread while the engines start (the HIP runtime's start and the table
+        // build leave the host cores idle); a failure surfaces where the reference reports it, after "Loading targets"
+        std::future<Matcher> targets_loading;
+        if (cmd == "scan" && !targets.empty())
+            targets_loading = std::async(std::launch::async, [&targets]() {
+                Matcher m = Matcher::load(targets);
+                m.prepare_device_targets();
+                return m;
+            });
         std::vector<vk_engine *> engines(devs.size(), nullptr);
         const bool timing_env = getenv("VUKE_HIP_TIMING") != nullptr;
         const auto t_create = std::chrono::steady_clock::now();
@@ -484,7 +495,7 @@ int main(int argc, char **argv)
         ProcessStats stats;
         if (cmd == "scan") {
             fprintf(stderr, "Loading targets from \"%s\"...\n", targets.c_str());
-            Matcher m = Matcher::load(targets);
+            Matcher m = targets_loading.valid() ? targets_loading.get() : Matcher::load(targets);
             fprintf(stderr, "Loaded %zu targets.\n", m.count());
             fprintf(stderr, "Scanning...\n");
             stamp("targets loaded");

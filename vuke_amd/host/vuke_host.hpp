@@ -104,10 +104,15 @@ public:
     // Device form of the set: hash160 + kind for every line that is a valid mainnet P2PKH / P2WPKH
     // address (any other line can never equal a derived address, so it cannot match in the reference).
     void device_targets(std::vector<uint8_t> &h160, std::vector<uint8_t> &kind) const;
+    // decodes the set now (e.g. on the thread that loaded the file, while the GPU engine is still starting); device_targets() then copies
+    void prepare_device_targets();
     bool contains(const std::string &s) const { return targets_.count(s) != 0; }
 
 private:
+    void decode_all(std::vector<uint8_t> &h160, std::vector<uint8_t> &kind) const;
     std::unordered_set<std::string> targets_;
+    std::vector<uint8_t> dev_h160_, dev_kind_;
+    bool dev_ready_ = false;
 };
 
 // ---------------------------------------------------------------- transform/mod.rs
