@@ -100,3 +100,20 @@ def test_kernel_source_hash_ignores_comments_but_not_code(tmp_path, monkeypatch)
     assert bench.csrc_hash() != h0
     (d / "a.cuh").write_text('// one\nint f(int x) { return x + 1; } /* two */\nconst char *s = "// not a comment!";\n')
     assert bench.csrc_hash() != h0
+
+
+def test_profile_files_cited_in_the_documents_exist():
+    """DESIGN / README / INTEGRATION cite rocprof summaries and probe records under profiles/ by name; a re-taken profile renames
+    them (the tag carries the round and a letter), and a stale citation would point the reader at nothing."""
+    import glob
+    import re
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("tools", "README.md")):
+        text = open(os.path.join(ROOT, doc)).read()
+        for cited in set(re.findall(r"profiles/[A-Za-z0-9_.*{},\-]+", text)):
+            cited = cited.rstrip(".,)")
+            pats = [cited]
+            m = re.match(r"(.*)\{([^}]*)\}(.*)", cited)
+            if m:
+                pats = [m.group(1) + x + m.group(3) for x in m.group(2).split(",")]
+            for p in pats:
+                assert glob.glob(os.path.join(ROOT, p)) or glob.glob(os.path.join(ROOT, p + "*")), (doc, p)
