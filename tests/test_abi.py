@@ -117,3 +117,17 @@ def test_profile_files_cited_in_the_documents_exist():
                 pats = [m.group(1) + x + m.group(3) for x in m.group(2).split(",")]
             for p in pats:
                 assert glob.glob(os.path.join(ROOT, p)) or glob.glob(os.path.join(ROOT, p + "*")), (doc, p)
+
+
+def test_tests_cited_in_the_documents_exist():
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "tests", "*.py")):
+        names |= set(re.findall(r"^def (test_\w+)", open(f).read(), re.M))
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        for cited in set(re.findall(r"::(test_[A-Za-z0-9_]+\*?)", text)):
+            assert any(n.startswith(cited.rstrip("*")) for n in names), (doc, cited)
+        for f in set(re.findall(r"tests/(test_\w+\.py)", text)):
+            assert os.path.exists(os.path.join(ROOT, "tests", f)), (doc, f)
