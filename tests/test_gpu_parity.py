@@ -211,6 +211,10 @@ def test_scan_planted_targets_priority(eng, vko):
         h = vko.sha256(b"decoy" + struct.pack("<Q", j))[:20]
         h160s.append(h); kinds.append(j & 1)
         lines.append(pyref.b58check(b"\0" + h) if not (j & 1) else vko.segwit_encode("bc", 0, h))
+    # the same target listed six times (a HashSet of strings in the reference, src/matcher.rs:50-56): still one hit for its key
+    lines += [lines[0]] * 5
+    h160s += [h160s[0]] * 5
+    kinds += [kinds[0]] * 5
     eng.targets_set(h160s, kinds)
     m = vko.Matcher(lines)
     for flags in (3, 1, 2):
