@@ -14,8 +14,11 @@
  *   Transform::apply_batch (numeric inputs)                 vk_transform_batch
  *     src/transform/mod.rs:39-65
  *   TransformType  src/transform/mod.rs:68-98               vk_transform_spec
- *   KeyDeriver::derive  src/derive.rs:78-165                vk_derive_batch (hash160s; text
- *                                                           encodings stay on the host)
+ *   KeyDeriver::derive  src/derive.rs:78-165                vk_derive_batch (hash160s), vk_derive_columns
+ *                                                           (every field of the record, as columns)
+ *   ConsoleOutput::key  src/output/console.rs:62-81         vk_generate_lines, vk_generate_verbose,
+ *                                                           vk_generate_lines_strings (text made on the device)
+ *   records_to_batch  src/storage/schema.rs:137-262         vk_generate_columns, vk_derive_columns
  *   Matcher::{from_addresses,check}  src/matcher.rs:62-98   vk_targets_set + on-device probe
  *   MatchInfo/AddressType  src/matcher.rs:13-36             vk_hit.addr_kind
  *   GpuError  src/gpu/error.rs:7-20                         VK_E_* + vk_last_error
