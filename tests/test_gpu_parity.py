@@ -3,6 +3,7 @@
 Run on the MI355X box with `pytest -m gpu`.  Every compute call goes through
 libvuke_hip.so; the oracle is only the checker.
 """
+import os
 import random
 import struct
 
@@ -1012,6 +1013,56 @@ def test_record_columns_on_the_device_equal_the_oracles_records(eng, vko):
                 assert got[name] == want[name], (gs.kind, lo, name)
     with pytest.raises(Exception):
         eng.generate_columns(ffi.spec(ffi.T_SHA256), 0, 2**19, [""] * 3)       # more than 2^20 (input, slot) pairs
+
+
+def _oracle_records(vko, osp, lo, hi, suffix):
+    """(records, source labels) of a range from the oracle, the per-key work spread over the host cores (ctypes drops the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    slots = len(suffix)
+
+    def one(seed):
+        out = []
+        for sub in range(slots):
+            k = vko.transform_key(osp, seed, sub)
+            if k is not None:
+                out.append((vko.derive(k), f"{seed}{suffix[sub]}".encode()))
+        return out
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        rows = [r for part in ex.map(one, range(lo, hi + 1), chunksize=256) for r in part]
+    return [r[0] for r in rows], [r[1] for r in rows]
+
+
+def test_record_columns_of_the_staged_transforms_over_many_tiles(eng, vko):
+    """vk_generate_columns keeps the public keys in a scratch slot across run_range; the staged sweep of
+    sha256_chain / armory (run_range_staged) used to take the same slot for its keys -- the raw-key sweep then read its keys out of
+    the buffer it wrote public keys into (wrong private_key / WIF / address columns once a call spans more than one tile), and
+    armory's first chunk reallocated the slot under the caller.  Both transforms over many tiles (2^18 items of sha256_chain, a
+    first-call armory range on a fresh engine) against the oracle's records, every column."""
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+    CH = ("iterated", "indexed:be", "indexed:le", "counter")
+    fresh = vuke_amd.Engine(0)          # armory as the first user of the scratch slots (the reallocation case)
+    try:
+        cases = [
+            (fresh, ffi.spec(ffi.T_ARMORY), vko.spec(vko.T_ARMORY), ["", ""], (0, 40_000)),
+            (fresh, ffi.spec(ffi.T_ARMORY), vko.spec(vko.T_ARMORY), ["", ""], (2**64 - 3000, 2**64 - 1)),
+            (eng, ffi.spec(ffi.T_SHA256_CHAIN, ffi.VARIANT_ALL, 0, 4), vko.spec(vko.T_SHA256_CHAIN, vko.VARIANT_ALL, 0, 4),
+             [f"[{v}:{i}]" for _ in range(2) for v in CH for i in range(4)], (2**32 - 4096, 2**32 + 4095)),
+            (eng, ffi.spec(ffi.T_SHA256_CHAIN, 0, 0, 10), vko.spec(vko.T_SHA256_CHAIN, 0, 0, 10),
+             [f"[iterated:{i}]" for _ in range(2) for i in range(10)], (1, 13_107)),
+        ]
+        for e, gs, osp, suffix, (lo, hi) in cases:
+            assert vko.slots_per_input(osp) == len(suffix)
+            if gs.kind == ffi.T_ARMORY:
+                suffix = [vko.transform_label(osp, 7, sub)[1:] for sub in range(len(suffix))]   # whatever follows the input in the oracle's label
+            got, rows, st = e.generate_columns(gs, lo, hi, suffix)
+            recs, srcs = _oracle_records(vko, osp, lo, hi, suffix)
+            want = _columns_of(recs, srcs)
+            assert rows == len(recs) == st["keys"] and rows > 6_000
+            for name in ffi.RC_NAMES:
+                assert got[name] == want[name], (gs.kind, lo, name)
+    finally:
+        fresh.close()
 
 
 def fold_digests(parts):

@@ -26,6 +26,8 @@ static_assert(sizeof(vk_hit) == 72, "vk_hit is 72 bytes");
 
 static thread_local std::string g_create_error;
 
+enum { VK_SCR_STAGED = 10, VK_SCR_SLOTS = 11 };
+
 struct vk_engine {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -60,9 +62,11 @@ struct vk_engine {
     size_t work_bytes = 0;
     // device scratch for the batch entry points (inputs / outputs of one call), kept between calls: a hipMalloc +
     // hipFree pair per buffer per call cost more than the kernel for batches of a few hundred keys
-    // slots 0-5: inputs / outputs; 6-9: the key-derivation chains (staging slices, chain state, validity, ring)
-    void *scr[10] = {};
-    size_t scr_cap[10] = {};
+    // slots 0-5: inputs / outputs; 6-9: the key-derivation chains (staging slices, chain state, validity, ring);
+    // VK_SCR_STAGED: the staged keys of run_range_staged -- owned by run_range, so no caller of run_range may hold it
+    // (every other slot a caller took BEFORE run_range stays valid across it: run_range touches no other slot)
+    void *scr[VK_SCR_SLOTS] = {};
+    size_t scr_cap[VK_SCR_SLOTS] = {};
     std::mutex mu;
     std::string err;
     std::string warn; // what a successful call wants the caller to know (vk_last_warning); cleared on entry of every call that can set it
@@ -451,7 +455,7 @@ static int run_range_staged(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32
         const u64 left = span - done; // inclusive
         const u64 n = std::min<u64>(left, step_inputs - 1) + 1, items = n * slots;
         const size_t extra = kind == VK_T_ARMORY ? items * (32 + 64) : 0;
-        SCRATCH(e, d_keys, u32 *, 5, items * 32 + items + 64 + extra);
+        SCRATCH(e, d_keys, u32 *, VK_SCR_STAGED, items * 32 + items + 64 + extra);
         unsigned char *d_valid = (unsigned char *)d_keys + items * 32;
         double pre_seconds = 0.0; // kernel time of the staging work that is not a run_range of the caller's statistics
         u32 pre_launches = 0;
@@ -1798,7 +1802,7 @@ extern "C" int vk_debug_scratch(vk_engine *e, int slot, size_t offset, uint8_t *
 {
     if (!e || !out) return VK_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
-    if (slot < 0 || slot >= 10 || !e->scr[slot] || offset + n > e->scr_cap[slot]) return fail(e, VK_E_INVALID_ARG, "vk_debug_scratch: slot / range");
+    if (slot < 0 || slot >= VK_SCR_SLOTS || !e->scr[slot] || offset + n > e->scr_cap[slot]) return fail(e, VK_E_INVALID_ARG, "vk_debug_scratch: slot / range");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipMemcpy(out, (const unsigned char *)e->scr[slot] + offset, n, hipMemcpyDeviceToHost));
     return VK_OK;
