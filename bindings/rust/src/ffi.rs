@@ -3,7 +3,7 @@
 use core::mem::{offset_of, size_of};
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const VK_ABI_VERSION: c_int = 4;
+pub const VK_ABI_VERSION: c_int = 5;
 pub const VK_OK: c_int = 0;
 pub const VK_E_NO_DEVICE: c_int = -1;
 pub const VK_E_HIP: c_int = -2;
@@ -137,8 +137,11 @@ pub struct VkEngineInfo {
     pub _pad: u32,
     pub table_bytes: u64,
     pub table_build_seconds: f64,
+    pub runtime_init_seconds: f64,
+    pub alloc_seconds: f64,
+    pub table_wall_seconds: f64,
 }
-const _: () = assert!(size_of::<VkEngineInfo>() == 48);
+const _: () = assert!(size_of::<VkEngineInfo>() == 72);
 const _: () = assert!(offset_of!(VkEngineInfo, device) == 0);
 const _: () = assert!(offset_of!(VkEngineInfo, cu_count) == 4);
 const _: () = assert!(offset_of!(VkEngineInfo, window_bits) == 8);
@@ -149,6 +152,9 @@ const _: () = assert!(offset_of!(VkEngineInfo, layout) == 24);
 const _: () = assert!(offset_of!(VkEngineInfo, _pad) == 28);
 const _: () = assert!(offset_of!(VkEngineInfo, table_bytes) == 32);
 const _: () = assert!(offset_of!(VkEngineInfo, table_build_seconds) == 40);
+const _: () = assert!(offset_of!(VkEngineInfo, runtime_init_seconds) == 48);
+const _: () = assert!(offset_of!(VkEngineInfo, alloc_seconds) == 56);
+const _: () = assert!(offset_of!(VkEngineInfo, table_wall_seconds) == 64);
 
 /// AnalysisConfig of the reference (`src/analyze/mod.rs:61-66`) in device form.
 #[repr(C)]
@@ -256,9 +262,4 @@ extern "C" {
                      out: *mut VkSearchResult) -> c_int;
     pub fn vk_slots_per_input(t: *const VkTransformSpec) -> u32;
     pub fn vk_slots_per_string(t: *const VkTransformSpec) -> u32;
-    // test hooks of the engine's own test-suite
-    pub fn vk_debug_table_entry(e: *mut VkEngine, window: u32, digit: u32, xy: *mut u8) -> c_int;
-    pub fn vk_debug_scratch(e: *mut VkEngine, slot: c_int, offset: usize, out: *mut u8, n: usize) -> c_int;
-    pub fn vk_debug_chain_stop(e: *mut VkEngine, stages: c_int) -> c_int;
-    pub fn vk_debug_field(e: *mut VkEngine, op: c_int, a: *const u8, b: *const u8, n: usize, out: *mut u8) -> c_int;
 }

@@ -28,10 +28,12 @@ impl HipRangeSource {
 }
 
 /// What `Transform::apply_batch` appends to the input's decimal string in the label of slot `sub`
-/// (`src/transform/lcg.rs:54-66`, `xorshift.rs:43-47`, `sha256_chain.rs:67`).
+/// (`src/transform/lcg.rs:54-66`, `xorshift.rs:43-47`, `sha256_chain.rs:67`).  Held slot by slot to the oracle-made
+/// `tests/golden/labels.json` by `tests/test_labels.py`, which replays this function from its source text: keep its shape.
 pub fn label_suffix(spec: &VkTransformSpec, sub: u32) -> String {
     const LCG: [&str; 4] = ["glibc", "minstd", "msvc", "borland"];
-    const XS: [&str; 4] = ["64", "128", "128plus", "128starstar"];
+    // XorshiftVariant::name() (src/xorshift.rs:36-43), NOT the short forms from_str also accepts
+    const XS: [&str; 4] = ["xorshift64", "xorshift128", "xorshift128+", "xoroshiro128**"];
     const CH: [&str; 4] = ["iterated", "indexed:be", "indexed:le", "counter"];
     let all = spec.variant == VK_VARIANT_ALL;
     match spec.kind {

@@ -40,10 +40,13 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 4 /* 2: vk_sweep_stats.shader_clock_ghz, vk_scan_strings; 3: vk_generate_lines, vk_last_warning,
+#define VK_ABI_VERSION 5 /* 2: vk_sweep_stats.shader_clock_ghz, vk_scan_strings; 3: vk_generate_lines, vk_last_warning,
                            vk_sweep_stats.inputs_skipped (was padding), string limits 448 bytes, vk_engine_opts.algo must be 0;
                            4: vk_generate_lines_strings, vk_generate_verbose,
-                           vk_generate_columns / vk_derive_columns + vk_record_columns */
+                           vk_generate_columns / vk_derive_columns + vk_record_columns;
+                           5: vk_engine_info_t gains runtime_init_seconds / alloc_seconds / table_wall_seconds; the vk_debug_*
+                           test hooks leave this header and the shipped library (include/vuke_hip_test_hooks.h,
+                           libvuke_hip_hooks.so) */
 
 /* error codes */
 #define VK_OK 0
@@ -153,7 +156,12 @@ typedef struct vk_engine_info_t {
     uint32_t layout;
     uint32_t _pad;
     uint64_t table_bytes;   /* table entries * 64 */
-    double table_build_seconds;
+    double table_build_seconds;  /* hipEvent time of the two table kernels */
+    /* where vk_engine_create's wall time went (ABI 5): HIP runtime start + small buffers; the hipMalloc of workspace and
+     * table (waits for the driver's scrub when another process has just freed as much); table kernels launch -> sync */
+    double runtime_init_seconds;
+    double alloc_seconds;
+    double table_wall_seconds;
 } vk_engine_info_t;
 
 int vk_abi_version(void);
@@ -361,19 +369,8 @@ uint32_t vk_slots_per_input(const vk_transform_spec *t);
 /* Slots one string input (Input::from_string: no numeric forms) occupies; 0 = the transform emits nothing for strings. */
 uint32_t vk_slots_per_string(const vk_transform_spec *t);
 
-/* Test hook: (d << (window_bits*w)) * G table entry as 64 bytes X||Y big-endian. */
-int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digit, uint8_t xy[64]);
-/* Test hook: n bytes at `offset` of the engine's device scratch slot `slot` (inputs, outputs and chain state of the last
- * batch call; layout is internal).  Used by the GPU tests to look at intermediate values of the key-derivation chains. */
-int vk_debug_scratch(vk_engine *e, int slot, size_t offset, uint8_t *out, size_t n);
-/* Test hook: the multibit chain of the following vk_transform_strings calls stops after `stages` of its five kernels
- * (1 prepare, 2 + first stretch, 3 + repacking, 4 + second stretch; 0 = run to the end, the default), leaving the chain state
- * in scratch slot 7 for vk_debug_scratch.  No keys are produced by a stopped chain. */
-int vk_debug_chain_stop(vk_engine *e, int stages);
-
-/* Test hook: field multiply / inverse on the device, big-endian 32-byte operands. */
-int vk_debug_field(vk_engine *e, int op /* 0 mul, 1 sqr, 2 inv, 3 add, 4 sub */, const uint8_t *a, const uint8_t *b,
-                   size_t n, uint8_t *out);
+/* The vk_debug_* test hooks of ABI versions 1-4 are not part of this interface any more: include/vuke_hip_test_hooks.h,
+ * exported only by the test build libvuke_hip_hooks.so. */
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,7 @@ int main(void)
     S(vk_engine_info_t); F(vk_engine_info_t, device); F(vk_engine_info_t, cu_count); F(vk_engine_info_t, window_bits); F(vk_engine_info_t, windows);
     F(vk_engine_info_t, batch); F(vk_engine_info_t, blocks_per_cu); F(vk_engine_info_t, layout); F(vk_engine_info_t, _pad);
     F(vk_engine_info_t, table_bytes); F(vk_engine_info_t, table_build_seconds);
+    F(vk_engine_info_t, runtime_init_seconds); F(vk_engine_info_t, alloc_seconds); F(vk_engine_info_t, table_wall_seconds);
     S(vk_search_target); F(vk_search_target, mode); F(vk_search_target, n_cascade); F(vk_search_target, key); F(vk_search_target, mask_bits);
     F(vk_search_target, _pad); F(vk_search_target, bits); F(vk_search_target, targets);
     S(vk_search_result); F(vk_search_result, found); F(vk_search_result, n_keys); F(vk_search_result, seed); F(vk_search_result, seeds_checked);

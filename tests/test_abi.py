@@ -28,7 +28,31 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/vuke_hip.h but not exported"
     assert sorted(_ffi.EXPORTS) == names
-    assert L.vk_abi_version() == 4
+    assert L.vk_abi_version() == 5
+
+
+def declared_hooks():
+    hdr = open(os.path.join(ROOT, "include", "vuke_hip_test_hooks.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(vk_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_shipped_library_exports_no_test_hooks(built):
+    """The vk_debug_* hooks live in include/vuke_hip_test_hooks.h and in libvuke_hip_hooks.so (the same sources with
+    -DVK_TEST_HOOKS) only: the shipped library exports none of them, the test build all of them plus the whole boundary."""
+    from vuke_amd import _ffi
+    hooks = declared_hooks()
+    assert hooks == sorted(_ffi.HOOK_EXPORTS) and len(hooks) == 5 and all(h.startswith("vk_debug_") for h in hooks)
+    L, H = _ffi.load(), _ffi.load(hooks=True)
+    for h in hooks:
+        assert not hasattr(L, h), f"{h} exported by the shipped library"
+        assert hasattr(H, h), f"{h} missing from libvuke_hip_hooks.so"
+    for n in declared_functions():
+        assert hasattr(H, n)
+    assert not any("vk_debug" in n for n in declared_functions())
+    # nothing in the product reads launch-policy knobs from the environment any more (ADVICE r3)
+    eng_src = open(os.path.join(ROOT, "vuke_amd", "csrc", "vk_engine.hip")).read()
+    assert "getenv" not in eng_src
 
 
 def test_struct_layouts_match_header():

@@ -28,6 +28,16 @@ def eng():
     e.close()
 
 
+@pytest.fixture(scope="module")
+def heng():
+    """An engine of libvuke_hip_hooks.so: the shipped sources + the vk_debug_* hooks (include/vuke_hip_test_hooks.h), for the tests
+    that look inside an engine.  Everything that is a parity claim about the product goes through `eng` (libvuke_hip.so)."""
+    import vuke_amd
+    e = vuke_amd.Engine(0, hooks=True)
+    yield e
+    e.close()
+
+
 def be(x):
     return x.to_bytes(32, "big")
 
@@ -56,7 +66,8 @@ def field_cases():
     return ops, a, b
 
 
-def test_field_ops(eng):
+def test_field_ops(heng):
+    eng = heng
     ops, a, b = field_cases()
     ab, bb = [be(x) for x in a], [be(x) for x in b]
     for op, f in ops:
@@ -93,10 +104,10 @@ def _check_table(e, vko, rnd, n_random):
         assert e.table_entry(nwin - 1, (1 << W) - 1) == (bytes(32), bytes(32))
 
 
-def test_table_entries(eng, vko):
+def test_table_entries(heng, vko):
     # entry (w, d) = (d << W*w) * G; default engine = 24-bit windows
-    assert eng.info()["window_bits"] == 24 and eng.info()["windows"] == 11
-    _check_table(eng, vko, random.Random(12), 60)
+    assert heng.info()["window_bits"] == 24 and heng.info()["windows"] == 11
+    _check_table(heng, vko, random.Random(12), 300)
 
 
 def test_derive_batch_edges_and_random(eng, vko):
@@ -274,9 +285,11 @@ def test_other_window_widths(vko):
     import vuke_amd
     from vuke_amd import _ffi as ffi
     for W, batch in ((6, 4), (12, 16), (13, 1), (16, 32), (21, 64)):
-        e = vuke_amd.Engine(0, window_bits=W, batch=batch)
+        e = vuke_amd.Engine(0, window_bits=W, batch=batch, hooks=True)   # the table itself: through the test hooks
+        _check_table(e, vko, random.Random(W), 40)
+        e.close()
+        e = vuke_amd.Engine(0, window_bits=W, batch=batch)               # what the shipped library computes with the same geometry
         assert e.info()["window_bits"] == W and e.info()["batch"] == batch
-        _check_table(e, vko, random.Random(W), 12)
         st, _ = e.sweep(ffi.spec(ffi.T_MILKSAD), 1000, 1999, flags=3)
         ost, _ = vko.sweep(vko.spec(vko.T_MILKSAD), 1000, 1999, flags=3, nthreads=8)
         assert st["digest"] == ost["digest"] and st["keys"] == 1000, W
@@ -287,7 +300,7 @@ def test_signed_nine_window_layout(eng, vko):
     """VK_LAYOUT_SIGNED9: 9 signed-digit windows (8 additions per key, 120 GB table)."""
     import vuke_amd
     from vuke_amd import _ffi as ffi
-    e = vuke_amd.Engine(0, layout=ffi.LAYOUT_SIGNED9, batch=16)
+    e = vuke_amd.Engine(0, layout=ffi.LAYOUT_SIGNED9, batch=16, hooks=True)      # table entries: through the test hooks
     info = e.info()
     assert info["layout"] == 1 and info["windows"] == 9 and info["table_bytes"] == (4 * 2**28 + 4 * 2**27 + 2**28 + 9) * 64
     # table entries: window i covers bits off_i.., entry d = (d << off_i) * G; the top entry 2^28 is 2^256 mod n
@@ -295,7 +308,12 @@ def test_signed_nine_window_layout(eng, vko):
     tbs = [28, 28, 28, 28, 27, 27, 27, 27, 28]
     rnd = random.Random(31)
     picks = [(i, d) for i in range(9) for d in (1, 2, 7, 8, 9, (1 << tbs[i]) - 1, 1 << tbs[i], (1 << (tbs[i] // 2)), (3 << (tbs[i] // 2)) | 5)]
-    picks += [(i, rnd.randrange(1, (1 << tbs[i]) + 1)) for i in range(9) for _ in range(6)]
+    picks += [(i, rnd.randrange(1, (1 << tbs[i]) + 1)) for i in range(9) for _ in range(40)]
+    # seams of the builder (vk_table_combine_kernel): a wave owns 64 low digits and walks runs of 256 high digits
+    for i in (0, 4, 8):
+        h = tbs[i] // 2
+        picks += [(i, (hi << h) | lo) for hi in (1, 255, 256, 257, 511, 512, (1 << (tbs[i] - h)) - 256, (1 << (tbs[i] - h)) - 1)
+                  for lo in (0, 1, 63, 64, 65, (1 << h) - 64, (1 << h) - 1)]
     for i, d in picks:
         k = (d << offs[i]) % N if (d << offs[i]) >> 256 else d << offs[i]
         if (d << offs[i]) >> 256 and not (i == 8 and d == 1 << 28):
@@ -303,6 +321,8 @@ def test_signed_nine_window_layout(eng, vko):
         _, p65 = vko.pubkey(be(k))
         x, y = e.table_entry(i, d)
         assert x + y == p65[1:], (i, d)
+    e.close()
+    e = vuke_amd.Engine(0, layout=ffi.LAYOUT_SIGNED9, batch=16)                  # the shipped library from here on
     # keys that drive the recoding through every corner: digits exactly half, half+1, all ones, carries into the top window
     keys = [be(1), be(N - 1), be(N - 2), be(2**256 - 1), be(N), bytes(32), be(2**255), be(2**228), be(2**228 - 1),
             be((1 << 28) | 1), be(1 << 28), be((1 << 28) + 1), be((1 << 29) - 1), be(1 << 29), be(((1 << 28) + 1) << 29),
@@ -400,7 +420,7 @@ def test_multibit_chain(eng, vko):
     assert sum(1 for r in got for k in r if k is not None) == 23 * 20
 
 
-def test_multibit_chain_stage_by_stage_against_hashlib(eng):
+def test_multibit_chain_stage_by_stage_against_hashlib(heng):
     """The five kernels of the MultiBit chain one at a time (vk_debug_chain_stop) against hashlib / hmac: U1 of both stretches, the
     two PBKDF2 results after the ring has carried every group through its 32 chunks, and the rebuilt 48-word password -- for
     lanes 0, 1 and 63 of the first group and lanes of the second (round 3's first ring advanced lane 0 of every group only)."""
@@ -409,6 +429,7 @@ def test_multibit_chain_stage_by_stage_against_hashlib(eng):
     import struct
     from tests.test_oracle_multibit import synthetic_wordlist
     from vuke_amd import _ffi as ffi
+    eng = heng
     words = synthetic_wordlist()
     eng.bip39_wordlist_set(words)
     rnd = random.Random(5)
@@ -441,7 +462,7 @@ def test_multibit_chain_stage_by_stage_against_hashlib(eng):
     assert all(k is not None for r in eng.transform_strings(spec, ms[:3]) for k in r)
 
 
-def test_chain_ring_under_stress(vko, monkeypatch):
+def test_chain_ring_under_stress(vko):
     """The ring of vk_chain.cuh away from its comfortable operating point: far more workers than groups (most pops wait for a push,
     the spin path), one-iteration chunks (2 047 laps per stretch, every hand-over through the release / acquire fences), and groups
     that do not fill a wave -- results must not depend on any of it.  Electrum with a short stretch would not exercise more."""
@@ -454,12 +475,11 @@ def test_chain_ring_under_stress(vko, monkeypatch):
     ms = [" ".join(rnd.choice(words) for _ in range(12)) for _ in range(150)]
     want = {i: [k for _, k in vko.multibit_keys(wl, ms[i], count=3)[2]] for i in (0, 1, 63, 64, 65, 127, 128, 149)}
     spec = ffi.spec(ffi.T_MULTIBIT, 0, 0, 3)
-    e = vuke_amd.Engine(0, window_bits=16)
+    e = vuke_amd.Engine(0, window_bits=16, hooks=True)
     try:
         e.bip39_wordlist_set(words)
-        for workers, chunk in (("512", "64"), ("3", "1"), ("2", "7"), ("1", "2047"), ("64", "300")):
-            monkeypatch.setenv("VUKE_RING_WORKERS", workers)
-            monkeypatch.setenv("VUKE_RING_CHUNK", chunk)
+        for workers, chunk in ((512, 64), (3, 1), (2, 7), (1, 2047), (64, 300)):
+            e.debug_ring_knobs(chunk_iters=chunk, workers=workers)
             rows = e.transform_strings(spec, [m.encode() for m in ms])
             for i, w in want.items():
                 assert rows[i] == w, (workers, chunk, i)

@@ -1,23 +1,19 @@
 """Chain ring probe (GPU box): time of one vk_transform_strings call per config-5 chain for worker counts, chunk sizes and input
-counts.  VUKE_RING_WAVES_PER_SIMD / VUKE_RING_CHUNK are read by the library on every call."""
+counts, through the vk_debug_ring_knobs hook of the test build (libvuke_hip_hooks.so)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vuke_amd
 from vuke_amd import _ffi as ffi
 import bench_workloads as wl
 
-eng = vuke_amd.Engine(0)
+eng = vuke_amd.Engine(0, hooks=True)
 eng.bip39_wordlist_set(wl.c5_wordlist())
 which = sys.argv[1] if len(sys.argv) > 1 else "m"
 lines_all = wl.c5_mnemonics(262144) if which == "m" else wl.c5_electrum_seeds(262144)
 spec = ffi.spec(ffi.T_MULTIBIT if which == "m" else ffi.T_ELECTRUM, 0, 0, 20)
 
 def run(n, wps=None, chunk=None, workers=None):
-    for k, v in (("VUKE_RING_WAVES_PER_SIMD", wps), ("VUKE_RING_CHUNK", chunk), ("VUKE_RING_WORKERS", workers)):
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = str(v)
+    eng.debug_ring_knobs(chunk_iters=chunk or 0, waves_per_simd=wps or 0, workers=workers or 0)
     lines = lines_all[:n]
     best = 1e9
     for _ in range(2):

@@ -9,6 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvuke_hip.so")
 LIB_PATH = os.environ.get("VUKE_HIP_LIB", LIB_PATH)  # A/B runs of two builds of the same library (tools/), nothing else
+HOOKS_LIB_PATH = LIB_PATH[:-3] + "_hooks.so"          # the same sources built with -DVK_TEST_HOOKS (include/vuke_hip_test_hooks.h): tests / tools only
 
 VK_OK = 0
 VK_E_NO_DEVICE, VK_E_HIP, VK_E_INVALID_ARG, VK_E_UNSUPPORTED, VK_E_NOMEM = -1, -2, -3, -4, -5
@@ -44,7 +45,8 @@ class EngineInfo(C.Structure):
     _fields_ = [("device", C.c_int32), ("cu_count", C.c_uint32), ("window_bits", C.c_uint32), ("windows", C.c_uint32),
                 ("batch", C.c_uint32), ("blocks_per_cu", C.c_uint32), ("layout", C.c_uint32), ("_pad", C.c_uint32),
                 ("table_bytes", C.c_uint64),
-                ("table_build_seconds", C.c_double)]
+                ("table_build_seconds", C.c_double), ("runtime_init_seconds", C.c_double), ("alloc_seconds", C.c_double),
+                ("table_wall_seconds", C.c_double)]
 
 
 class SearchTarget(C.Structure):
@@ -73,20 +75,26 @@ EXPORTS = [
     "vk_abi_version", "vk_device_count", "vk_engine_create", "vk_engine_create_ex", "vk_engine_destroy", "vk_engine_info",
     "vk_last_error", "vk_last_warning", "vk_targets_set", "vk_sweep", "vk_generate", "vk_generate_lines", "vk_generate_verbose", "vk_generate_lines_strings", "vk_generate_columns", "vk_derive_columns", "vk_record_column_stride", "vk_derive_batch", "vk_derive_batch_pub", "vk_transform_batch",
     "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_scan_strings", "vk_rescan_strings", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
-    "vk_slots_per_input", "vk_slots_per_string", "vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop",
+    "vk_slots_per_input", "vk_slots_per_string",
 ]
+HOOK_EXPORTS = ["vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop", "vk_debug_ring_knobs"]
 
 _lib = None
+_hooks_lib = None
 
 
-def load():
-    """Load libvuke_hip.so; raises OSError if it has not been built (no fallback)."""
-    global _lib
-    if _lib is not None:
+def load(hooks=False):
+    """Load libvuke_hip.so (hooks=True: libvuke_hip_hooks.so, the test build that also exports the vk_debug_* hooks); raises
+    OSError if it has not been built (no fallback)."""
+    global _lib, _hooks_lib
+    if not hooks and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise OSError(f"{LIB_PATH} is missing: build it with vuke_amd/csrc/build.sh (or __graft_entry__.build())")
-    L = C.CDLL(LIB_PATH)
+    if hooks and _hooks_lib is not None:
+        return _hooks_lib
+    path = HOOKS_LIB_PATH if hooks else LIB_PATH
+    if not os.path.exists(path):
+        raise OSError(f"{path} is missing: build it with vuke_amd/csrc/build.sh (or __graft_entry__.build())")
+    L = C.CDLL(path)
     vp, cp, sz, u32, u64 = C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint64
     L.vk_abi_version.restype = C.c_int
     L.vk_device_count.restype = C.c_int
@@ -124,11 +132,15 @@ def load():
     L.vk_slots_per_input.restype = u32
     L.vk_slots_per_string.argtypes = [C.POINTER(TransformSpec)]
     L.vk_slots_per_string.restype = u32
-    L.vk_debug_table_entry.argtypes = [vp, u32, u32, vp]
-    L.vk_debug_field.argtypes = [vp, C.c_int, cp, cp, sz, vp]
-    L.vk_debug_scratch.argtypes = [vp, C.c_int, sz, vp, sz]
-    L.vk_debug_chain_stop.argtypes = [vp, C.c_int]
-    _lib = L
+    if hooks:
+        L.vk_debug_table_entry.argtypes = [vp, u32, u32, vp]
+        L.vk_debug_field.argtypes = [vp, C.c_int, cp, cp, sz, vp]
+        L.vk_debug_scratch.argtypes = [vp, C.c_int, sz, vp, sz]
+        L.vk_debug_chain_stop.argtypes = [vp, C.c_int]
+        L.vk_debug_ring_knobs.argtypes = [vp, u32, u32, u32]
+        _hooks_lib = L
+    else:
+        _lib = L
     return L
 
 
@@ -141,8 +153,8 @@ class VkError(RuntimeError):
 class Engine:
     """One engine per GPU (vk_engine).  Raises VkError when no gfx950 device is usable."""
 
-    def __init__(self, device=0, window_bits=0, batch=0, blocks_per_cu=0, stream=None, layout=0, algo=0):
-        L = load()
+    def __init__(self, device=0, window_bits=0, batch=0, blocks_per_cu=0, stream=None, layout=0, algo=0, hooks=False):
+        L = load(hooks)     # hooks=True: the test build (vk_debug_* available); the product never asks for it
         self._L = L
         self._e = C.c_void_p()
         opts = EngineOpts(window_bits, batch, blocks_per_cu, layout, stream, algo, 0)
@@ -340,6 +352,10 @@ class Engine:
 
     def debug_chain_stop(self, stages):
         self._chk(self._L.vk_debug_chain_stop(self._e, stages))
+
+    def debug_ring_knobs(self, chunk_iters=0, waves_per_simd=0, workers=0):
+        """Launch policy of the chain ring for the following chain calls (0 = the library's choice); hooks build only."""
+        self._chk(self._L.vk_debug_ring_knobs(self._e, chunk_iters, waves_per_simd, workers))
 
     def debug_scratch(self, slot, offset, n):
         out = C.create_string_buffer(n)

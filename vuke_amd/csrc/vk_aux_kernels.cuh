@@ -5,13 +5,20 @@
 #include "vk_kernels.cuh"
 
 // ---------------------------------------------------------------- table builder
-// entry (w, d) = (d << (W*w)) * G, affine canonical; d = 0 and unrepresentable entries = 0.
+// entry (w, d) = (d << off_w) * G, affine canonical; d = 0 and unrepresentable entries = 0.
 //
-// Two phases so that even a 2^26-entry-per-window table (43 GB) builds in a fraction of a second:
-//   seed     the 2^h "low" multiples d = j and the 2^(W-h) "high" multiples d = i << h of every
-//            window, each by a generic double-and-add (a few 10^4 scalar multiplications);
-//   combine  every other entry is T[i << h] + T[j]: one affine + affine addition, eight of them
-//            per lane sharing one field inversion (Montgomery's trick).
+// Two phases, ONE launch each for all windows, so that even the 120 GB nine-window table builds in a fraction of a second:
+//   seed     the 2^h "low" multiples d = j and the 2^(tb-h) "high" multiples d = i << h of every window, each by a generic
+//            double-and-add (a few 10^4 scalar multiplications per window; windows below 2^12 entries are seeded whole);
+//   combine  every other entry is T[i << h] + T[j]: one affine + affine addition (2M + 1S) under a shared inversion
+//            (Montgomery's trick, 3M per entry + one fe_inv per RUN).  A wave owns 64 consecutive low digits j -- one per
+//            lane, (xj, yj) stay in registers -- and walks a run of K consecutive high digits i, which are wave-uniform:
+//            every store of a step is 64 consecutive entries = 4 KB, the high multiple is one broadcast line.  The K
+//            running products of a lane are parked in the engine's batch-inversion workspace as [wave][k][half][lane]
+//            uint4 rows (coalesced 1 KB rows; 64 B of workspace traffic per entry next to the 64 B of the entry itself),
+//            so the run length is not bounded by registers: K = 256 puts the inversion at ~1 multiplication per entry.
+//            Rounds 1-3 kept the products in registers (one lane = one high digit x 16 low digits): 298 VGPRs + 42 AGPR
+//            spills, one fe_inv per 16 entries = 3/4 of the kernel's multiplications, 253 ms for the 120 GB table.
 VK_DEV bool table_scalar(u32 s[8], u32 d, u32 shift, bool allow_2p256 = false)
 {
     const u32 dbits = 32 - __builtin_clz(d | 1u);
@@ -46,10 +53,24 @@ VK_DEV void table_store(uint4 *dst, const fe &x, const fe &y)
     dst[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
 }
 
-// seed phase for one window (`win` -> its entry 0, scalar shift `off`, `tb` index bits): the 2^h low
-// digits, the 2^(tb-h) high digits i << h, and (with_max) the single entry 2^tb.
-__global__ void __launch_bounds__(VK_BLOCK) vk_table_seed_kernel(uint4 *win, u32 off, u32 tb, u32 h, u32 with_max)
+// what the two builder kernels know about a window: where its entry 0 lives, its scalar shift, its index bits, the split h
+// (low digits: h bits) and the first work item of the combine phase that belongs to it
+struct vk_tbl_win {
+    u64 base;
+    u32 off, tb, h, first_item;
+};
+struct vk_tbl_jobs {
+    u32 nwin, with_max; // with_max: every window also holds the single entry 2^tb (signed layouts)
+    u32 K, items;       // combine phase: run length (power of two, <= 2^(tb-h) of every combined window), work items in all
+    vk_tbl_win w[VK_MAX_WIN];
+};
+
+// seed phase, blockIdx.y = window: the 2^h low digits, the 2^(tb-h) high digits i << h, and (with_max) the single entry 2^tb.
+__global__ void __launch_bounds__(VK_BLOCK) vk_table_seed_kernel(uint4 *table, vk_tbl_jobs jobs)
 {
+    const vk_tbl_win &wd = jobs.w[blockIdx.y];
+    uint4 *win = table + wd.base * 4;
+    const u32 tb = wd.tb, h = wd.h, off = wd.off, with_max = jobs.with_max;
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
     const u32 nlo = 1u << h, nhi = 1u << (tb - h);
     if (idx >= (u64)nlo + nhi + with_max) return;
@@ -72,68 +93,92 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_table_seed_kernel(uint4 *win, u32
     table_store(dst, x, y);
 }
 
-#define VK_TBL_K 16
-// combine phase for one window: one lane = one high digit i >= 1 and VK_TBL_K consecutive low digits
-__global__ void __launch_bounds__(VK_BLOCK) vk_table_combine_kernel(uint4 *win, u32 off, u32 tb, u32 h)
+// combine phase, persistent waves striding over the work items of all windows: item = (window, block of 64 low digits, run
+// of K high digits).  `ws` holds K x 2 rows of 64 uint4 per wave of the grid.
+__global__ void __launch_bounds__(VK_BLOCK) vk_table_combine_kernel(uint4 *table, vk_tbl_jobs jobs, uint4 *ws)
 {
-    const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
-    const u32 nlo = 1u << h, nhi = 1u << (tb - h), runs = nlo / VK_TBL_K;
-    if (idx >= (u64)nhi * runs) return;
-    const u32 run = (u32)(idx % runs), i = (u32)(idx / runs);
-    if (i == 0) return; // those are the seeded low multiples themselves
-    const u32 hi_d = i << h;
-    // digits whose scalar does not fit 256 bits are never looked up: leave them zero
-    u32 tmp[8];
-    const bool hi_ok = table_scalar(tmp, hi_d, off);
-    fe xi, yi;
-    table_load(xi, yi, win + (u64)hi_d * 4);
-    fe c[VK_TBL_K]; // running products of the x differences
+    const u32 lane = threadIdx.x & 63u;
+    const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * VK_BLOCK + threadIdx.x) >> 6);
+    const u32 nwaves = gridDim.x * (VK_BLOCK / 64);
+    const u32 K = jobs.K;
+    uint4 *my = ws + (u64)wave * K * 128 + lane;
     fe one;
     fe_set_one(one);
-#pragma unroll
-    for (int k = 0; k < VK_TBL_K; k++) {
-        const u32 j = run * VK_TBL_K + k;
-        fe xj, yj, dx;
+#pragma unroll 1
+    for (u32 item = wave; item < jobs.items; item += nwaves) {
+        u32 wi = 0;
+#pragma unroll 1
+        for (u32 t = 1; t < jobs.nwin; t++)
+            if (jobs.w[t].first_item <= item) wi = t; // first_item is non-decreasing; windows without items repeat their successor's
+        const vk_tbl_win &wd = jobs.w[wi];
+        const u32 h = wd.h, off = wd.off;
+        const u32 rel = item - wd.first_item, jblocks = (1u << h) >> 6;
+        const u32 jb = rel % jblocks, i0 = (rel / jblocks) * K;
+        uint4 *win = table + wd.base * 4;
+        const u32 j = (jb << 6) + lane;
+        fe xj, yj;
         table_load(xj, yj, win + (u64)j * 4);
-        fe_sub(dx, xj, xi);
-        if (j == 0 || !hi_ok) dx = one;
-        if (k == 0) c[0] = dx;
-        else fe_mul(c[k], c[k - 1], dx);
-    }
-    fe inv;
-    fe_inv(inv, c[VK_TBL_K - 1]);
-#pragma unroll
-    for (int k = VK_TBL_K - 1; k >= 0; k--) {
-        const u32 j = run * VK_TBL_K + k;
-        fe xj, yj, dx, dinv;
-        table_load(xj, yj, win + (u64)j * 4);
-        fe_sub(dx, xj, xi);
-        if (j == 0 || !hi_ok) dx = one;
-        if (k > 0) {
-            fe_mul(dinv, inv, c[k - 1]);
-            fe_mul(inv, inv, dx);
-        } else {
-            dinv = inv;
+        fe c = one;
+        // forward: running products of the x differences, parked row by row
+#pragma unroll 1
+        for (u32 k = 0; k < K; k++) {
+            const u32 i = i0 + k, hi_d = i << h;
+            u32 tmp[8];
+            const bool live = i != 0 && table_scalar(tmp, hi_d, off); // wave-uniform
+            if (live) {
+                const uint4 *src = win + (u64)hi_d * 4;
+                const uint4 a = src[0], b = src[1];
+                fe xi, dx;
+                xi.v[0] = a.x; xi.v[1] = a.y; xi.v[2] = a.z; xi.v[3] = a.w;
+                xi.v[4] = b.x; xi.v[5] = b.y; xi.v[6] = b.z; xi.v[7] = b.w;
+                fe_sub(dx, xj, xi);
+                if (j == 0) dx = one;
+                fe_mul(c, c, dx);
+            }
+            my[(u64)k * 128] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
+            my[(u64)k * 128 + 64] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
         }
-        uint4 *dst = win + ((u64)hi_d + j) * 4;
-        if (j == 0) continue; // the seeded high multiple itself
-        if (!hi_ok) {
-            dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(0, 0, 0, 0);
-            continue;
+        fe inv;
+        fe_inv(inv, c);
+        // backward: 1 / dx of step k = inv * (product before k); the addition; the entries of the step, 4 KB per wave
+#pragma unroll 1
+        for (u32 kk = K; kk > 0; kk--) {
+            const u32 k = kk - 1, i = i0 + k, hi_d = i << h;
+            if (i == 0) continue; // the seeded low multiples themselves
+            uint4 *dst = win + ((u64)hi_d + j) * 4;
+            u32 tmp[8];
+            if (!table_scalar(tmp, hi_d, off)) { // digits whose scalar does not fit 256 bits are never looked up: zero
+                if (j != 0) dst[0] = dst[1] = dst[2] = dst[3] = make_uint4(0, 0, 0, 0);
+                continue;
+            }
+            fe xi, yi, dx, dinv;
+            table_load(xi, yi, win + (u64)hi_d * 4);
+            fe_sub(dx, xj, xi);
+            if (j == 0) dx = one;
+            if (k > 0) {
+                const uint4 a = my[(u64)(k - 1) * 128], b = my[(u64)(k - 1) * 128 + 64];
+                fe cp;
+                cp.v[0] = a.x; cp.v[1] = a.y; cp.v[2] = a.z; cp.v[3] = a.w;
+                cp.v[4] = b.x; cp.v[5] = b.y; cp.v[6] = b.z; cp.v[7] = b.w;
+                fe_mul(dinv, inv, cp);
+                fe_mul(inv, inv, dx);
+            } else {
+                dinv = inv;
+            }
+            // (xi, yi) + (xj, yj), distinct x guaranteed (distinct scalars below n, never negatives of each other)
+            fe lam, x3, y3, t;
+            fe_sub(t, yj, yi);
+            fe_mul(lam, t, dinv);
+            fe_sqr(x3, lam);
+            fe_sub(x3, x3, xi);
+            fe_sub(x3, x3, xj);
+            fe_sub(t, xi, x3);
+            fe_mul(y3, lam, t);
+            fe_sub(y3, y3, yi);
+            fe_canon(x3);
+            fe_canon(y3);
+            if (j != 0) table_store(dst, x3, y3); // j = 0 is the seeded high multiple itself
         }
-        // (xi, yi) + (xj, yj), distinct x guaranteed (distinct scalars below n, never negatives of each other)
-        fe lam, x3, y3, t;
-        fe_sub(t, yj, yi);
-        fe_mul(lam, t, dinv);
-        fe_sqr(x3, lam);
-        fe_sub(x3, x3, xi);
-        fe_sub(x3, x3, xj);
-        fe_sub(t, xi, x3);
-        fe_mul(y3, lam, t);
-        fe_sub(y3, y3, yi);
-        fe_canon(x3);
-        fe_canon(y3);
-        table_store(dst, x3, y3);
     }
 }
 
@@ -284,7 +329,8 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_strings_kernel(vk_spec_dev spec, 
     valid[idx] = ok ? 1 : 0;
 }
 
-// ---------------------------------------------------------------- field test hook
+// ---------------------------------------------------------------- field test hook (libvuke_hip_hooks.so only)
+#ifdef VK_TEST_HOOKS
 __global__ void vk_field_kernel(int op, const u32 *a, const u32 *b, u64 n, u32 *out)
 {
     const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,3 +364,4 @@ __global__ void vk_field_kernel(int op, const u32 *a, const u32 *b, u64 n, u32 *
 #pragma unroll
     for (int i = 0; i < 8; i++) out[idx * 8 + 7 - i] = bswap32(r.v[i]);
 }
+#endif // VK_TEST_HOOKS

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <mutex>
 #include <cctype>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -42,13 +43,15 @@ struct vk_engine {
     u64 *d_mb_salt = nullptr;      // PBKDF2 salt message of the multibit chain, ready-padded blocks (vk_multibit_passphrase_set; "" by default)
     u32 mb_salt_nblk = 0;
     int ring_waves_per_simd = 0;   // resident worker waves per SIMD of the chain ring (occupancy query, once)
-    int chain_stop = 99;           // vk_debug_chain_stop
+    int chain_stop = 99;           // vk_debug_chain_stop (test-hook build only; 99 = run every stage)
+    u32 dbg_ring_chunk = 0, dbg_ring_wps = 0, dbg_ring_workers = 0; // vk_debug_ring_knobs (test-hook build only; 0 = library's choice)
     double clk_cycles = 0.0, clk_ticks = 0.0; // shader-clock samples of the sweep launches of the call in progress
     u64 rescan_items = 0;          // vk_rescan_strings: keys of the last vk_scan_strings call still in scratch slots 1 / 4 (0 = gone)
     u32 rescan_slots = 0;
     u64 rescan_inputs = 0, rescan_skipped = 0;
     vk_win_desc *d_wins = nullptr; // device copy of wins (kernels that take the layout by pointer)
     double table_build_seconds = 0.0;
+    double runtime_init_seconds = 0.0, alloc_seconds = 0.0, table_wall_seconds = 0.0; // where vk_engine_create's wall time went
     u32 batch = 128;
     u32 blocks_per_cu = 0;
     uint4 *table = nullptr;
@@ -207,8 +210,14 @@ extern "C" void vk_engine_destroy(vk_engine *e)
     delete e;
 }
 
+static double wall_now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
 {
+    const double t_start = wall_now();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(e, VK_E_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (device < 0 || device >= n) return fail(e, VK_E_INVALID_ARG, "device index out of range");
@@ -284,27 +293,65 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     }
     HIPCHK(e, hipMalloc(&e->d_wins, sizeof e->wins));
     HIPCHK(e, hipMemcpy(e->d_wins, e->wins, sizeof e->wins, hipMemcpyHostToDevice));
+    const double t_runtime = wall_now(); // the HIP runtime is up (first engine of a process: ~0.25 s), the small buffers exist
+    e->runtime_init_seconds = t_runtime - t_start;
     // batch-inversion workspace for the full grid, once (a multi-GB hipMalloc inside a sweep call costs seconds);
     // run_range only grows it for specs whose slots per input exceed the batch
     e->work_bytes = (size_t)e->cu_count * e->blocks_per_cu * VK_BLOCK * e->batch * 8 * sizeof(uint4);
     HIPCHK(e, hipMalloc(&e->work, e->work_bytes));
     // the k*G table: affine points (64 B each), built on the device window by window in two phases
     HIPCHK(e, hipMalloc(&e->table, e->table_entries * 64));
-    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    const double t_alloc = wall_now(); // the two large allocations: waits for the driver's scrub of VRAM another process has just freed
+    e->alloc_seconds = t_alloc - t_runtime;
+    // one seed launch and one combine launch for all windows (vk_aux_kernels.cuh)
+    vk_tbl_jobs jobs;
+    memset(&jobs, 0, sizeof jobs);
+    jobs.nwin = e->nwin;
+    jobs.with_max = e->layout == VK_LAYOUT_SIGNED9 ? 1u : 0u;
+    u32 min_nhi = 0;
+    u64 max_seeds = 0;
     for (u32 i = 0; i < e->nwin; i++) {
         const vk_win_desc &w = e->wins[i];
-        u32 h = w.tb / 2;
-        if (h < 4) h = 4; // the combine kernel walks VK_TBL_K = 16 low digits per lane
-        const u32 with_max = e->layout == VK_LAYOUT_SIGNED9 ? 1u : 0u;
-        const u64 seeds = (1ull << h) + (1ull << (w.tb - h)) + with_max;
-        const u64 runs = (1ull << (w.tb - h)) * ((1ull << h) / VK_TBL_K);
-        uint4 *win = e->table + w.base * 4;
-        hipLaunchKernelGGL(vk_table_seed_kernel, dim3((u32)((seeds + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, win, w.off,
-                           w.tb, h, with_max);
-        HIPCHK(e, hipGetLastError());
-        hipLaunchKernelGGL(vk_table_combine_kernel, dim3((u32)((runs + VK_BLOCK - 1) / VK_BLOCK)), dim3(VK_BLOCK), 0, e->stream, win, w.off,
-                           w.tb, h);
-        HIPCHK(e, hipGetLastError());
+        vk_tbl_win &j = jobs.w[i];
+        j.base = w.base;
+        j.off = w.off;
+        j.tb = w.tb;
+        j.h = w.tb < 12 ? w.tb : w.tb / 2; // a combined window gives every wave 64 low digits: h >= 6; smaller windows are seeded whole
+        max_seeds = std::max<u64>(max_seeds, (1ull << j.h) + (1ull << (j.tb - j.h)) + jobs.with_max);
+        if (j.h < j.tb) min_nhi = min_nhi ? std::min(min_nhi, 1u << (j.tb - j.h)) : 1u << (j.tb - j.h);
+    }
+    HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    hipLaunchKernelGGL(vk_table_seed_kernel, dim3((u32)((max_seeds + VK_BLOCK - 1) / VK_BLOCK), e->nwin), dim3(VK_BLOCK), 0, e->stream, e->table, jobs);
+    HIPCHK(e, hipGetLastError());
+    if (min_nhi) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, vk_table_combine_kernel, VK_BLOCK, 0) != hipSuccess || occ < 1) occ = 1;
+        const u32 blocks = (u32)e->cu_count * (u32)std::min(occ, 4);
+        const u64 row_bytes = (u64)blocks * (VK_BLOCK / 64) * 128 * sizeof(uint4); // one step of every wave of the grid
+        u32 K = 256; // run length: the inversion costs ~270 / K multiplications per entry
+        while (K > min_nhi) K >>= 1;
+        uint4 *ws = e->work;
+        void *own_ws = nullptr;
+        if (row_bytes * K > e->work_bytes) { // an engine created with a small batch: its workspace is too small for a useful run
+            K = std::min(K, 64u);
+            HIPCHK(e, hipMalloc(&own_ws, row_bytes * K));
+            ws = (uint4 *)own_ws;
+        }
+        jobs.K = K;
+        u64 items = 0;
+        for (u32 i = 0; i < e->nwin; i++) {
+            vk_tbl_win &j = jobs.w[i];
+            j.first_item = (u32)items;
+            if (j.h < j.tb) items += (u64)((1u << j.h) >> 6) * ((1u << (j.tb - j.h)) / K);
+        }
+        jobs.items = (u32)items;
+        hipLaunchKernelGGL(vk_table_combine_kernel, dim3(blocks), dim3(VK_BLOCK), 0, e->stream, e->table, jobs, ws);
+        hipError_t lc = hipGetLastError();
+        if (own_ws) {
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipFree(own_ws);
+        }
+        HIPCHK(e, lc);
     }
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -312,6 +359,7 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
         float ms = 0.f;
         HIPCHK(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
         e->table_build_seconds = (double)ms * 1e-3;
+        e->table_wall_seconds = wall_now() - t_alloc;
     }
     return VK_OK;
 }
@@ -347,6 +395,9 @@ extern "C" int vk_engine_info(const vk_engine *e, vk_engine_info_t *out)
     out->table_bytes = e->table_entries * 64;
     out->layout = e->layout;
     out->table_build_seconds = e->table_build_seconds;
+    out->runtime_init_seconds = e->runtime_init_seconds;
+    out->alloc_seconds = e->alloc_seconds;
+    out->table_wall_seconds = e->table_wall_seconds;
     return VK_OK;
 }
 
@@ -1163,7 +1214,7 @@ template <class Body>
 static int run_ring(vk_engine *e, u32 groups, u32 iters, u32 chunk_iters, typename Body::args a)
 {
     if (groups == 0 || iters == 0) return VK_OK;
-    if (const char *v = getenv("VUKE_RING_CHUNK")) chunk_iters = std::max(1, atoi(v));
+    if (e->dbg_ring_chunk) chunk_iters = e->dbg_ring_chunk;
     const u32 chunks = (iters + chunk_iters - 1) / chunk_iters;
     if ((u64)groups * chunks >= (1ull << 32)) return fail(e, VK_E_INVALID_ARG, "too many chain chunks for one call");
     u32 nslots = 1;
@@ -1186,12 +1237,12 @@ static int run_ring(vk_engine *e, u32 groups, u32 iters, u32 chunk_iters, typena
     // 737 ms (the dispatcher doubles some CUs up and leaves others with one wave, and the doubled ones set the time) and 2 048
     // workers 93 / 639 ms (a quarter of them spin for a group at any time).
     int wps = e->ring_waves_per_simd;
-    if (const char *v = getenv("VUKE_RING_WAVES_PER_SIMD")) wps = std::max(1, std::min(wps, atoi(v)));
+    if (e->dbg_ring_wps) wps = std::min(wps, (int)e->dbg_ring_wps);
     const u32 simds = (u32)e->cu_count * 4u;
     const u32 per_simd = std::max(1u, std::min((u32)wps, groups / simds));
     u32 workers = groups < simds ? groups : simds * per_simd;
     const u32 resident = simds * (u32)wps;
-    if (const char *v = getenv("VUKE_RING_WORKERS")) workers = std::max(1u, std::min((u32)atoi(v), resident)); // experiments: may exceed groups
+    if (e->dbg_ring_workers) workers = std::min(e->dbg_ring_workers, resident); // experiments: may exceed groups
     a.iters = iters;
     a.chunk_iters = chunk_iters;
     hipLaunchKernelGGL(vk_ring_init_kernel, dim3((nslots + 255) / 256), dim3(256), 0, e->stream, ring, slots, chunk_done, groups, chunks, nslots);
@@ -1769,6 +1820,10 @@ extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
 }
 
 // ------------------------------------------------------------------------- test hooks
+// Only in libvuke_hip_hooks.so (build.sh compiles this file a second time with -DVK_TEST_HOOKS); declared in
+// include/vuke_hip_test_hooks.h.  The shipped library exports none of them.
+#ifdef VK_TEST_HOOKS
+#include "../../include/vuke_hip_test_hooks.h"
 extern "C" int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digit, uint8_t xy[64])
 {
     if (!e || !xy) return VK_E_INVALID_ARG;
@@ -1836,3 +1891,17 @@ extern "C" int vk_debug_field(vk_engine *e, int op, const uint8_t *a, const uint
     }
     return VK_OK;
 }
+
+// chunk length (iterations), resident waves per SIMD and worker waves of the chain ring for the following chain calls; 0 = the
+// library's own choice.  (Rounds 2-3 read VUKE_RING_* from the environment on every call, in the shipped library: ADVICE r3.)
+extern "C" int vk_debug_ring_knobs(vk_engine *e, uint32_t chunk_iters, uint32_t waves_per_simd, uint32_t workers)
+{
+    if (!e) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (chunk_iters > 100000 || waves_per_simd > 16 || workers > 65536) return fail(e, VK_E_INVALID_ARG, "vk_debug_ring_knobs: value out of range");
+    e->dbg_ring_chunk = chunk_iters;
+    e->dbg_ring_wps = waves_per_simd;
+    e->dbg_ring_workers = workers;
+    return VK_OK;
+}
+#endif // VK_TEST_HOOKS
