@@ -29,6 +29,9 @@ int vk_debug_field(vk_engine *e, int op /* 0 mul, 1 sqr, 2 inv, 3 add, 4 sub */,
  * iterations per visit, keeps at most `waves_per_simd` worker waves resident per SIMD and starts `workers` worker waves (which may
  * exceed the number of groups: the waiting paths of the ring).  0 = the library's own choice for that knob. */
 int vk_debug_ring_knobs(vk_engine *e, uint32_t chunk_iters, uint32_t waves_per_simd, uint32_t workers);
+/* Test hook: exclusive prefix sum (mod 2^32) of n u32 through the library's single-pass scan kernel (vk_scan.cuh), the one that
+ * places the compacted text lines / column pages of generate mode. */
+int vk_debug_scan(vk_engine *e, const uint32_t *in, size_t n, uint32_t *out);
 
 #ifdef __cplusplus
 }

@@ -96,11 +96,11 @@ int main(int argc, char **argv)
         }
         fclose(f);
     }
-    static char line[8192], a1[4096], a2[4096];
+    static char line[40000], a1[16384], a2[16384];
     char cmd[32];
     while (fgets(line, sizeof line, stdin)) {
         a1[0] = a2[0] = 0;
-        if (sscanf(line, "%31s %4095s %4095s", cmd, a1, a2) < 2) continue;
+        if (sscanf(line, "%31s %16383s %16383s", cmd, a1, a2) < 2) continue;
         const std::vector<unsigned char> x = unhex(a1), y = unhex(a2[0] ? a2 : "-");
         blockIdx.x = 0;
         threadIdx.x = 0;
@@ -167,7 +167,7 @@ int main(int argc, char **argv)
             if (!ok) continue;
             vk_electrum_body::args a = {state.data(), 0, 0};
             if (rounds > 1) run_stretch<vk_electrum_body>(a, 1, rounds - 1, 37);
-            if (ok == 2) vk_electrum_long_kernel(data.data(), offs, 1, rounds, stage.data(), state.data(), &ok);
+            if (ok == 2) vk_electrum_long_kernel(data.data(), offs, 1, rounds, state.data(), &ok);
             printf("x ");
             for (int i = 0; i < 8; i++) printf("%08x", state[64 * i]);
             printf("\n");

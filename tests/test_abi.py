@@ -42,7 +42,7 @@ def test_shipped_library_exports_no_test_hooks(built):
     -DVK_TEST_HOOKS) only: the shipped library exports none of them, the test build all of them plus the whole boundary."""
     from vuke_amd import _ffi
     hooks = declared_hooks()
-    assert hooks == sorted(_ffi.HOOK_EXPORTS) and len(hooks) == 5 and all(h.startswith("vk_debug_") for h in hooks)
+    assert hooks == sorted(_ffi.HOOK_EXPORTS) and len(hooks) == 6 and all(h.startswith("vk_debug_") for h in hooks)
     L, H = _ffi.load(), _ffi.load(hooks=True)
     for h in hooks:
         assert not hasattr(L, h), f"{h} exported by the shipped library"

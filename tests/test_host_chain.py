@@ -109,9 +109,11 @@ def electrum_stretch(seed, rounds):
 
 
 def test_electrum_prepare_stretch_and_long_seeds(emu):
+    # any length (the reference hashes the whole slice, src/electrum.rs:57-78,150-168): beyond 64 bytes the long path reads the
+    # input bytes themselves; lengths around every block boundary of x || seed || padding, and past the 448 bytes of rounds 2-3
     seeds = [b"", b"0", b"7f", b"abc", b"f" * 22, b"f" * 23, b"f" * 24, b"0123456789abcdefABCDEF0123456789", b"a" * 55, b"b" * 63, b"c" * 64,
-             b"d" * 65, b"e" * 87, b"1" * 88, b"2" * 300, b"3" * 448]
-    out = emu([f"electrum {hx(s)} 150" for s in seeds] + ["electrum " + hx(b"xyz") + " 3", "electrum " + hx(b"4" * 449) + " 3", f"electrum {hx(b'5' * 32)} 1"])
+             b"d" * 65, b"e" * 87, b"1" * 88, b"2" * 300, b"3" * 448, b"4" * 449, b"5" * 535, b"6" * 536, b"7" * 1000, b"89abcdef" * 400]
+    out = emu([f"electrum {hx(s)} 150" for s in seeds] + ["electrum " + hx(b"xyz") + " 3", "electrum " + hx(b"4" * 500 + b"g") + " 3", f"electrum {hx(b'5' * 32)} 1"])
     for i, s in enumerate(seeds):
         assert out[2 * i] == ("ok 1" if len(s) <= 64 else "ok 2"), s
         assert out[2 * i + 1] == "x " + electrum_stretch(s, 150).hex(), s

@@ -1,0 +1,37 @@
+"""A/B of sweep-kernel variants on the bench geometry (VUKE_HIP_LIB selects the library): kernel time and wall time per 2^28-key
+block of config 2 (Milksad, compressed) and per 2^25-input block of config 3 (sha256, both hash160s, 1 M-slot probe table),
+after one untimed block (a variant may size its workspace on first use).  Digests are printed so that two variants can be
+compared: they must be equal.
+
+    VUKE_HIP_LIB=vuke_amd/lib/variants/libvuke_hip_split.so python3 tools/probe_split.py [blocks=4]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vuke_amd
+from vuke_amd import _ffi as ffi
+import bench_workloads as wl
+
+blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+eng = vuke_amd.Engine(0, layout=1, batch=256, blocks_per_cu=2)
+tag = os.path.basename(os.environ.get("VUKE_HIP_LIB", "shipped"))
+for name, spec, flags, log2, per in (("c2 milksad", ffi.spec(ffi.T_MILKSAD), 1, 28, 1), ("c3 sha256", ffi.spec(ffi.T_SHA256), 3, 25, 3)):
+    if name.startswith("c3"):
+        h, k = zip(*wl.c3_decoys())
+        eng.targets_set(list(h), list(k))
+    n = 1 << log2
+    eng.sweep(spec, 0, n - 1, flags=flags)
+    ks = wall = 0.0
+    keys = 0
+    dg = None
+    for b in range(1, blocks + 1):
+        t = time.perf_counter()
+        st, _ = eng.sweep(spec, b * n, (b + 1) * n - 1, flags=flags)
+        wall += time.perf_counter() - t
+        ks += st["kernel_seconds"]
+        keys += st["keys"]
+        dg = st["digest"]
+    print(f"{tag:32s} {name}: {keys / wall / 1e9:.4f} G keys/s wall, {keys / ks / 1e9:.4f} G keys/s kernel, {1e3 * wall / blocks:.2f} ms/block, "
+          f"clock {st['shader_clock_ghz']:.3f} GHz, last digest {dg[0]:016x}", flush=True)
+eng.close()

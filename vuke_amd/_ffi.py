@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvuke_hip.so")
-LIB_PATH = os.environ.get("VUKE_HIP_LIB", LIB_PATH)  # A/B runs of two builds of the same library (tools/), nothing else
+LIB_PATH = os.environ.get("VUKE_HIP_LIB") or LIB_PATH  # A/B runs of two builds of the same library (tools/), nothing else
 HOOKS_LIB_PATH = LIB_PATH[:-3] + "_hooks.so"          # the same sources built with -DVK_TEST_HOOKS (include/vuke_hip_test_hooks.h): tests / tools only
 
 VK_OK = 0
@@ -77,7 +77,7 @@ EXPORTS = [
     "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_scan_strings", "vk_rescan_strings", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
     "vk_slots_per_input", "vk_slots_per_string",
 ]
-HOOK_EXPORTS = ["vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop", "vk_debug_ring_knobs"]
+HOOK_EXPORTS = ["vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop", "vk_debug_ring_knobs", "vk_debug_scan"]
 
 _lib = None
 _hooks_lib = None
@@ -138,6 +138,7 @@ def load(hooks=False):
         L.vk_debug_scratch.argtypes = [vp, C.c_int, sz, vp, sz]
         L.vk_debug_chain_stop.argtypes = [vp, C.c_int]
         L.vk_debug_ring_knobs.argtypes = [vp, u32, u32, u32]
+        L.vk_debug_scan.argtypes = [vp, vp, sz, vp]
         _hooks_lib = L
     else:
         _lib = L
@@ -352,6 +353,14 @@ class Engine:
 
     def debug_chain_stop(self, stages):
         self._chk(self._L.vk_debug_chain_stop(self._e, stages))
+
+    def debug_scan(self, values):
+        """Exclusive prefix sum mod 2^32 of a numpy uint32 array through vk_scan_kernel; hooks build only."""
+        import numpy as np
+        a = np.ascontiguousarray(values, dtype=np.uint32)
+        out = np.empty_like(a)
+        self._chk(self._L.vk_debug_scan(self._e, a.ctypes.data, a.size, out.ctypes.data))
+        return out
 
     def debug_ring_knobs(self, chunk_iters=0, waves_per_simd=0, workers=0):
         """Launch policy of the chain ring for the following chain calls (0 = the library's choice); hooks build only."""

@@ -153,51 +153,13 @@ VK_DEV void fe_cond_negate(fe &y, bool neg)
     }
 }
 
-// ---- quad-cooperative table reads ------------------------------------------------------------------------------
+// ---- quad-cooperative table reads landing in LDS directly (global_load_lds_dwordx4) ----------------------------------
 // A lane reading its own 64-byte entry with four 16-byte loads makes every load instruction touch 64 different lines;
 // the per-CU L1 miss path then sustains only ~19 G entries/s chip-wide (tools/gather_bench.hip).  Here the four lanes of
-// a quad read one whole entry per instruction (16 lines per instruction, ~50 G entries/s) and hand the quarters to
-// their owner through a per-wave LDS tile.  Every lane of the wave must take part (no divergence around these calls).
-struct quad_regs {
-    u32 r[16]; // quarter (lane & 3) of the entries of quad lanes 0..3, four words each (plain words: stays in VGPRs across the loop)
-};
-VK_DEV void quad_put(quad_regs &v, int i, const uint4 &t)
-{
-    v.r[4 * i] = t.x; v.r[4 * i + 1] = t.y; v.r[4 * i + 2] = t.z; v.r[4 * i + 3] = t.w;
-}
-VK_DEV uint4 quad_get(const quad_regs &v, int i) { return make_uint4(v.r[4 * i], v.r[4 * i + 1], v.r[4 * i + 2], v.r[4 * i + 3]); }
-VK_DEV void quad_gather_issue(quad_regs &v, const uint4 *__restrict__ table, u64 entry)
-{
-    const u32 lo = (u32)entry, hi = (u32)(entry >> 32);
-    const u32 q = threadIdx.x & 3u;
-    const u32 l0 = __builtin_amdgcn_update_dpp(0u, lo, 0x00, 0xF, 0xF, false), h0 = __builtin_amdgcn_update_dpp(0u, hi, 0x00, 0xF, 0xF, false);
-    const u32 l1 = __builtin_amdgcn_update_dpp(0u, lo, 0x55, 0xF, 0xF, false), h1 = __builtin_amdgcn_update_dpp(0u, hi, 0x55, 0xF, 0xF, false);
-    const u32 l2 = __builtin_amdgcn_update_dpp(0u, lo, 0xAA, 0xF, 0xF, false), h2 = __builtin_amdgcn_update_dpp(0u, hi, 0xAA, 0xF, 0xF, false);
-    const u32 l3 = __builtin_amdgcn_update_dpp(0u, lo, 0xFF, 0xF, 0xF, false), h3 = __builtin_amdgcn_update_dpp(0u, hi, 0xFF, 0xF, 0xF, false);
-    quad_put(v, 0, table[((((u64)h0 << 32) | l0) << 2) + q]);
-    quad_put(v, 1, table[((((u64)h1 << 32) | l1) << 2) + q]);
-    quad_put(v, 2, table[((((u64)h2 << 32) | l2) << 2) + q]);
-    quad_put(v, 3, table[((((u64)h3 << 32) | l3) << 2) + q]);
-}
-// tile = this wave's 64 x 5 uint4 of LDS: entry slots of 80 bytes (64 + 16 of padding) so that neither the quarter
-// writes nor the whole-entry reads of sixteen consecutive lanes share a bank
-#define VK_GTILE_STRIDE 5
-VK_DEV void quad_gather_commit(fe &x, fe &y, const quad_regs &v, uint4 *tile)
-{
-    const u32 lane = threadIdx.x & 63u, base = lane & ~3u, q = lane & 3u;
-    tile[(base + 0) * VK_GTILE_STRIDE + q] = quad_get(v, 0);
-    tile[(base + 1) * VK_GTILE_STRIDE + q] = quad_get(v, 1);
-    tile[(base + 2) * VK_GTILE_STRIDE + q] = quad_get(v, 2);
-    tile[(base + 3) * VK_GTILE_STRIDE + q] = quad_get(v, 3);
-    const uint4 a = tile[lane * VK_GTILE_STRIDE + 0], b = tile[lane * VK_GTILE_STRIDE + 1], c = tile[lane * VK_GTILE_STRIDE + 2],
-                d = tile[lane * VK_GTILE_STRIDE + 3];
-    x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
-    x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
-    y.v[0] = c.x; y.v[1] = c.y; y.v[2] = c.z; y.v[3] = c.w;
-    y.v[4] = d.x; y.v[5] = d.y; y.v[6] = d.z; y.v[7] = d.w;
-}
-
-// ---- the same reads landing in LDS directly (global_load_lds_dwordx4) ------------------------------------------------
+// a quad read one whole entry per instruction (16 lines per instruction, ~50 G entries/s), and the load unit hands the
+// quarters to their owner through the wave's LDS slot.  Every lane of the wave must take part (no divergence around
+// these calls).  (The per-lane and the register-staged forms of the sweep's table read, and its Jacobian accumulator,
+// were A/B variants until round 3: profiles/r01_table_read_experiments.txt; last in the sources at commit 4b24351.)
 // No staging registers: the load unit writes lane i's 16 bytes to slot + 16 i.  Round r of a whole-entry read fetches,
 // in lane L, quarter L & 3 of the entry owned by quad lane r; the owner then finds its 64 bytes contiguous in round
 // (lane & 3) at lanes (lane & ~3) .. +3.  The x-only read does the same with lane pairs and halves of x.  A round is 65
@@ -207,7 +169,6 @@ VK_DEV void quad_gather_commit(fe &x, fe &y, const quad_regs &v, uint4 *tile)
 // (lds_gather_reuse_fence).
 #define VK_LTILE_ROUND 65
 #define VK_LTILE_FULL (4 * VK_LTILE_ROUND) /* uint4 per whole-entry slot */
-#define VK_LTILE_X (2 * VK_LTILE_ROUND)    /* uint4 per x-only slot */
 typedef const void __attribute__((address_space(1))) *vk_gptr;
 typedef void __attribute__((address_space(3))) *vk_lptr;
 VK_DEV void lds_gather_reuse_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -235,62 +196,6 @@ VK_DEV void lds_gather_read(fe &x, fe &y, const uint4 *slot)
     x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
     y.v[0] = c.x; y.v[1] = c.y; y.v[2] = c.z; y.v[3] = c.w;
     y.v[4] = d.x; y.v[5] = d.y; y.v[6] = d.z; y.v[7] = d.w;
-}
-VK_DEV void lds_gather_issue_x(uint4 *slot, const uint4 *__restrict__ table, u32 entry)
-{
-    const u32 h = threadIdx.x & 1u;
-    const u32 e0 = __builtin_amdgcn_update_dpp(0u, entry, 0xA0, 0xF, 0xF, false); // quad_perm [0, 0, 2, 2]
-    const u32 e1 = __builtin_amdgcn_update_dpp(0u, entry, 0xF5, 0xF, 0xF, false); // quad_perm [1, 1, 3, 3]
-    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e0 << 2) + h), (vk_lptr)(slot + 0 * VK_LTILE_ROUND), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e1 << 2) + h), (vk_lptr)(slot + 1 * VK_LTILE_ROUND), 16, 0, 0);
-}
-VK_DEV void lds_gather_read_x(fe &x, const uint4 *slot)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const u32 lane = threadIdx.x & 63u;
-    const uint4 *m = slot + (lane & 1u) * VK_LTILE_ROUND + (lane & ~1u);
-    const uint4 a = m[0], b = m[1];
-    x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w;
-    x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
-}
-
-// ecmult_table with cooperative reads: the whole wave calls it (lanes without a key pass k = 1)
-VK_DEV void ecmult_table_coop(jac &acc, const u32 k[8], const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin, uint4 *tile)
-{
-    bool inf = true, zone = false;
-    fe_set_zero(acc.x);
-    fe_set_zero(acc.y);
-    fe_set_one(acc.z);
-    u32 carry = 0;
-    bool neg;
-    u32 d = window_digit(k, wins[0], carry, neg);
-    quad_regs v;
-    quad_gather_issue(v, table, wins[0].base + d);
-#pragma unroll 1
-    for (u32 w = 0; w < nwin; w++) {
-        fe cx, cy;
-        quad_gather_commit(cx, cy, v, tile);
-        const u32 cd = d;
-        const bool cneg = neg;
-        if (w + 1 < nwin) {
-            d = window_digit(k, wins[w + 1], carry, neg);
-            quad_gather_issue(v, table, wins[w + 1].base + d);
-        }
-        if (cd != 0) {
-            fe_cond_negate(cy, cneg);
-            if (inf) {
-                acc.x = cx;
-                acc.y = cy;
-                inf = false;
-                zone = true;
-            } else if (zone) {
-                jac_aadd(acc, acc.x, acc.y, cx, cy);
-                zone = false;
-            } else {
-                jac_madd(acc, acc, cx, cy);
-            }
-        }
-    }
 }
 
 // acc = k*G, k in [1, n).  Returns Jacobian (z = 1 possible).
@@ -372,60 +277,6 @@ VK_DEV void jac_to_affine(fe &x, fe &y, const jac &p, const fe &zinv)
     fe_canon(y);
 }
 
-// ecmult_table with the reads landing in LDS directly (the whole wave calls it; lanes without a key pass k = 1).
-// VK_LDS_DEPTH reads are in flight per lane: slots = this wave's VK_LDS_DEPTH x VK_LTILE_FULL uint4, used as a ring.
-#ifndef VK_LDS_DEPTH
-#define VK_LDS_DEPTH 1 /* power of two; 2 and 4 measured 0.4 % slower than 1: the latency is covered, the gain is the cheaper miss path */
-#endif
-VK_DEV void ecmult_table_lds(jac &acc, const u32 k[8], const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin, uint4 *slots)
-{
-    bool inf = true, zone = false;
-    fe_set_zero(acc.x);
-    fe_set_zero(acc.y);
-    fe_set_one(acc.z);
-    u32 carry = 0;
-    u32 dq[VK_LDS_DEPTH];
-    bool nq[VK_LDS_DEPTH];
-    lds_gather_reuse_fence();
-#pragma unroll
-    for (u32 i = 0; i < VK_LDS_DEPTH; i++) { // nwin >= VK_LDS_DEPTH for every layout
-        dq[i] = window_digit(k, wins[i], carry, nq[i]);
-        lds_gather_issue(slots + i * VK_LTILE_FULL, table, (u32)(wins[i].base + dq[i]));
-    }
-#pragma unroll 1
-    for (u32 w = 0; w < nwin; w++) {
-        uint4 *slot = slots + (w & (VK_LDS_DEPTH - 1)) * VK_LTILE_FULL;
-        fe cx, cy;
-        lds_gather_read(cx, cy, slot);
-        const u32 cd = dq[0];
-        const bool cneg = nq[0];
-#pragma unroll
-        for (u32 i = 0; i + 1 < VK_LDS_DEPTH; i++) {
-            dq[i] = dq[i + 1];
-            nq[i] = nq[i + 1];
-        }
-        if (w + VK_LDS_DEPTH < nwin) {
-            dq[VK_LDS_DEPTH - 1] = window_digit(k, wins[w + VK_LDS_DEPTH], carry, nq[VK_LDS_DEPTH - 1]);
-            lds_gather_reuse_fence();
-            lds_gather_issue(slot, table, (u32)(wins[w + VK_LDS_DEPTH].base + dq[VK_LDS_DEPTH - 1]));
-        }
-        if (cd != 0) {
-            fe_cond_negate(cy, cneg);
-            if (inf) {
-                acc.x = cx;
-                acc.y = cy;
-                inf = false;
-                zone = true;
-            } else if (zone) {
-                jac_aadd(acc, acc.x, acc.y, cx, cy);
-                zone = false;
-            } else {
-                jac_madd(acc, acc, cx, cy);
-            }
-        }
-    }
-}
-
 // ---- the sweep's accumulator in XYZZ coordinates ---------------------------------------------------------------------
 // (X, Y, ZZ, ZZZ) with x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2.  Adding an affine point costs 8M + 2S instead of the
 // 8M + 3S of the Jacobian mixed addition (no Z^2 to recompute: "madd-2008-s").  Leaving the chain costs the same as
@@ -472,7 +323,11 @@ VK_DEV void xyzz_aadd(xyzz &r, const fe &qx, const fe &qy)
     fe_sub(r.y, q, yp);
     r.x = t;
 }
-// ecmult_table_lds with the XYZZ accumulator
+// ecmult_table with the reads landing in LDS directly and the XYZZ accumulator (the whole wave calls it; lanes without a key
+// pass k = 1).  VK_LDS_DEPTH reads are in flight per lane: slots = this wave's VK_LDS_DEPTH x VK_LTILE_FULL uint4, used as a ring.
+#ifndef VK_LDS_DEPTH
+#define VK_LDS_DEPTH 1 /* power of two; 2 and 4 measured 0.4 % slower than 1: the latency is covered, the gain is the cheaper miss path */
+#endif
 VK_DEV void ecmult_table_lds_xyzz(xyzz &acc, const u32 k[8], const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin, uint4 *slots)
 {
     bool inf = true, zone = false;

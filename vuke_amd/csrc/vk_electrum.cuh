@@ -11,14 +11,30 @@
 //
 //   vk_electrum_prepare_kernel  hex check, x0, the constant tail of the stretch message (seed, padding, length)   (cold)
 //   vk_ring_kernel<electrum>    99 999 rounds in chunks: only the 8 chaining words change, the tail stays in registers (hot)
-//   vk_electrum_long_kernel     the same rounds for seeds of 65 .. 448 bytes (the reference accepts any length; such lines
-//                               are rare): tail words read from the staging slice every round, one lane per seed      (cold)
+//   vk_electrum_long_kernel     the same rounds for seeds of more than 64 bytes -- ANY length, as the reference hashes the whole
+//                               slice (src/electrum.rs:57-78,150-168); such lines are rare: tail words read from the caller's
+//                               input bytes every round, one lane per seed (ceil((41 + len) / 64) compressions per round)   (cold)
 //   vk_electrum_final_kernel    master * G, 20 sequence hashes, child keys                                         (cold, vk_chain_keys.cuh)
 #pragma once
 #include "vk_chain.cuh"
 
 #define VK_ELECTRUM_FAST_SEED 64 /* bytes: x || seed || padding then spans at most two SHA-256 blocks (register-resident tail) */
-#define VK_ELECTRUM_MAX_SEED 448 /* bytes: the staging slice minus padding */
+
+// big-endian word i of seed || 0x80 || 0.. || 64-bit bit length of (prefix + len) bytes, read from the input bytes themselves
+// (any length, any alignment); `last` = index of the low word of the length field
+VK_DEV u32 electrum_tail_word_bytes(const unsigned char *__restrict__ seed, u32 i, u32 len, u32 last, u32 prefix)
+{
+    u32 v = 0;
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        const u32 k = 4 * i + j;
+        const u32 byte = k < len ? seed[k] : (k == len ? 0x80u : 0u);
+        v = (v << 8) | byte;
+    }
+    if (i == last) v |= (prefix + len) << 3;
+    if (i + 1 == last) v |= (prefix + len) >> 29;
+    return v;
+}
 
 // big-endian word i of the constant tail seed || 0x80 || 0.. || bit length of (32 + len) bytes; `last` = index of the length word
 VK_DEV u32 electrum_tail_word(const u64 *stage, u32 i, u32 len, u32 last)
@@ -41,16 +57,16 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_electrum_prepare_kernel(const uns
     if (idx >= n) return;
     ok_out[idx] = 0;
     const u32 len = offs[idx + 1] - offs[idx];
-    if (len > VK_ELECTRUM_MAX_SEED) return;
     const unsigned char *seed = data + offs[idx];
     u64 *stage = stage_all + idx * VK_STAGE_WORDS;
+    const bool fast = len <= VK_ELECTRUM_FAST_SEED; // only the register-resident path reads the seed back from the staging slice
     vk_stage_writer wr;
     wr.init(stage);
     bool ok = true;
     for (u32 i = 0; i < len; i++) {
         const unsigned char c = seed[i];
         ok = ok && ((c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F')); // is_ascii_hexdigit
-        wr.put(c, 1);
+        if (fast) wr.put(c, 1);
     }
     wr.finish();
     if (!ok) return;
@@ -69,7 +85,8 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_electrum_prepare_kernel(const uns
                     const u32 byte = k < mlen ? seed[k < len ? k : k - len] : (k == mlen ? 0x80u : 0u);
                     v = (v << 8) | byte;
                 }
-                if (16 * b + i == 16 * nblk - 1) v |= mlen * 8;
+                if (16 * b + i == 16 * nblk - 1) v |= mlen << 3;
+                if (16 * b + i == 16 * nblk - 2) v |= mlen >> 29;
                 w[i] = v;
             }
             sha256_compress(x, w);
@@ -133,16 +150,16 @@ struct vk_electrum_body {
     }
 };
 
-// Seeds of 65 .. 448 bytes: x0 is in the state (the ring has meanwhile stretched it with a wrong tail: recomputed from the
-// staged seed here).  One lane per such seed, all rounds in one go; launched only when the host saw one.
+// Seeds of more than 64 bytes, any length: x0 is in the state (the ring has meanwhile stretched it with a wrong tail: recomputed
+// from the input here).  One lane per such seed, all rounds in one go, every message word assembled from the caller's input bytes
+// (no staging slice: no length limit); launched only when the host saw one.
 __global__ void __launch_bounds__(VK_BLOCK) vk_electrum_long_kernel(const unsigned char *__restrict__ data, const u32 *__restrict__ offs, u64 n, u32 rounds,
-                                                                      const u64 *__restrict__ stage_all, u32 *__restrict__ state, unsigned char *__restrict__ ok)
+                                                                      u32 *__restrict__ state, unsigned char *__restrict__ ok)
 {
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
     if (idx >= n || ok[idx] != 2) return;
     const u32 len = offs[idx + 1] - offs[idx];
     const unsigned char *seed = data + offs[idx];
-    const u64 *stage = stage_all + idx * VK_STAGE_WORDS;
     u32 x[8] = VK_SHA256_IV;
     { // x0 again (the state's copy was advanced by the ring)
         const u32 mlen = 2 * len, nb0 = (mlen + 9 + 63) / 64;
@@ -157,7 +174,8 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_electrum_long_kernel(const unsign
                     const u32 byte = k < mlen ? seed[k < len ? k : k - len] : (k == mlen ? 0x80u : 0u);
                     v = (v << 8) | byte;
                 }
-                if (16 * b + i == 16 * nb0 - 1) v |= mlen * 8;
+                if (16 * b + i == 16 * nb0 - 1) v |= mlen << 3;
+                if (16 * b + i == 16 * nb0 - 2) v |= mlen >> 29;
                 w[i] = v;
             }
             sha256_compress(x, w);
@@ -173,7 +191,7 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_electrum_long_kernel(const unsign
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 if (b == 0 && i < 8) w[i] = x[i];
-                else w[i] = electrum_tail_word(stage, 16 * b + i - 8, len, last);
+                else w[i] = electrum_tail_word_bytes(seed, 16 * b + i - 8, len, last, 32u);
             }
             sha256_compress(st, w);
         }

@@ -11,7 +11,7 @@
 #include "vk_search.cuh"
 #include "vk_lines.cuh"
 #include "vk_records.cuh"
-#include <hipcub/hipcub.hpp>
+#include "vk_scan.cuh"
 
 #include <algorithm>
 #include <cstdio>
@@ -111,6 +111,18 @@ static void *scratch(vk_engine *e, int i, size_t bytes)
             return VK_E_HIP;                                                                        \
         }                                                                                           \
     } while (0)
+
+// exclusive prefix sum of n u32 on the engine's stream (vk_scan.cuh); temp = scan_temp_bytes(n) bytes of device memory
+static size_t scan_temp_bytes(u64 n) { return (size_t)(1 + (n + VK_SCAN_TILE - 1) / VK_SCAN_TILE) * sizeof(unsigned long long); }
+static hipError_t exclusive_scan(vk_engine *e, void *temp, const u32 *in, u32 *out, u64 n)
+{
+    if (n == 0) return hipSuccess;
+    hipError_t c = hipMemsetAsync(temp, 0, scan_temp_bytes(n), e->stream);
+    if (c != hipSuccess) return c;
+    hipLaunchKernelGGL(vk_scan_kernel, dim3((u32)((n + VK_SCAN_TILE - 1) / VK_SCAN_TILE)), dim3(256), 0, e->stream, in, out, (u32)n, (unsigned long long *)temp);
+    return hipGetLastError();
+}
+
 
 static int fail(vk_engine *e, int code, const char *msg)
 {
@@ -577,6 +589,10 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     const u64 tile_inputs = (u64)VK_BLOCK * R;
     const u64 ntiles = span / tile_inputs + 1;
     u32 grid = (u32)std::min<u64>(ntiles, max_grid);
+    // an A/B variant whose sweep is two kernels (VK_SPLIT_PASS2) keeps every tile's items until the second kernel has read them
+    const bool split = (kind == VK_T_MILKSAD || kind == VK_T_MT64 || kind == VK_T_RAWKEYS) ? vk_sweep_split_g0()
+                       : (kind == VK_T_LCG || kind == VK_T_XORSHIFT)                      ? vk_sweep_split_g2()
+                                                                                           : vk_sweep_split_g1();
     // The workspace is one slice of B items per resident workgroup.  B >= slots, and slots grows with the chain depth of
     // sha256_chain (up to 8 * 4096): keep the allocation under 16 GiB by launching fewer workgroups (the tile counter hands
     // the same tiles to a smaller grid), and say what is wrong if even one workgroup does not fit.
@@ -592,7 +608,7 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
         }
         grid = (u32)std::min<size_t>(grid, fit);
     }
-    const size_t need = (size_t)grid * per_wg;
+    const size_t need = (split ? (size_t)ntiles : (size_t)grid) * per_wg;
     if (need > e->work_bytes) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         if (e->work) HIPCHK(e, hipFree(e->work));
@@ -628,6 +644,7 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     p.R = R;
     p.flags = flags;
     p.nwin = e->nwin;
+    p.ws_per_tile = split ? 1u : 0u;
     memcpy(p.wins, e->wins, sizeof p.wins);
     p.table = e->table;
     p.tgt = e->tgt;
@@ -826,9 +843,7 @@ static int generate_text(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
     SCRATCH(e, d_hu, u32 *, 3, verbose ? items * 20 : 4);
     SCRATCH(e, d_valid, unsigned char *, 4, items);
     SCRATCH(e, d_slots, u64 *, 6, items * stride);
-    size_t temp_bytes = 0;
-    u32 *null32 = nullptr;
-    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, null32, null32, (int)items, e->stream));
+    const size_t temp_bytes = scan_temp_bytes(items);
     const size_t off_lens = 0, off_offs = (items + 1) * 4, off_temp = ((off_offs + (items + 1) * 4 + 255) / 256) * 256;
     SCRATCH(e, d_scan, unsigned char *, 7, off_temp + temp_bytes);
     u32 *d_lens = (u32 *)(d_scan + off_lens), *d_offs32 = (u32 *)(d_scan + off_offs);
@@ -852,7 +867,7 @@ static int generate_text(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
         hipLaunchKernelGGL(vk_lines_kernel, dim3(grid), dim3(256), 0, e->stream, (u64)lo, items, slots, d_priv, d_hc, d_valid, d_texts, (const u32 *)nullptr,
                            d_slots, d_lens);
     HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(d_scan + off_temp, temp_bytes, d_lens, d_offs32, (int)items, e->stream));
+    HIPCHK(e, exclusive_scan(e, d_scan + off_temp, d_lens, d_offs32, items));
     hipLaunchKernelGGL(vk_lines_compact_kernel, dim3((u32)((items + 63) / 64 * 64 + 255) / 256), dim3(256), 0, e->stream, items, slots, stride, d_slots, d_lens, d_offs32,
                        (const unsigned char *)nullptr, (const u32 *)nullptr, d_text);
     HIPCHK(e, hipGetLastError());
@@ -898,10 +913,8 @@ static int records_pack(vk_engine *e, u64 items, u32 slots, u64 lo, const unsign
     base[0] = 0;
     for (int c = 0; c < VK_RC_COLUMNS; c++) base[c + 1] = base[c] + (size_t)items * vk_rc_stride(c);
     SCRATCH(e, d_slots, unsigned char *, 6, base[VK_RC_COLUMNS]);
-    size_t temp_bytes = 0;
-    u32 *null32 = nullptr;
-    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, null32, null32, (int)items, e->stream));
-    // per column: items lengths; then one array of offsets (reused column after column) and hipcub's workspace
+    const size_t temp_bytes = scan_temp_bytes(items);
+    // per column: items lengths; then one array of offsets (reused column after column) and the scan's tile states
     const size_t off_offs = (size_t)VK_RC_COLUMNS * items * 4, off_temp = ((off_offs + (items + 1) * 4 + 255) / 256) * 256;
     SCRATCH(e, d_scan, unsigned char *, 7, off_temp + temp_bytes);
     SCRATCH(e, d_packed, unsigned char *, 8, base[VK_RC_COLUMNS]);
@@ -919,7 +932,7 @@ static int records_pack(vk_engine *e, u64 items, u32 slots, u64 lo, const unsign
     HIPCHK(e, hipGetLastError());
     u32 tails[2 * VK_RC_COLUMNS]; // per column: offset and length of the last item
     for (int c = 0; c < VK_RC_COLUMNS; c++) {
-        HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(d_scan + off_temp, temp_bytes, rs.lens[c], d_offs32, (int)items, e->stream));
+        HIPCHK(e, exclusive_scan(e, d_scan + off_temp, rs.lens[c], d_offs32, items));
         hipLaunchKernelGGL(vk_lines_compact_kernel, dim3((u32)((items + 63) / 64 * 64 + 255) / 256), dim3(256), 0, e->stream, items, slots, vk_rc_stride(c),
                            rs.slot[c], rs.lens[c], d_offs32, (const unsigned char *)nullptr, (const u32 *)nullptr, d_packed + base[c]);
         HIPCHK(e, hipGetLastError());
@@ -1262,22 +1275,18 @@ static int strings_to_device_keys(vk_engine *e, const vk_transform_spec *t, cons
                                   u32 **d_keys_out, unsigned char **d_valid_out, size_t *overlong, double *kernel_seconds)
 {
     const bool kdf = t->kind == VK_T_ELECTRUM || t->kind == VK_T_MULTIBIT;
-    const u32 max_len = t->kind == VK_T_MULTIBIT ? VK_MULTIBIT_MAX_MNEMONIC : kdf ? VK_ELECTRUM_MAX_SEED : 0x7FFFFFFFu;
+    // Electrum takes a seed of ANY length (src/electrum.rs:57-78 hashes the whole slice): beyond the register-resident 64 bytes
+    // a seed runs on the one-lane path that reads the caller's bytes.  MultiBit's password is the line as given and is staged in
+    // a 512-byte slice: a valid mnemonic has at most 24 words of at most 8 letters (215 bytes with single spaces), so only a line
+    // with more than ~230 redundant white-space characters BETWEEN its words (the sources trim the ends) can exceed the limit.
+    const u32 max_len = t->kind == VK_T_MULTIBIT ? VK_MULTIBIT_MAX_MNEMONIC : 0xFFFFFFFFu;
     *overlong = 0;
     size_t n_long = 0; // electrum seeds beyond the register-resident fast path
     for (size_t i = 0; i < n; i++) {
         if (offsets[i + 1] < offsets[i]) return fail(e, VK_E_INVALID_ARG, "offsets must be non-decreasing");
         const u32 len = offsets[i + 1] - offsets[i];
-        if (t->kind == VK_T_ELECTRUM && len > VK_ELECTRUM_FAST_SEED && len <= VK_ELECTRUM_MAX_SEED) n_long++;
-        if (len > max_len) {
-            // ElectrumTransform::apply_batch drops every non-hex string itself (src/transform/electrum.rs:49-52): only an
-            // over-long string of hex digits is a key the reference would have produced and this path does not
-            bool counts = true;
-            if (t->kind == VK_T_ELECTRUM) {
-                for (u32 j = 0; j < len && counts; j++) counts = isxdigit(data[offsets[i] + j]) != 0;
-            }
-            if (counts) (*overlong)++;
-        }
+        if (t->kind == VK_T_ELECTRUM && len > VK_ELECTRUM_FAST_SEED) n_long++;
+        if (len > max_len) (*overlong)++;
     }
     HIPCHK(e, hipSetDevice(e->device));
     const size_t bytes = offsets[n], items = n * slots;
@@ -1349,8 +1358,8 @@ static int strings_to_device_keys(vk_engine *e, const vk_transform_spec *t, cons
         vk_electrum_body::args a = {d_state, 0, 0};
         const int rc = run_ring<vk_electrum_body>(e, groups, 100000u - 1u, 500, a);
         if (rc) return rc;
-        if (n_long) // seeds of 65 .. 448 bytes: rare, stretched one lane each outside the ring
-            hipLaunchKernelGGL(vk_electrum_long_kernel, grid, block, 0, e->stream, d_data, d_offs, (u64)n, 100000u, d_stage, d_state, d_ok);
+        if (n_long) // seeds of more than 64 bytes: rare, stretched one lane each outside the ring
+            hipLaunchKernelGGL(vk_electrum_long_kernel, grid, block, 0, e->stream, d_data, d_offs, (u64)n, 100000u, d_state, d_ok);
         hipLaunchKernelGGL(vk_electrum_final_kernel, grid, block, 0, e->stream, (u64)n, t->variant, t->chain_depth, d_state, d_ok, d_stage, e->table, e->d_wins,
                            e->nwin, d_keys, d_valid);
     }
@@ -1373,7 +1382,7 @@ chain_done:
 static void note_overlong(vk_engine *e, const vk_transform_spec *t, size_t overlong)
 {
     (void)t;
-    if (overlong) e->warn = "warning: " + std::to_string(overlong) + " input string(s) longer than the device limit (448 bytes) produced no keys";
+    if (overlong) e->warn = "warning: " + std::to_string(overlong) + " multibit line(s) longer than the device limit (448 bytes) produced no keys";
 }
 
 extern "C" size_t vk_last_warning(vk_engine *e, char *buf, size_t cap)
@@ -1523,6 +1532,11 @@ extern "C" int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *
     if ((u64)n * slots > VK_LINES_MAX_ITEMS) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines_strings: at most 2^21 (input, slot) pairs per call");
     const u64 items = (u64)n * slots;
     const uint32_t *lab_offs = label_offsets ? label_offsets : offsets; // what a line starts with: the caller's label or the input itself
+    // both offset arrays are checked before anything is computed from them: a decreasing entry would wrap a length to ~4 G on the
+    // device (vk_lines_kernel), and lab_offs[n] sizes the text below
+    if (label_offsets && label_offsets[0] != 0) return fail(e, VK_E_INVALID_ARG, "label_offsets[0] must be 0");
+    for (size_t i = 0; i < n; i++)
+        if (lab_offs[i + 1] < lab_offs[i]) return fail(e, VK_E_INVALID_ARG, label_offsets ? "label_offsets must be non-decreasing" : "offsets must be non-decreasing");
     const u64 need = (u64)lab_offs[n] * slots + items * VK_LINE_STRIDE;
     if (need >= (1ull << 32)) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines_strings: more than 4 GB of text in one call; pass fewer lines");
     if (text_cap < need) return fail(e, VK_E_INVALID_ARG, "vk_generate_lines_strings: text_cap must be at least slots x the label bytes + 192 bytes per (input, slot) pair");
@@ -1552,9 +1566,7 @@ extern "C" int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *
     SCRATCH(e, d_priv, u32 *, 3, items * 32);
     SCRATCH(e, d_hc, u32 *, 5, items * 20);
     SCRATCH(e, d_slots, u64 *, 6, items * VK_LINE_STRIDE);
-    size_t temp_bytes = 0;
-    u32 *null32 = nullptr;
-    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, null32, null32, (int)items, e->stream));
+    const size_t temp_bytes = scan_temp_bytes(items);
     const size_t off_offs = (items + 1) * 4, off_temp = ((off_offs + (items + 1) * 4 + 255) / 256) * 256;
     SCRATCH(e, d_scan, unsigned char *, 7, off_temp + temp_bytes);
     u32 *d_lens = (u32 *)d_scan, *d_offs32 = (u32 *)(d_scan + off_offs);
@@ -1574,7 +1586,7 @@ extern "C" int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *
     hipLaunchKernelGGL(vk_lines_kernel, dim3((u32)((items + 255) / 256)), dim3(256), 0, e->stream, (u64)0, items, slots, d_priv, d_hc, d_valid, d_texts, d_offs, d_slots,
                        d_lens);
     HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipcub::DeviceScan::ExclusiveSum(d_scan + off_temp, temp_bytes, d_lens, d_offs32, (int)items, e->stream));
+    HIPCHK(e, exclusive_scan(e, d_scan + off_temp, d_lens, d_offs32, items));
     hipLaunchKernelGGL(vk_lines_compact_kernel, dim3((u32)((items + 63) / 64 * 64 + 255) / 256), dim3(256), 0, e->stream, items, slots, VK_LINE_STRIDE, d_slots, d_lens, d_offs32, d_data,
                        d_offs, d_text);
     HIPCHK(e, hipGetLastError());
@@ -1902,6 +1914,21 @@ extern "C" int vk_debug_ring_knobs(vk_engine *e, uint32_t chunk_iters, uint32_t 
     e->dbg_ring_chunk = chunk_iters;
     e->dbg_ring_wps = waves_per_simd;
     e->dbg_ring_workers = workers;
+    return VK_OK;
+}
+
+// exclusive prefix sum of n u32 through vk_scan_kernel (the offsets of generate mode's compacted text / columns)
+extern "C" int vk_debug_scan(vk_engine *e, const uint32_t *in, size_t n, uint32_t *out)
+{
+    if (!e || !in || !out || n == 0 || n > (1u << 26)) return VK_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t off_out = ((n * 4 + 255) / 256) * 256, off_temp = 2 * off_out;
+    SCRATCH(e, d, unsigned char *, 7, off_temp + scan_temp_bytes(n));
+    HIPCHK(e, hipMemcpy(d, in, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(e, exclusive_scan(e, d + off_temp, (const u32 *)d, (u32 *)(d + off_out), n));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out, d + off_out, n * 4, hipMemcpyDeviceToHost));
     return VK_OK;
 }
 #endif // VK_TEST_HOOKS

@@ -29,18 +29,14 @@
 #define VK_F_EMIT 0x10000u /* internal: generate-mode records */
 
 #define VK_BLOCK 256
-// How the sweep reads its table entries: 0 = every lane loads its own 64 bytes, 1 = quad-cooperative loads handed over
-// through an LDS tile, 2 = quad-cooperative loads landing in LDS directly (global_load_lds_dwordx4).  Same-box A/B on the
-// Milksad sweep: 2 is 1.4 % faster than 0, 1 is slower than 0 (tools/README.md).
-#ifndef VK_COOP_GATHER
-#define VK_COOP_GATHER 2
+// VK_SPLIT_PASS2 (one bounded experiment; NOT the shipped form): pass 1 + inversion and pass 2 as two
+// kernels.  vk_sweep_kernel then parks the inverse in the workspace and stops; vk_sweep_pass2_kernel, budgeted for 4 waves per
+// SIMD, walks the items backwards from it.  The workspace holds one slice per TILE instead of one per resident workgroup.
+#ifndef VK_SPLIT_PASS2
+#define VK_SPLIT_PASS2 0
 #endif
-// 1: the sweep's accumulator in XYZZ coordinates (vk_ec.cuh; needs VK_COOP_GATHER 2), 0: Jacobian
-#ifndef VK_XYZZ
-#define VK_XYZZ (VK_COOP_GATHER == 2)
-#endif
-#ifndef VK_PASS2_PREFETCH
-#define VK_PASS2_PREFETCH 1 /* 1: pass 2 requests e and c of the next item one iteration ahead */
+#ifndef VK_PASS2_WAVES
+#define VK_PASS2_WAVES 4 /* waves per SIMD vk_sweep_pass2_kernel is register-budgeted for */
 #endif
 #ifndef VK_SWEEP_WAVES
 #define VK_SWEEP_WAVES 2 /* minimum waves per SIMD the sweep kernel is register-budgeted for */
@@ -63,7 +59,8 @@ struct vk_sweep_params {
     u32 slots;      // slots per input
     u32 R;          // inputs per lane per tile
     u32 flags;
-    u32 nwin, pad1;
+    u32 nwin;
+    u32 ws_per_tile; // 1: the workspace slice is the tile's (VK_SPLIT_PASS2 builds), 0: the resident workgroup's
     u32 tgt_mask;   // capacity - 1 (power of two), valid when tgt != nullptr
     u32 hit_cap;
     u32 pad0;
@@ -152,6 +149,137 @@ VK_DEV bool item_key(u32 kw[8], const vk_sweep_params &p, u64 off, u32 sub)
     return transform_key<KIND>(kw, p.spec, p.lo + off, sub);
 }
 
+// pass 2 of one tile: walk the B items of this lane backwards from `inv` = 1 / (e_0 .. e_{B-1}); (r, sub) = the (input row, slot)
+// counters as pass 1 left them.  e and the running product of the item before it are what the two multiplies at the top of the
+// body wait for: they are requested one item ahead (16 registers), X and Y at the top of the body (needed two multiplies later).
+template <u32 KIND>
+VK_DEV void sweep_pass2(const vk_sweep_params &p, const uint4 *wk, const u32 B, const u64 tile_off, fe inv, u32 r, u32 sub, u64 *dg, u32 &n_keys,
+                        u32 &n_match)
+{
+    const u32 tid = threadIdx.x;
+    const u64 nth = VK_BLOCK;
+    fe nz, ncp;
+    work_load(nz, wk + (u64)(B - 1) * 8 * nth + 4 * nth, nth);
+    if (B > 1) work_load(ncp, wk + (u64)(B - 2) * 8 * nth + 6 * nth, nth);
+#pragma unroll 1
+    for (u32 bb = B; bb > 0; bb--) {
+        const u32 b = bb - 1;
+        if (sub == 0) {
+            sub = p.slots - 1;
+            r--;
+        } else {
+            sub--;
+        }
+        const uint4 *it = wk + (u64)b * 8 * nth;
+        jac P;
+        fe zinv;
+        work_load(P.x, it, nth);
+        work_load(P.y, it + 2 * nth, nth);
+        P.z = nz;
+        const fe cp = ncp;
+        if (b > 0) {
+            work_load(nz, it - 4 * nth, nth);                 // e of item b-1
+            if (b > 1) work_load(ncp, it - 10 * nth, nth);    // c of item b-2
+            fe_mul(zinv, inv, cp);
+            fe_mul(inv, inv, P.z);
+        } else {
+            zinv = inv;
+        }
+        u32 nzw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) nzw |= P.x.v[i] | P.y.v[i];
+        if (nzw == 0) continue;
+        fe x, y;
+        fe_mul(y, P.y, zinv); // P.x = X*ZZ^2, P.y = Y, zinv = 1 / ZZZ
+        fe_sqr(zinv, zinv);
+        fe_mul(x, P.x, zinv);
+        fe_canon(x);
+        fe_canon(y);
+        n_keys++;
+        const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
+        u32 hc[5], hu[5];
+        u32 bits_c = 0, bits_u = 0;
+        if (p.flags & VK_F_COMPRESSED) {
+            hash160_pub33(hc, x, y.v[0] & 1u);
+            digest_fold(dg, hc);
+            if (p.tgt) bits_c = probe_targets(p.tgt, p.tgt_mask, hc);
+        }
+        if (p.flags & VK_F_UNCOMPRESSED) {
+            hash160_pub65(hu, x, y);
+            digest_fold(dg, hu);
+            if (p.tgt) bits_u = probe_targets(p.tgt, p.tgt_mask, hu);
+        }
+        // Matcher::check order (reference src/matcher.rs:72-98): p2pkh(c), p2pkh(u), p2wpkh
+        int kind = -1;
+        if (bits_c & 1u) kind = 0;
+        else if (bits_u & 1u) kind = 1;
+        else if (bits_c & 2u) kind = 2;
+        const bool emit = (p.flags & VK_F_EMIT) != 0;
+        if (kind >= 0 || emit) {
+            // rare (or output-bound) path: regenerate the normalised key bytes
+            u32 kw[8], k[8];
+            item_key<KIND>(kw, p, off, sub);
+#pragma unroll
+            for (int i = 0; i < 8; i++) k[i] = kw[7 - i];
+            scalar_normalize(k);
+            if (kind >= 0) {
+                n_match++;
+                u64 slot = atomicAdd((unsigned long long *)&p.stats[2], 1ull);
+                if (slot < p.hit_cap) {
+                    vk_hit_dev *h = p.hits + slot;
+                    h->seed = p.lo + off;
+                    h->sub_index = sub;
+                    h->addr_kind = (u32)kind;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) h->privkey[i] = bswap32(k[7 - i]);
+#pragma unroll
+                    for (int i = 0; i < 5; i++) h->h160[i] = (kind == 1) ? hu[i] : hc[i];
+                    h->pad = 0;
+                }
+            }
+            if (emit) {
+                const u64 item = off * p.slots + sub;
+                if (p.out_valid) p.out_valid[item] = 1;
+                if (p.out_priv) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) p.out_priv[item * 8 + i] = bswap32(k[7 - i]);
+                }
+                if (p.out_h160c && (p.flags & VK_F_COMPRESSED)) {
+#pragma unroll
+                    for (int i = 0; i < 5; i++) p.out_h160c[item * 5 + i] = hc[i];
+                }
+                if (p.out_h160u && (p.flags & VK_F_UNCOMPRESSED)) {
+#pragma unroll
+                    for (int i = 0; i < 5; i++) p.out_h160u[item * 5 + i] = hu[i];
+                }
+                if (p.out_pub) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        p.out_pub[item * 16 + i] = bswap32(FE_BE(x, i));
+                        p.out_pub[item * 16 + 8 + i] = bswap32(FE_BE(y, i));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// counters of one workgroup into p.stats: one wave-reduced atomic per wave and counter
+VK_DEV void sweep_counters(const vk_sweep_params &p, const u64 *dg, u32 n_keys, u32 n_match)
+{
+    const u32 tid = threadIdx.x;
+    const u64 w_keys = wave_add((u64)n_keys), w_match = wave_add((u64)n_match);
+    const u64 d0 = wave_xor(dg[0]), d1 = wave_xor(dg[VK_BLOCK]), d2 = wave_xor(dg[2 * VK_BLOCK]), d3 = wave_add(dg[3 * VK_BLOCK]);
+    if ((tid & 63) == 0) {
+        atomicAdd((unsigned long long *)&p.stats[0], (unsigned long long)w_keys);
+        atomicAdd((unsigned long long *)&p.stats[1], (unsigned long long)w_match);
+        atomicXor((unsigned long long *)&p.stats[3], (unsigned long long)d0);
+        atomicXor((unsigned long long *)&p.stats[4], (unsigned long long)d1);
+        atomicXor((unsigned long long *)&p.stats[5], (unsigned long long)d2);
+        atomicAdd((unsigned long long *)&p.stats[6], (unsigned long long)d3);
+    }
+}
+
 template <u32 KIND>
 __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(const vk_sweep_params p)
 {
@@ -168,15 +296,12 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
     // workspace of this workgroup: item b, quad q, lane t at wk[(b*8 + q) * VK_BLOCK] -- one contiguous
     // B * 32 KB region per workgroup (a few TLB entries), every access a fully coalesced 16 B per lane
     const u64 nth = VK_BLOCK;
+#if !VK_SPLIT_PASS2
     uint4 *wk = p.work + (u64)blockIdx.x * ((u64)B * 8 * VK_BLOCK) + tid;
+#endif
     __shared__ u64 s_tile;
-#if VK_COOP_GATHER == 2
     __shared__ uint4 s_gather[(VK_BLOCK / 64) * VK_LDS_DEPTH * VK_LTILE_FULL]; // whole-entry slots per wave (lds_gather_issue)
     uint4 *gtile = s_gather + (tid >> 6) * (VK_LDS_DEPTH * VK_LTILE_FULL);
-#elif VK_COOP_GATHER == 1
-    __shared__ uint4 s_gather[VK_BLOCK * VK_GTILE_STRIDE]; // one 64-entry tile per wave (quad_gather_commit)
-    uint4 *gtile = s_gather + (tid & ~63u) * VK_GTILE_STRIDE;
-#endif
 
 #pragma unroll 1
     for (;;) {
@@ -187,6 +312,9 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
         __syncthreads();
         if (tile >= p.ntiles) break;
         const u64 tile_off = tile * ((u64)VK_BLOCK * p.R);
+#if VK_SPLIT_PASS2
+        uint4 *wk = p.work + tile * ((u64)B * 8 * VK_BLOCK) + tid;
+#endif
         // ---------------------------------------------------------------- pass 1
         fe c;
         u32 r = 0, sub = 0;
@@ -194,7 +322,6 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
         for (u32 b = 0; b < B; b++) {
             const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
             u32 kw[8];
-#if VK_XYZZ
             // parked per item: X*ZZ^2, Y, e = ZZZ and the running product of e: y = Y / e, x = X*ZZ^2 / e^2 (ZZ^3 = ZZZ^2)
             uint4 *it = wk + (u64)b * 8 * nth;
             {
@@ -222,47 +349,6 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
                 work_store(it + 4 * nth, nth, e);
                 work_store(it + 6 * nth, nth, c);
             }
-#else
-            jac P;
-#if VK_COOP_GATHER
-            {
-                const bool have = item_key<KIND>(kw, p, off, sub);
-                u32 k[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) k[i] = have ? kw[7 - i] : (i == 0 ? 1u : 0u); // lanes without a key walk the table with k = 1
-                scalar_normalize(k);
-#if VK_COOP_GATHER == 2
-                ecmult_table_lds(P, k, p.table, p.wins, p.nwin, gtile);
-#else
-                ecmult_table_coop(P, k, p.table, p.wins, p.nwin, gtile);
-#endif
-                if (!have) {
-                    fe_set_zero(P.x);
-                    fe_set_zero(P.y);
-                    fe_set_one(P.z);
-                }
-            }
-#else
-            if (item_key<KIND>(kw, p, off, sub)) {
-                u32 k[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) k[i] = kw[7 - i];
-                scalar_normalize(k);
-                ecmult_table(P, k, p.table, p.wins, p.nwin);
-            } else { // (0, 0, 1) marks "no key here"; (0,0) is not on the curve
-                fe_set_zero(P.x);
-                fe_set_zero(P.y);
-                fe_set_one(P.z);
-            }
-#endif
-            if (b == 0) c = P.z;
-            else fe_mul(c, c, P.z);
-            uint4 *it = wk + (u64)b * 8 * nth;
-            work_store(it, nth, P.x);
-            work_store(it + 2 * nth, nth, P.y);
-            work_store(it + 4 * nth, nth, P.z);
-            work_store(it + 6 * nth, nth, c);
-#endif
             if (++sub == p.slots) {
                 sub = 0;
                 r++;
@@ -271,145 +357,41 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
         // ---------------------------------------------------------------- invert
         fe inv;
         fe_inv(inv, c);
+#if VK_SPLIT_PASS2
+        work_store(wk + (u64)(B - 1) * 8 * nth + 6 * nth, nth, inv); // the last running product has done its part: its place takes the inverse
+#else
         // ---------------------------------------------------------------- pass 2
-#if VK_PASS2_PREFETCH
-        // e and the running product of the item before it are what the two multiplies at the top of the body wait for:
-        // they are requested one item ahead (16 registers), X and Y at the top of the body (needed two multiplies later)
-        fe nz, ncp;
-        work_load(nz, wk + (u64)(B - 1) * 8 * nth + 4 * nth, nth);
-        if (B > 1) work_load(ncp, wk + (u64)(B - 2) * 8 * nth + 6 * nth, nth);
+        sweep_pass2<KIND>(p, wk, B, tile_off, inv, r, sub, dg, n_keys, n_match);
 #endif
-#pragma unroll 1
-        for (u32 bb = B; bb > 0; bb--) {
-            const u32 b = bb - 1;
-            if (sub == 0) {
-                sub = p.slots - 1;
-                r--;
-            } else {
-                sub--;
-            }
-            const uint4 *it = wk + (u64)b * 8 * nth;
-            jac P;
-            fe zinv;
-            work_load(P.x, it, nth);
-            work_load(P.y, it + 2 * nth, nth);
-#if VK_PASS2_PREFETCH
-            P.z = nz;
-            const fe cp = ncp;
-            if (b > 0) {
-                work_load(nz, it - 4 * nth, nth);                 // e of item b-1
-                if (b > 1) work_load(ncp, it - 10 * nth, nth);    // c of item b-2
-                fe_mul(zinv, inv, cp);
-                fe_mul(inv, inv, P.z);
-            } else {
-                zinv = inv;
-            }
-#else
-            work_load(P.z, it + 4 * nth, nth);
-            if (b > 0) {
-                fe cp;
-                work_load(cp, it - 2 * nth, nth); // c of item b-1
-                fe_mul(zinv, inv, cp);
-                fe_mul(inv, inv, P.z);
-            } else {
-                zinv = inv;
-            }
-#endif
-            u32 nz = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) nz |= P.x.v[i] | P.y.v[i];
-            if (nz == 0) continue;
-            fe x, y;
-#if VK_XYZZ
-            fe_mul(y, P.y, zinv); // P.x = X*ZZ^2, P.y = Y, zinv = 1 / ZZZ
-            fe_sqr(zinv, zinv);
-            fe_mul(x, P.x, zinv);
-            fe_canon(x);
-            fe_canon(y);
-#else
-            jac_to_affine(x, y, P, zinv);
-#endif
-            n_keys++;
-            const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
-            u32 hc[5], hu[5];
-            u32 bits_c = 0, bits_u = 0;
-            if (p.flags & VK_F_COMPRESSED) {
-                hash160_pub33(hc, x, y.v[0] & 1u);
-                digest_fold(dg, hc);
-                if (p.tgt) bits_c = probe_targets(p.tgt, p.tgt_mask, hc);
-            }
-            if (p.flags & VK_F_UNCOMPRESSED) {
-                hash160_pub65(hu, x, y);
-                digest_fold(dg, hu);
-                if (p.tgt) bits_u = probe_targets(p.tgt, p.tgt_mask, hu);
-            }
-            // Matcher::check order (reference src/matcher.rs:72-98): p2pkh(c), p2pkh(u), p2wpkh
-            int kind = -1;
-            if (bits_c & 1u) kind = 0;
-            else if (bits_u & 1u) kind = 1;
-            else if (bits_c & 2u) kind = 2;
-            const bool emit = (p.flags & VK_F_EMIT) != 0;
-            if (kind >= 0 || emit) {
-                // rare (or output-bound) path: regenerate the normalised key bytes
-                u32 kw[8], k[8];
-                item_key<KIND>(kw, p, off, sub);
-#pragma unroll
-                for (int i = 0; i < 8; i++) k[i] = kw[7 - i];
-                scalar_normalize(k);
-                if (kind >= 0) {
-                    n_match++;
-                    u64 slot = atomicAdd((unsigned long long *)&p.stats[2], 1ull);
-                    if (slot < p.hit_cap) {
-                        vk_hit_dev *h = p.hits + slot;
-                        h->seed = p.lo + off;
-                        h->sub_index = sub;
-                        h->addr_kind = (u32)kind;
-#pragma unroll
-                        for (int i = 0; i < 8; i++) h->privkey[i] = bswap32(k[7 - i]);
-#pragma unroll
-                        for (int i = 0; i < 5; i++) h->h160[i] = (kind == 1) ? hu[i] : hc[i];
-                        h->pad = 0;
-                    }
-                }
-                if (emit) {
-                    const u64 item = off * p.slots + sub;
-                    if (p.out_valid) p.out_valid[item] = 1;
-                    if (p.out_priv) {
-#pragma unroll
-                        for (int i = 0; i < 8; i++) p.out_priv[item * 8 + i] = bswap32(k[7 - i]);
-                    }
-                    if (p.out_h160c && (p.flags & VK_F_COMPRESSED)) {
-#pragma unroll
-                        for (int i = 0; i < 5; i++) p.out_h160c[item * 5 + i] = hc[i];
-                    }
-                    if (p.out_h160u && (p.flags & VK_F_UNCOMPRESSED)) {
-#pragma unroll
-                        for (int i = 0; i < 5; i++) p.out_h160u[item * 5 + i] = hu[i];
-                    }
-                    if (p.out_pub) {
-#pragma unroll
-                        for (int i = 0; i < 8; i++) {
-                            p.out_pub[item * 16 + i] = bswap32(FE_BE(x, i));
-                            p.out_pub[item * 16 + 8 + i] = bswap32(FE_BE(y, i));
-                        }
-                    }
-                }
-            }
-        }
     }
     // ------------------------------------------------------------------- counters
-    const u64 w_keys = wave_add((u64)n_keys), w_match = wave_add((u64)n_match);
-    const u64 d0 = wave_xor(dg[0]), d1 = wave_xor(dg[VK_BLOCK]), d2 = wave_xor(dg[2 * VK_BLOCK]), d3 = wave_add(dg[3 * VK_BLOCK]);
     if (blockIdx.x == 0 && tid == 0) {
         p.stats[8] = __builtin_amdgcn_s_memtime() - clk0;
         p.stats[9] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
-    if ((tid & 63) == 0) {
-        atomicAdd((unsigned long long *)&p.stats[0], (unsigned long long)w_keys);
-        atomicAdd((unsigned long long *)&p.stats[1], (unsigned long long)w_match);
-        atomicXor((unsigned long long *)&p.stats[3], (unsigned long long)d0);
-        atomicXor((unsigned long long *)&p.stats[4], (unsigned long long)d1);
-        atomicXor((unsigned long long *)&p.stats[5], (unsigned long long)d2);
-        atomicAdd((unsigned long long *)&p.stats[6], (unsigned long long)d3);
-    }
+#if !VK_SPLIT_PASS2
+    sweep_counters(p, dg, n_keys, n_match);
+#endif
 }
+
+#if VK_SPLIT_PASS2
+// pass 2 as a kernel of its own (experiment): one workgroup per tile, budgeted for 4 waves per SIMD
+template <u32 KIND>
+__global__ void __launch_bounds__(VK_BLOCK, VK_PASS2_WAVES) vk_sweep_pass2_kernel(const vk_sweep_params p)
+{
+    const u32 tid = threadIdx.x;
+    const u32 B = p.R * p.slots;
+    const u64 nth = VK_BLOCK;
+    __shared__ u64 s_dg[4 * VK_BLOCK];
+    u64 *dg = s_dg + tid;
+#pragma unroll
+    for (int i = 0; i < 4; i++) dg[i * VK_BLOCK] = 0;
+    u32 n_keys = 0, n_match = 0;
+    const u64 tile = blockIdx.x;
+    const uint4 *wk = p.work + tile * ((u64)B * 8 * VK_BLOCK) + tid;
+    fe inv;
+    work_load(inv, wk + (u64)(B - 1) * 8 * nth + 6 * nth, nth);
+    sweep_pass2<KIND>(p, wk, B, tile * ((u64)VK_BLOCK * p.R), inv, p.R, 0u, dg, n_keys, n_match);
+    sweep_counters(p, dg, n_keys, n_match);
+}
+#endif

@@ -109,7 +109,10 @@ public:
     // appends lines to `b` until it holds max_lines or max_bytes; false at end of input
     bool fill(LineBatch &b, size_t max_lines, size_t max_bytes)
     {
-        while (!failed_ && b.n() < max_lines && b.data.size() < max_bytes) {
+        // strict mode: a batch ends only where the reference's batches of 1000 lines end (whatever limit cut it -- lines or bytes),
+        // so that a line that is not UTF-8 loses exactly the lines the reference never processes (src/source/stdin.rs:45-60)
+        auto full = [&]() { return (b.n() >= max_lines || b.data.size() >= max_bytes) && (!strict_ || accepted_ % 1000 == 0); };
+        while (!failed_ && !full()) {
             if (pos_ == len_) {
                 len_ = fread(buf_.data(), 1, buf_.size(), fp_);
                 pos_ = 0;
@@ -200,10 +203,16 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
     for (const Transform &t : transforms) max_slots = std::max(max_slots, t.string_slots());
     size_t max_lines = std::max<size_t>(1, std::min<size_t>(1u << 20, (1u << 27) / max_slots));
     if (max_lines >= 1000) max_lines -= max_lines % 1000; // batches end where the reference's batches of 1000 end (strict mode's cut-off)
+    // bytes per device batch (the CLI's knob, tests/test_golden.py cuts batches short with it; the library reads no environment)
+    size_t batch_bytes = 256u << 20;
+    if (const char *v = getenv("VUKE_HIP_BATCH_BYTES")) {
+        const long long x = atoll(v);
+        if (x >= 1024 && x <= (1ll << 31)) batch_bytes = (size_t)x;
+    }
     bool more = true;
     while (more) {
         b.clear();
-        more = reader.fill(b, max_lines, 256u << 20); // a million passphrases per batch, fewer when one line makes many keys
+        more = reader.fill(b, max_lines, batch_bytes); // a million passphrases per batch, fewer when one line makes many keys
         const size_t n = b.n();
         if (n == 0) continue;
         st.inputs_processed += n;
