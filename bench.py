@@ -18,6 +18,10 @@ Other configs under the same contract (inputs in bench_workloads
   --config 5e  the same for Electrum v1 seeds
 --strong (config 2): the N ranks share ONE 2^32 sweep (16/N disjoint blocks each, no wrap) and the line also reports the
 end-to-end wall time from before the engine (table build) exists to after the counters are reduced.
+The default config-2 line carries that measurement too, as `strong`: AFTER the timed region (never inside it, never part of
+`value`) the 120 GB engine is destroyed and the same ranks share one whole 2^32 sweep on the geometry the product picks for a
+single sweep (43 GB W = 26 table on one GPU, 11.8 GB W = 24 from two), timed from before vk_engine_create to after the counter
+all-reduce -- `strong.wall_s`, `covers_full_2p32: true` (--no-strong-after skips it).
 
 Every expected value comes from the CPU oracle through committed fixtures (tests/golden/): planted hash160s, the
 digest of every 2^28 block of the Milksad space, the digest of each config's warm-up window.  bench.py itself touches
@@ -113,6 +117,18 @@ def load_pmc(tag):
     if pj.get("csrc_hash") != csrc_hash():
         return None, f"profiles/pmc_{tag}.json was taken from other kernel sources ({pj.get('csrc_hash')} != {csrc_hash()}): re-run tools/profile.sh"
     return pj, None
+
+
+def kernel_meta(kernel):
+    """Code-object metadata of `kernel` from profiles/r04_kernel_meta.json (tools/kernel_meta.py) if it was taken from the kernel
+    sources in this tree, else None."""
+    path = os.path.join(ROOT, "profiles", "r04_kernel_meta.json")
+    if not os.path.exists(path):
+        return None
+    km = json.load(open(path))
+    if km.get("csrc_hash") != csrc_hash():
+        return None
+    return next((r for r in km["kernels"] if kernel in r["kernel"]), None)
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -391,6 +407,7 @@ def main():
     ap.add_argument("--strong", action="store_true", help="config 2: N ranks share one 2^32 sweep; also report end-to-end wall time")
     ap.add_argument("--emulate-gpus", type=int, default=0, help="--strong on one GPU: sweep only this rank-0 share of an M-GPU run (16/M blocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong-after", action="store_true", help="config 2: skip the one-whole-sweep measurement that follows the timed region")
     # rehearsal knobs (not used by the driver): run the N-rank path on a box with fewer GPUs than ranks
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal)")
     ap.add_argument("--share-device", type=int, default=-1, help="put every rank on this one GPU (rehearsal only)")
@@ -487,10 +504,15 @@ def main():
     digest = (0, 0, 0, 0)
     full_after = w.full_sweep_steps() if (args.config == "2" and not args.emulate_gpus) else 0
     t_full = 0.0
+    step_ms = []
     sync()
     t0 = time.perf_counter()
+    t_prev = t0
     for s in range(steps):
         st = w.step(eng, s)
+        t_now = time.perf_counter()
+        step_ms.append(1e3 * (t_now - t_prev))   # vk_sweep / vk_scan_strings return after the device work of the step is done
+        t_prev = t_now
         if s + 1 == full_after:   # vk_sweep has returned its counters: this rank's share of one whole 2^32 sweep is done
             t_full = time.perf_counter() - t0
         units += st["units"]
@@ -522,6 +544,53 @@ def main():
         print(f"bench.py: PARITY FAILURE: {dg_bad} of {dg_checked} digests differ from the oracle's (tests/golden)", file=sys.stderr)
         sys.exit(3)
 
+    # ---- one whole 2^32 sweep as the product would run it when that is the whole job (outside the timed region: `value` is done)
+    strong_after = None
+    if args.config == "2" and not args.strong and not args.no_strong_after and not args.emulate_gpus and w.nblocks % world == 0 and world <= w.nblocks:
+        import copy
+        eng.close()
+        a2 = copy.copy(args)
+        a2.strong = True
+        sync()
+        ts0 = time.perf_counter()
+        g_bits = 26 if world == 1 else 24     # by measured wall time, profiles/r02_strong_geometry.txt: the big table cannot pay for itself inside one sweep
+        eng = vuke_amd.Engine(local_rank, window_bits=g_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=0)
+        s_create = time.perf_counter() - ts0
+        s_info = eng.info()
+        w2 = Milksad(a2, rank, world)
+        w2.setup(eng, ffi, wl)
+        s_setup = time.perf_counter() - ts0 - s_create
+        s_keys = s_matches = s_expected = 0
+        s_digest = (0, 0, 0, 0)
+        ts1 = time.perf_counter()
+        for s in range(w2.step_total()):
+            st = w2.step(eng, s)
+            s_keys += st["keys"]
+            s_matches += st["matches"]
+            s_expected += st["expected"]
+            s_digest = wl.fold_digests([s_digest, st["digest"]])
+        sync()
+        s_sweep = time.perf_counter() - ts1
+        (sk, sm, se, sdc, sdb), (s_sweep_max, s_create_max, s_setup_max) = reduce_counters(
+            dist, red_dev, [s_keys, s_matches, s_expected, w2.digest_checked, w2.digest_bad], [s_sweep, s_create, s_setup])
+        s_wall = time.perf_counter() - ts0
+        s_digests = [s_digest]
+        if use_dist:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, [int(x) for x in s_digest])
+            s_digests = [tuple(g) for g in gathered]
+        if sm != se or sdb:
+            print(f"bench.py: PARITY FAILURE in the one-sweep run: {sm} matches / {se} planted, {sdb} of {sdc} digests differ", file=sys.stderr)
+            sys.exit(3)
+        strong_after = {"covers_full_2p32": sk == 1 << 32, "keys": sk, "blocks_per_rank": w2.step_total(), "window_bits": s_info["window_bits"],
+                        "table_gb": s_info["table_bytes"] / 1e9, "engine_create_s": s_create_max,
+                        "engine_create_split_rank0": {"hip_runtime_s": s_info["runtime_init_seconds"], "alloc_s": s_info["alloc_seconds"],
+                                                      "table_build_s": s_info["table_build_seconds"], "table_wall_s": s_info["table_wall_seconds"]},
+                        "targets_and_fixtures_s": s_setup_max, "sweep_s": s_sweep_max, "wall_s": s_wall, "keys_per_s_end_to_end": sk / s_wall,
+                        "digest": wl.hexd(wl.fold_digests(s_digests)), "digests_checked_against_oracle": sdc, "matches": sm,
+                        "note": "measured AFTER the timed region, on the table geometry the product picks for ONE sweep; wall_s = from before "
+                                "vk_engine_create to after the counter all-reduce (max over ranks by construction: barriers on both sides)"}
+
     if rank == 0:
         value = total_keys / t
         per_launch_keys = keys_done / max(launches, 1)
@@ -546,9 +615,14 @@ def main():
                          "valu_busy_pct_in_profile": pmc.get("valu_busy_pct"),
                          "effective_clock_ghz_in_profile": pmc.get("effective_clock_ghz"),
                          "traffic": pmc.get("hbm_bytes_per_launch_calibrated", pmc.get("hbm_bytes_per_launch")),
-                         "vgpr": pmc.get("dispatch", {}).get("VGPR_Count"), "scratch": pmc.get("dispatch", {}).get("Scratch_Size")})
+                         "cycles_per_valu_inst_floor": pmc.get("cycles_per_valu_inst_floor"), "valu_int64_share": (pmc.get("valu_mix") or {}).get("int64_share"),
+                         "scratch": pmc.get("dispatch", {}).get("Scratch_Size")})
         else:
             roof.update({"achieved": None, "frac": None, "traffic": None, "pmc_refused": why})
+        km = kernel_meta(w.kernel)
+        if km:   # registers the CODE OBJECT allocates per lane (tools/kernel_meta.py), not rocprof's dispatch field (which counts in units of two)
+            roof.update({"vgpr": km["vgpr"], "agpr": km["agpr"], "vgpr_spills": km["vgpr_spill_count"], "waves_per_simd": max(1, 512 // max(km["vgpr"] + km["agpr"], 1)),
+                         "static_cycles_per_valu_inst_floor": km.get("cycles_per_valu_inst_floor")})
         if hasattr(w, "canonical_ops_per_key"):
             roof["canonical_ops_per_key"] = w.canonical_ops_per_key
             roof["canonical_frac"] = w.canonical_ops_per_key * rate / PEAK_INT32
@@ -565,6 +639,7 @@ def main():
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * t / steps,
+            "ms_per_step_rank0": {"min": min(step_ms), "median": sorted(step_ms)[len(step_ms) // 2], "max": max(step_ms), "argmax": step_ms.index(max(step_ms))},
             "higher_is_better": True,
             "scaling": "strong" if (args.strong or args.config in ("5m", "5e")) else "weak",
             "vs_baseline": None,
@@ -590,6 +665,11 @@ def main():
         # target upload; outside `value` (sustained throughput), inside every *_end_to_end_s below
         out["engine_create_s"] = create_max
         out["table_build_s"] = info["table_build_seconds"]
+        # where rank 0's vk_engine_create went (vk_engine_info, ABI 5): HIP runtime start, the two large hipMallocs (this is where a
+        # box waits while the driver scrubs VRAM a previous process has just freed), the table kernels (hipEvent time / host wall)
+        out["engine_create_split_rank0"] = {"total_s": engine_create_s, "hip_runtime_s": info["runtime_init_seconds"], "alloc_s": info["alloc_seconds"],
+                                            "table_build_s": info["table_build_seconds"], "table_wall_s": info["table_wall_seconds"],
+                                            "other_s": engine_create_s - info["runtime_init_seconds"] - info["alloc_seconds"] - info["table_wall_seconds"]}
         out["targets_and_fixtures_s"] = setup_max
         if args.config == "2":
             out["sweep_2p32_seconds_at_this_rate"] = (1 << 32) / value
@@ -604,6 +684,8 @@ def main():
                                    "traffic": roof.get("traffic"), "algorithmic_bytes_per_key": ab,
                                    "table_gathers_per_s": info["windows"] * rate,
                                    "table_gather_ceiling_per_s": 48.5e9}  # quad-cooperative 64-B reads landing in LDS, tools/lds_gather_test.hip
+        if strong_after:
+            out["strong"] = strong_after
         if args.strong:
             covered = steps * world == w.nblocks and not args.emulate_gpus
             out["strong"] = {"blocks_per_rank": steps, "covers_full_2p32": covered, "engine_create_s": engine_create_s,

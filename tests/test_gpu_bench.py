@@ -55,6 +55,19 @@ def test_default_config_two_steps_digest_checked_against_the_oracle():
     assert o["matches"] == 130 and o["value"] > 1.0e9   # planted seeds in blocks 0 and 1
     assert o["digests_checked_against_oracle"] == 3       # the warm-up window + two 2^28 blocks of the full-space golden
     assert o["roofline_hbm"]["frac"] < 1.0
+    # line hygiene: per-step spread, where engine creation went, registers from the code object
+    ms = o["ms_per_step_rank0"]
+    assert ms["min"] <= ms["median"] <= ms["max"] and ms["max"] < 1.5 * ms["min"]
+    sp = o["engine_create_split_rank0"]
+    assert sp["total_s"] == pytest.approx(sp["hip_runtime_s"] + sp["alloc_s"] + sp["table_wall_s"] + sp["other_s"]) and 0 < sp["table_build_s"] < 0.2
+    if o["roofline"]["frac"] is not None:
+        assert 200 <= o["roofline"]["vgpr"] <= 256 and o["roofline"]["waves_per_simd"] == 2
+    # the one-sweep run that follows the timed region: the whole 2^32 space on the geometry the product picks for it
+    s = o["strong"]
+    assert s["covers_full_2p32"] is True and s["keys"] == 2**32 and s["window_bits"] == 26 and s["matches"] == 1026
+    assert s["digests_checked_against_oracle"] == 16 and s["wall_s"] > s["sweep_s"] > 1.5 and s["wall_s"] < 12
+    import bench_workloads as wl
+    assert s["digest"] == wl.load_golden("milksad_2p32.json")["digest"]
 
 
 @pytest.mark.parametrize("cfg,steps,matches", [("3", 1, 1000), ("4", 2, None), ("5m", 1, 100), ("5e", 1, 100)])
@@ -85,8 +98,9 @@ def test_two_ranks_share_the_device():
     """The N > 1 path end to end (launcher, rank-major disjoint blocks, counter all-reduce, max-over-ranks time, digest
     gather) with both ranks on GPU 0.  RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the rehearsal's
     collectives run over gloo; on the driver's 8-GPU node the same code path runs with backend nccl, one rank per GPU."""
-    o = run_bench("--share-device", "0", "--backend", "gloo", "--layout", "0", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", nproc=2)
+    o = run_bench("--share-device", "0", "--backend", "gloo", "--layout", "0", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-strong-after", nproc=2)
     check_contract(o, n_gpus=2)
+    assert "strong" not in o
     import bench_workloads as wl
     planted = wl.c2_planted_seeds()
     blocks = (0, 1, 8, 9)                                                   # rank r starts at block r * 16/2
@@ -111,12 +125,18 @@ def test_plain_gpus_2_starts_its_own_ranks():
     g = wl.load_golden("milksad_2p32.json")
     assert o["digest"] == wl.hexd(wl.fold_digests([wl.unhexd(g["block_digests"][b]) for b in blocks]))
     assert o["digests_checked_against_oracle"] == 6 and o["engine_create_s"] > 0
+    # the N-GPU line carries BOTH the sustained rate (value, 120 GB geometry -- here the fallback table, two ranks
+    # share one card) and a full-sweep wall time the product would deliver: the two ranks share one 2^32 sweep on W = 24 tables
+    s = o["strong"]
+    assert s["covers_full_2p32"] is True and s["keys"] == 2**32 and s["blocks_per_rank"] == 8 and s["window_bits"] == 24
+    assert s["matches"] == 1026 and s["digests_checked_against_oracle"] == 16 and s["digest"] == g["digest"]
+    assert s["wall_s"] >= s["sweep_s"] > 0 and s["wall_s"] >= s["engine_create_s"]
 
 
 def test_rccl_call_sequence_with_one_rank():
     """The collectives of the N > 1 path over RCCL itself (backend nccl: init with device_id, barrier, all_reduce SUM / MAX on
     device tensors, all_gather_object, destroy) on the one GPU of the box, world size 1 -- the two-rank rehearsal above has to
     use gloo because RCCL refuses two ranks on one device."""
-    o = run_bench("--force-dist", "--layout", "0", "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    o = run_bench("--force-dist", "--layout", "0", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-strong-after")
     check_contract(o)
     assert o["n_gpus"] == 1 and o["matches"] == 65 and o["digests_checked_against_oracle"] == 2

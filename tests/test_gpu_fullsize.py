@@ -172,47 +172,31 @@ def test_config4_all_lcg_variants_over_2p31_seeds(eng):
     assert wl.hexd(whole["digest"]) == wl.load_golden("bench_c4_full.json")["digest"]   # the oracle's, over the whole config
 
 
-def test_config5_key_chains_at_size(eng, vko):
-    """BASELINE config 5 at its stated size for MultiBit (100 000 synthetic 12-word mnemonics, 20 indices) and a
-    4 096-seed Electrum slice of it (the stretch is 2 x 10^5 compressions per seed on the CPU side of the check):
-    planted = index-7 key of every 1000th / 512th input; the oracle recomputes exactly those inputs."""
-    import random
-    from tests.test_oracle_multibit import synthetic_wordlist
+def test_config5_key_chains_at_size(eng):
+    """BASELINE config 5 at its stated size, BOTH chains over all 100 000 inputs (the bench workload: bench_workloads.c5_mnemonics /
+    c5_electrum_seeds), through vk_scan_strings.  Everything expected is the ORACLE's: the planted hash160s and private keys (key 7
+    of every 1000th input, tests/golden/bench_c5.json -- MultiBit planted on the compressed form, Electrum on the uncompressed one,
+    src/electrum.rs:216-285) and counters + digest over the 2 000 000 keys of each chain (tests/golden/bench_c5_full.json,
+    make_c5_full.py).  Whole hit records are compared, as for configs 3 / 4 (rounds 2-3 planted hash160s the
+    device itself had derived and ran a 4 096-seed slice of Electrum).  Reference: src/transform/multibit.rs:45-61,
+    src/transform/electrum.rs:43-67."""
+    import bench_workloads as wl
     from vuke_amd import _ffi as ffi
-    words = synthetic_wordlist()
-    eng.bip39_wordlist_set(words)
-    rnd = random.Random(5489)
-    mn = [" ".join(words[rnd.getrandbits(11)] for _ in range(12)) for _ in range(100_000)]
-    spec = ffi.spec(ffi.T_MULTIBIT, 0, 0, 20)
-    keys, valid, _ = eng.transform_strings(spec, [m.encode() for m in mn], raw=True)
-    assert sum(valid) == 20 * len(mn)
-    wl = vko.Wordlist(words)
-    chosen = list(range(0, len(mn), 1000))
-    want = {i: vko.multibit_keys(wl, mn[i])[2] for i in chosen}
-    for i in chosen:
-        assert [keys[32 * (20 * i + j):32 * (20 * i + j) + 32] for j in range(20)] == [k for _, k in want[i]], i
-    planted = [want[i][7][1] for i in chosen]
-    _, hc, _ = eng.derive_batch(planted)
-    eng.targets_set(hc, [ffi.TARGET_P2PKH] * len(hc))
-    st, hits = eng.scan_keys([keys[o:o + 32] for o in range(0, len(keys), 32)], flags=3, hit_cap=1024)
-    assert (st["inputs"], st["matches"]) == (20 * len(mn), len(chosen))
-    assert [h["index"] for h in hits] == [20 * i + 7 for i in chosen]
-    # Electrum: uncompressed P2PKH is the address form of interest (src/electrum.rs:216-285)
-    seeds = [("%032x" % rnd.getrandbits(128)).encode() for _ in range(4096)]
-    spec = ffi.spec(ffi.T_ELECTRUM, 0, 0, 20)
-    keys, valid, _ = eng.transform_strings(spec, seeds, raw=True)
-    assert sum(valid) == 20 * len(seeds)
-    chosen = list(range(0, len(seeds), 512))
-    want = {i: vko.electrum_keys(seeds[i], for_change=False)[1] for i in chosen}
-    for i in chosen:
-        assert [keys[32 * (20 * i + j):32 * (20 * i + j) + 32] for j in range(20)] == [k for _, k in want[i]], i
-    planted = [want[i][7][1] for i in chosen]
-    _, _, hu = eng.derive_batch(planted)
-    eng.targets_set(hu, [ffi.TARGET_P2PKH] * len(hu))
-    st, hits = eng.scan_keys([keys[o:o + 32] for o in range(0, len(keys), 32)], flags=3, hit_cap=64)
-    eng.targets_set([], [])
-    assert st["matches"] == len(chosen) and [h["index"] for h in hits] == [20 * i + 7 for i in chosen]
-    assert all(h["addr_kind"] == 1 for h in hits)
+    fx, full = wl.load_golden("bench_c5.json"), wl.load_golden("bench_c5_full.json")
+    eng.bip39_wordlist_set(wl.c5_wordlist())
+    for which, spec, lines in (("multibit", ffi.spec(ffi.T_MULTIBIT, 0, 0, 20), wl.c5_mnemonics()),
+                               ("electrum", ffi.spec(ffi.T_ELECTRUM, 0, 0, 20), wl.c5_electrum_seeds())):
+        planted = fx[which]["planted"]
+        assert len(lines) == wl.C5_INPUTS == 100_000 and lines[0].decode() == fx[which]["first_input"]
+        assert [p["input"] for p in planted] == list(range(0, 100_000, 1000)) and all(p["sub_index"] == 7 for p in planted)
+        eng.targets_set([bytes.fromhex(p["h160"]) for p in planted], [ffi.TARGET_P2PKH] * len(planted))
+        st, hits = eng.scan_strings(spec, lines, flags=3, hit_cap=1024)
+        eng.targets_set([], [])
+        g = full[which]
+        assert (st["inputs"], st["keys"], st["matches"], st["hits_dropped"], st["inputs_skipped"]) == (g["inputs"], g["keys"], len(planted), 0, 0)
+        assert g["keys"] == 2_000_000 and g["flags"] == 3 and wl.hexd(st["digest"]) == g["digest"], which
+        got = sorted((h["index"], h["sub_index"], h["addr_kind"], h["privkey"].hex(), h["h160"].hex()) for h in hits)
+        assert got == sorted((p["input"], p["sub_index"], p["addr_kind"], p["privkey"], p["h160"]) for p in planted), which
 
 
 def test_configs_3_and_4_at_their_stated_sizes_against_the_oracle(eng):

@@ -29,6 +29,43 @@ def demangle(names):
         return names
 
 
+# issue cost in cycles per wave-instruction per SIMD with two waves resident ("wall" column of profiles/r03_ubench_valu_rates.txt):
+# what a VALU instruction of each class holds its SIMD for when nothing else stalls -- the floor the measured
+# cycles_per_valu_inst_per_simd (rocprofv3: GRBM_GUI_ACTIVE / SQ_INSTS_VALU) is held against
+PRICE = {"mad64": 4.50, "full": 4.47, "bitop3": 3.34, "mov": 3.96, "fast": 2.47}
+FAST = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32",
+        "v_add_nc_u32", "v_min_u32", "v_max_u32", "v_xnor_b32")
+
+
+def classify(op):
+    if op.startswith("v_mad_u64_u32"):
+        return "mad64"
+    if op.startswith("v_bitop3"):
+        return "bitop3"
+    if op.startswith("v_mov_b32") or op.startswith("v_accvgpr"):
+        return "mov"
+    base = op.split("_e32")[0].split("_e64")[0].split("_dpp")[0].split("_sdwa")[0]
+    return "fast" if base in FAST else "full"
+
+
+def valu_mix(txt):
+    """Static VALU instruction mix of every kernel body in an assembly listing: {symbol: {class: count}}."""
+    out, cur = {}, None
+    for line in txt.splitlines():
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        if line.startswith("\t.end_amdhsa_kernel") or line.startswith(".Lfunc_end"):
+            cur = None
+            continue
+        m = re.match(r"^\s+(v_[a-z0-9_]+)", line)
+        if cur is not None and m and not m.group(1).startswith(("v_readfirstlane", "v_readlane", "v_writelane")):
+            c = classify(m.group(1))
+            cur[c] = cur.get(c, 0) + 1
+    return out
+
+
 def unit(src, extra, tag):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "u.s")
@@ -36,11 +73,20 @@ def unit(src, extra, tag):
                        check=True, capture_output=True)
         txt = open(out).read()
     rows = []
+    mix = valu_mix(txt)
     for b in txt.split("  - .agpr_count:")[1:]:
         g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", b).group(1))
-        rows.append({"unit": tag, "kernel": re.search(r"\.name:\s+(\S+)", b).group(1), "vgpr": g("vgpr_count"), "agpr": int(b.split()[0]),
-                     "sgpr": g("sgpr_count"), "vgpr_spill_count": g("vgpr_spill_count"), "sgpr_spill_count": g("sgpr_spill_count"),
-                     "scratch_bytes": g("private_segment_fixed_size"), "lds_bytes": g("group_segment_fixed_size")})
+        name = re.search(r"\.name:\s+(\S+)", b).group(1)
+        row = {"unit": tag, "kernel": name, "vgpr": g("vgpr_count"), "agpr": int(b.split()[0]),
+               "sgpr": g("sgpr_count"), "vgpr_spill_count": g("vgpr_spill_count"), "sgpr_spill_count": g("sgpr_spill_count"),
+               "scratch_bytes": g("private_segment_fixed_size"), "lds_bytes": g("group_segment_fixed_size")}
+        m = mix.get(name)
+        if m and sum(m.values()) > 1000:   # the sweep / chain kernels: long straight-line bodies, the static mix is the dynamic one to a few %
+            n = sum(m.values())
+            row["valu_static_mix"] = {k: round(v / n, 4) for k, v in sorted(m.items())}
+            row["valu_static_count"] = n
+            row["cycles_per_valu_inst_floor"] = round(sum(PRICE[k] * v for k, v in m.items()) / n, 3)
+        rows.append(row)
     return rows
 
 
@@ -55,7 +101,8 @@ def main():
     for r, d in zip(rows, demangle([r["kernel"] for r in rows])):
         r["kernel"] = d
     for r in rows:
-        print(f"{r['unit']:9s} {r['kernel'][:64]:64s} vgpr {r['vgpr']:3d} agpr {r['agpr']:3d} spills {r['vgpr_spill_count']:3d} scratch {r['scratch_bytes']:5d} B  lds {r['lds_bytes']:6d} B")
+        print(f"{r['unit']:9s} {r['kernel'][:64]:64s} vgpr {r['vgpr']:3d} agpr {r['agpr']:3d} spills {r['vgpr_spill_count']:3d} scratch {r['scratch_bytes']:5d} B  lds {r['lds_bytes']:6d} B"
+              + (f"  floor {r['cycles_per_valu_inst_floor']:.2f} cyc/VALU inst" if "cycles_per_valu_inst_floor" in r else ""))
     if args.json:
         sys.path.insert(0, ROOT)
         import bench

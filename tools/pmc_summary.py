@@ -50,10 +50,16 @@ def bench_line(name):
 counters = collections.defaultdict(float)
 meta = {}
 per_kernel_valu = collections.defaultdict(float)
+mix = collections.defaultdict(float)   # the pmc_mix pass counts SQ_INSTS_VALU again: kept apart so that no counter is summed twice
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    is_mix = os.sep + "pmc_mix" + os.sep in f
     for r in csv.DictReader(open(f)):
         for k in KERNELS:
             if k in r["Kernel_Name"]:
+                if is_mix:
+                    if k == KERNELS[0]:
+                        mix[r["Counter_Name"]] += float(r["Counter_Value"])
+                    continue
                 counters[r["Counter_Name"]] += float(r["Counter_Value"])
                 if r["Counter_Name"] == "SQ_INSTS_VALU":
                     per_kernel_valu[k] += float(r["Counter_Value"])
@@ -99,6 +105,26 @@ if "GRBM_GUI_ACTIVE" in counters and "SQ_INSTS_VALU" in counters and kstats:
     # cycles in which a SIMD's VALU is executing, at 4 cycles per wave-instruction
     if "SQ_ACTIVE_INST_VALU" in counters:
         out["valu_busy_pct"] = 100.0 * counters["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cycles
+if mix.get("SQ_INSTS_VALU"):
+    # dynamic mix of the dominant kernel: share of 64-bit integer VALU instructions (the multiplier v_mad_u64_u32, and
+    # v_lshl_add_u64 in the SHA-512 kernels); the floor prices that share at the multiplier's issue cost and the rest with the
+    # static mix of the code object (tools/kernel_meta.py: cycles per wave-instruction per SIMD with two waves resident,
+    # profiles/r03_ubench_valu_rates.txt)
+    out["valu_mix"] = {"int64_share": mix.get("SQ_INSTS_VALU_INT64", 0.0) / mix["SQ_INSTS_VALU"], "int32_share": mix.get("SQ_INSTS_VALU_INT32", 0.0) / mix["SQ_INSTS_VALU"]}
+    km_path = os.path.join(dst, "r04_kernel_meta.json")
+    if os.path.exists(km_path):
+        km = json.load(open(km_path))
+        row = next((r for r in km["kernels"] if KERNELS[0] in r["kernel"] and "valu_static_mix" in r), None)
+        if row and km.get("csrc_hash") == bench.csrc_hash():
+            price = {"mad64": 4.50, "full": 4.47, "bitop3": 3.34, "mov": 3.96, "fast": 2.47}
+            sm = dict(row["valu_static_mix"])
+            sm.pop("mad64", None)
+            rest = sum(sm.values())
+            rest_price = sum(price[k] * v for k, v in sm.items()) / rest if rest else price["full"]
+            share = out["valu_mix"]["int64_share"]
+            out["cycles_per_valu_inst_floor"] = share * price["mad64"] + (1.0 - share) * rest_price
+            out["cycles_per_valu_inst_floor_note"] = ("dynamic 64-bit share (SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU) at 4.50 cycles + the rest at the static mix of the code "
+                                                      "object (profiles/r04_kernel_meta.json) priced with profiles/r03_ubench_valu_rates.txt (two waves per SIMD)")
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters and keys_total:
     fetch, write = counters["FETCH_SIZE"] * 1024, counters["WRITE_SIZE"] * 1024
     out["hbm_fetch_bytes_raw"] = fetch

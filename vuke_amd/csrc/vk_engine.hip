@@ -589,10 +589,6 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     const u64 tile_inputs = (u64)VK_BLOCK * R;
     const u64 ntiles = span / tile_inputs + 1;
     u32 grid = (u32)std::min<u64>(ntiles, max_grid);
-    // an A/B variant whose sweep is two kernels (VK_SPLIT_PASS2) keeps every tile's items until the second kernel has read them
-    const bool split = (kind == VK_T_MILKSAD || kind == VK_T_MT64 || kind == VK_T_RAWKEYS) ? vk_sweep_split_g0()
-                       : (kind == VK_T_LCG || kind == VK_T_XORSHIFT)                      ? vk_sweep_split_g2()
-                                                                                           : vk_sweep_split_g1();
     // The workspace is one slice of B items per resident workgroup.  B >= slots, and slots grows with the chain depth of
     // sha256_chain (up to 8 * 4096): keep the allocation under 16 GiB by launching fewer workgroups (the tile counter hands
     // the same tiles to a smaller grid), and say what is wrong if even one workgroup does not fit.
@@ -608,7 +604,7 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
         }
         grid = (u32)std::min<size_t>(grid, fit);
     }
-    const size_t need = (split ? (size_t)ntiles : (size_t)grid) * per_wg;
+    const size_t need = (size_t)grid * per_wg;
     if (need > e->work_bytes) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         if (e->work) HIPCHK(e, hipFree(e->work));
@@ -644,7 +640,6 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     p.R = R;
     p.flags = flags;
     p.nwin = e->nwin;
-    p.ws_per_tile = split ? 1u : 0u;
     memcpy(p.wins, e->wins, sizeof p.wins);
     p.table = e->table;
     p.tgt = e->tgt;

@@ -29,15 +29,6 @@
 #define VK_F_EMIT 0x10000u /* internal: generate-mode records */
 
 #define VK_BLOCK 256
-// VK_SPLIT_PASS2 (one bounded experiment; NOT the shipped form): pass 1 + inversion and pass 2 as two
-// kernels.  vk_sweep_kernel then parks the inverse in the workspace and stops; vk_sweep_pass2_kernel, budgeted for 4 waves per
-// SIMD, walks the items backwards from it.  The workspace holds one slice per TILE instead of one per resident workgroup.
-#ifndef VK_SPLIT_PASS2
-#define VK_SPLIT_PASS2 0
-#endif
-#ifndef VK_PASS2_WAVES
-#define VK_PASS2_WAVES 4 /* waves per SIMD vk_sweep_pass2_kernel is register-budgeted for */
-#endif
 #ifndef VK_SWEEP_WAVES
 #define VK_SWEEP_WAVES 2 /* minimum waves per SIMD the sweep kernel is register-budgeted for */
 #endif
@@ -59,8 +50,7 @@ struct vk_sweep_params {
     u32 slots;      // slots per input
     u32 R;          // inputs per lane per tile
     u32 flags;
-    u32 nwin;
-    u32 ws_per_tile; // 1: the workspace slice is the tile's (VK_SPLIT_PASS2 builds), 0: the resident workgroup's
+    u32 nwin, pad1;
     u32 tgt_mask;   // capacity - 1 (power of two), valid when tgt != nullptr
     u32 hit_cap;
     u32 pad0;
@@ -296,9 +286,7 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
     // workspace of this workgroup: item b, quad q, lane t at wk[(b*8 + q) * VK_BLOCK] -- one contiguous
     // B * 32 KB region per workgroup (a few TLB entries), every access a fully coalesced 16 B per lane
     const u64 nth = VK_BLOCK;
-#if !VK_SPLIT_PASS2
     uint4 *wk = p.work + (u64)blockIdx.x * ((u64)B * 8 * VK_BLOCK) + tid;
-#endif
     __shared__ u64 s_tile;
     __shared__ uint4 s_gather[(VK_BLOCK / 64) * VK_LDS_DEPTH * VK_LTILE_FULL]; // whole-entry slots per wave (lds_gather_issue)
     uint4 *gtile = s_gather + (tid >> 6) * (VK_LDS_DEPTH * VK_LTILE_FULL);
@@ -312,9 +300,6 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
         __syncthreads();
         if (tile >= p.ntiles) break;
         const u64 tile_off = tile * ((u64)VK_BLOCK * p.R);
-#if VK_SPLIT_PASS2
-        uint4 *wk = p.work + tile * ((u64)B * 8 * VK_BLOCK) + tid;
-#endif
         // ---------------------------------------------------------------- pass 1
         fe c;
         u32 r = 0, sub = 0;
@@ -357,41 +342,16 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
         // ---------------------------------------------------------------- invert
         fe inv;
         fe_inv(inv, c);
-#if VK_SPLIT_PASS2
-        work_store(wk + (u64)(B - 1) * 8 * nth + 6 * nth, nth, inv); // the last running product has done its part: its place takes the inverse
-#else
         // ---------------------------------------------------------------- pass 2
+        // (as a kernel of its own, budgeted for 3 or 4 waves per SIMD, with every tile's items kept in HBM until it had read them,
+        // pass 2 made the Milksad sweep 4.8 % SLOWER and the sha256 scan 0 - 1.5 % slower, same box, three rounds each:
+        // profiles/r04_split_pass2_experiment.txt; the variant's last source is commit fe19f6c)
         sweep_pass2<KIND>(p, wk, B, tile_off, inv, r, sub, dg, n_keys, n_match);
-#endif
     }
     // ------------------------------------------------------------------- counters
     if (blockIdx.x == 0 && tid == 0) {
         p.stats[8] = __builtin_amdgcn_s_memtime() - clk0;
         p.stats[9] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
-#if !VK_SPLIT_PASS2
-    sweep_counters(p, dg, n_keys, n_match);
-#endif
-}
-
-#if VK_SPLIT_PASS2
-// pass 2 as a kernel of its own (experiment): one workgroup per tile, budgeted for 4 waves per SIMD
-template <u32 KIND>
-__global__ void __launch_bounds__(VK_BLOCK, VK_PASS2_WAVES) vk_sweep_pass2_kernel(const vk_sweep_params p)
-{
-    const u32 tid = threadIdx.x;
-    const u32 B = p.R * p.slots;
-    const u64 nth = VK_BLOCK;
-    __shared__ u64 s_dg[4 * VK_BLOCK];
-    u64 *dg = s_dg + tid;
-#pragma unroll
-    for (int i = 0; i < 4; i++) dg[i * VK_BLOCK] = 0;
-    u32 n_keys = 0, n_match = 0;
-    const u64 tile = blockIdx.x;
-    const uint4 *wk = p.work + tile * ((u64)B * 8 * VK_BLOCK) + tid;
-    fe inv;
-    work_load(inv, wk + (u64)(B - 1) * 8 * nth + 6 * nth, nth);
-    sweep_pass2<KIND>(p, wk, B, tile * ((u64)VK_BLOCK * p.R), inv, p.R, 0u, dg, n_keys, n_match);
     sweep_counters(p, dg, n_keys, n_match);
 }
-#endif

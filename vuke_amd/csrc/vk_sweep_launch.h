@@ -7,8 +7,3 @@ bool vk_launch_sweep_g0(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_
 bool vk_launch_sweep_g1(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s); // sha256, double_sha256, md5, direct
 bool vk_launch_sweep_g2(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s); // lcg, xorshift
 hipError_t vk_sweep_occupancy(int *blocks_per_cu);                                      // of the milksad instantiation
-// true when the group was built with -DVK_SPLIT_PASS2 (an A/B variant, tools/build_variant.sh): its launches are a pass-1 kernel
-// and a pass-2 kernel, and the workspace must hold one slice per tile
-bool vk_sweep_split_g0();
-bool vk_sweep_split_g1();
-bool vk_sweep_split_g2();

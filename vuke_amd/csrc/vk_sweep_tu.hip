@@ -12,9 +12,6 @@ template <u32 KIND>
 static void launch(const vk_sweep_params &p, u32 grid, hipStream_t s)
 {
     hipLaunchKernelGGL(vk_sweep_kernel<KIND>, dim3(grid), dim3(VK_BLOCK), 0, s, p);
-#if VK_SPLIT_PASS2
-    hipLaunchKernelGGL(vk_sweep_pass2_kernel<KIND>, dim3((u32)p.ntiles), dim3(VK_BLOCK), 0, s, p); // one workgroup per tile (experiment)
-#endif
 }
 
 #if VK_SWEEP_GROUP == 0
@@ -27,7 +24,6 @@ bool vk_launch_sweep_g0(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_
     default: return false;
     }
 }
-bool vk_sweep_split_g0() { return VK_SPLIT_PASS2 != 0; }
 hipError_t vk_sweep_occupancy(int *blocks_per_cu)
 {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, vk_sweep_kernel<VK_T_MILKSAD>, VK_BLOCK, 0);
@@ -43,9 +39,7 @@ bool vk_launch_sweep_g1(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_
     default: return false;
     }
 }
-bool vk_sweep_split_g1() { return VK_SPLIT_PASS2 != 0; }
 #elif VK_SWEEP_GROUP == 2
-bool vk_sweep_split_g2() { return VK_SPLIT_PASS2 != 0; }
 bool vk_launch_sweep_g2(u32 kind, const vk_sweep_params &p, u32 grid, hipStream_t s)
 {
     switch (kind) {
