@@ -105,7 +105,7 @@ def test_coalescer_lint_record_covers_the_kernel_sources_in_the_tree():
     import json
     import bench
     rec = json.load(open(os.path.join(ROOT, "profiles", "lint_coalescer.json")))
-    assert rec["dropped_outputs"] == 0 and rec.get("not_comparable", 0) == 0 and rec["asm_statements"] > 10000
+    assert rec["dropped_outputs"] == 0 and rec.get("not_comparable", 0) == 0 and rec["asm_statements"] > 8000
     assert rec["csrc_hash"] == bench.csrc_hash(), "kernel sources changed: re-run tools/lint_coalescer.py (about 4 minutes)"
 
 
