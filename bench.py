@@ -554,8 +554,19 @@ def main():
         sync()
         ts0 = time.perf_counter()
         g_bits = 26 if world == 1 else 24     # by measured wall time, profiles/r02_strong_geometry.txt: the big table cannot pay for itself inside one sweep
-        eng = vuke_amd.Engine(local_rank, window_bits=g_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=0)
+        try:
+            eng = vuke_amd.Engine(local_rank, window_bits=g_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=0)
+            created = 1
+        except vuke_amd.VkError as exc:   # the headline is already measured: a rank that cannot get the second table must not take the line down
+            print(f"bench.py: rank {rank}: no engine for the one-sweep run ({exc}); skipping it", file=sys.stderr)
+            eng, created = None, 0
+        (n_created,), _ = reduce_counters(dist, red_dev, [created], 0.0)
+        if n_created != world:
+            if eng is not None:
+                eng.close()
+            eng = None
         s_create = time.perf_counter() - ts0
+    if args.config == "2" and not args.strong and not args.no_strong_after and not args.emulate_gpus and w.nblocks % world == 0 and world <= w.nblocks and eng is not None:
         s_info = eng.info()
         w2 = Milksad(a2, rank, world)
         w2.setup(eng, ffi, wl)
@@ -696,7 +707,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out), flush=True)
 
-    eng.close()
+    if eng is not None:
+        eng.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -46,7 +46,7 @@ extern "C" {
                            vk_generate_columns / vk_derive_columns + vk_record_columns;
                            5: vk_engine_info_t gains runtime_init_seconds / alloc_seconds / table_wall_seconds; the vk_debug_*
                            test hooks leave this header and the shipped library (include/vuke_hip_test_hooks.h,
-                           libvuke_hip_hooks.so); electrum seeds of any length (was 448 bytes) */
+                           libvuke_hip_hooks.so); electrum seeds and multibit lines of any length (was 448 bytes: inputs_skipped is always 0) */
 
 /* error codes */
 #define VK_OK 0
@@ -173,9 +173,9 @@ int vk_engine_info(const vk_engine *e, vk_engine_info_t *out);
 /* Message for the last failing call on this engine (valid until the next call); e may be NULL
  * to read the message of a failed vk_engine_create. */
 const char *vk_last_error(const vk_engine *e);
-/* What the last SUCCESSFUL vk_transform_strings / vk_scan_strings call on this engine wants the caller to know (today: a
- * one-line "warning: N multibit line(s) longer than the device limit ..." when the reference would have produced keys for
- * inputs the device skipped); empty otherwise -- every such call clears it on entry.  Copied out under the engine's lock:
+/* What the last SUCCESSFUL vk_transform_strings / vk_scan_strings call on this engine wants the caller to know (ABI 3-4: a
+ * one-line "warning: N input string(s) longer than the device limit ..."; no such limit exists since ABI 5 and nothing sets a
+ * warning today); empty otherwise -- every such call clears it on entry.  Copied out under the engine's lock:
  * returns the message length, writes at most cap - 1 bytes and a NUL into buf (buf may be NULL to ask for the length). */
 size_t vk_last_warning(vk_engine *e, char *buf, size_t cap);
 
@@ -304,13 +304,12 @@ int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy /* n_files*32 */, size
 
 /* Transform::apply_batch for string inputs (Input::from_string; wordlist / stdin sources).  String i is
  * data[offsets[i] .. offsets[i+1]).  slots = vk_slots_per_string(t): the hash transforms (sha256, double_sha256, md5,
- * direct) and armory emit one key per string of any length, sha256_chain variants x depth, VK_T_ELECTRUM (seeds of any
- * length, as src/electrum.rs:57-78 hashes the whole slice; beyond 64 bytes on a slower one-lane path -- ABI 5) and
- * VK_T_MULTIBIT (lines up to 448 bytes) chain_depth keys; the PRNG transforms need a numeric seed and return
- * VK_E_UNSUPPORTED.  keys_out = n*slots*32, valid = n*slots, slot order = emit order.  A multibit line over the device limit
- * (a valid mnemonic is at most 24 words of at most 8 letters = 215 bytes with single blanks: only hundreds of redundant blanks
- * between the words get there) never aborts the batch: its slots stay invalid, the call returns VK_OK, it is counted in
- * vk_sweep_stats.inputs_skipped and vk_last_warning() holds a one-line "warning: N multibit line(s) ..." until the next call. */
+ * direct) and armory emit one key per string of any length, sha256_chain variants x depth, VK_T_ELECTRUM and VK_T_MULTIBIT
+ * chain_depth keys -- for strings of ANY length since ABI 5, as the reference hashes whatever it is given (src/electrum.rs:57-78,
+ * src/multibit.rs:87-101): an Electrum seed beyond 64 bytes and a MultiBit line beyond 448 bytes run on slower paths that read
+ * the caller's bytes (ABI 3-4 skipped strings over 448 bytes and reported them).  The PRNG transforms need a numeric seed and
+ * return VK_E_UNSUPPORTED.  keys_out = n*slots*32, valid = n*slots, slot order = emit order.  An input the reference skips (a
+ * non-hex seed, an unknown word, a wrong word count) has invalid slots; it never fails the batch. */
 int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
                          uint8_t *keys_out, uint8_t *valid);
 

@@ -407,22 +407,23 @@ def test_multibit_chain(eng, vko):
     ms = [" ".join(rnd.choice(words) for _ in range(n)) for n in (12, 15, 18, 21, 24) for _ in range(4)]
     ms += ["  " + ms[0].replace(" ", "\t", 2) + " \n", " ".join(words[:11]), " ".join(words[:12]) + " zzzzzzzzz", "", " ".join(words[:13]),
            " ".join(words[:11]) + " " + words[5][:-1]]
-    # the password is the string AS GIVEN: 12 words spread over 359 and 447 bytes (beyond the 256 of round 2, keys longer than one
-    # SHA-512 block are hashed first), one byte over the 448-byte staging limit (no keys, reported), a NUL inside a word
+    # the password is the string AS GIVEN, of any length (src/multibit.rs:87-101): 12 words spread over 359 and 447 bytes (keys longer
+    # than one SHA-512 block are hashed first, from the staging slice), 449 and ~1 300 bytes (beyond the slice: hashed from the input
+    # bytes -- rounds 2-3 reported such a line instead of deriving it), a NUL inside a word
     ms += [(" " * 25).join(words[100:112]), ("\t" * 33).join(words[100:112]), " ".join(words[:11]) + " " + words[11] + "\0"]
     ms[-2] = ms[-2] + " " * (447 - len(ms[-2]))
     ms.append(ms[-2] + "  ")
-    assert len(ms[-3]) == 447 and len(ms[-1]) == 449
+    ms.append((" " * 111).join(words[200:212]))
+    assert len(ms[-4]) == 447 and len(ms[-2]) == 449 and len(ms[-1]) > 1200
     got = eng.transform_strings(spec, [m.encode() for m in ms])
-    assert eng.last_warning().startswith("warning: 1 multibit line(s) longer")
+    assert eng.last_warning() == ""
     for m, row in zip(ms, got):
         exp = vko.multibit_keys(wl, m)
         want = [k for _, k in exp[2]] if exp else []
-        if len(m) > 448:
-            assert want and row == [None] * 20   # the reference would derive keys; the device reports the line instead (warning above)
-            continue
         assert [k for k in row if k is not None] == want, m
-    assert sum(1 for r in got for k in r if k is not None) == 23 * 20
+    st, _ = eng.scan_strings(spec, [m.encode() for m in (ms[-4], ms[-2], ms[-1])])    # 447, 449 and ~1 300 bytes
+    assert (st["inputs"], st["keys"], st["inputs_skipped"]) == (3, 60, 0)
+    assert sum(1 for r in got for k in r if k is not None) == 25 * 20
 
 
 def test_multibit_chain_stage_by_stage_against_hashlib(heng):

@@ -73,6 +73,11 @@ def test_multibit_prepare_stretch_and_repacking(emu):
         cases.append((" ".join(rnd.choice(words) for _ in range(n)), b""))
     cases.append(("  " + "\t\t".join(rnd.choice(words) for _ in range(12)) + " \n", b"TREZOR"))            # password = the string as given
     cases.append(((" " * 30).join(rnd.choice(words) for _ in range(12)), b"p" * 96))                        # key > 128 bytes, longest salt
+    # beyond the 448 bytes of the staging slice: the HMAC key is hashed from the input bytes (sha512_bytes); lengths around the slice
+    # limit and the SHA-512 block / padding boundaries (a 12-word mnemonic padded with blanks between and behind its words)
+    base = (" " * 33).join(rnd.choice(words) for _ in range(12))
+    for total in (448, 449, 495, 496, 511, 512, 623, 624, 1000, 3000):
+        cases.append((base + " " * (total - len(base)), b"pw"))
     bad = [" ".join(words[:11]), " ".join(words[:12]) + " zzzzzzzzz", " ".join(words[:11]) + " " + words[11][:-1], "",
            " ".join(words[:11]) + " " + words[11] + "\0", " ".join(words[:13])]
     out = emu([f"multibit {hx(m.encode())} {hx(p)}" for m, p in cases] + [f"multibit {hx(m.encode())} -" for m in bad])

@@ -22,11 +22,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function", "
 
 
 def demangle(names):
-    try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + names, capture_output=True, text=True, check=True).stdout.splitlines()
-        return [re.sub(r"\(.*", "", o) for o in out]
-    except Exception:
-        return names
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            out = subprocess.run([tool] + names, capture_output=True, text=True, check=True).stdout.splitlines()
+            if len(out) == len(names):
+                return [re.sub(r"\(.*", "", o) for o in out]
+        except Exception:
+            continue
+    return names
 
 
 # issue cost in cycles per wave-instruction per SIMD with two waves resident ("wall" column of profiles/r03_ubench_valu_rates.txt):

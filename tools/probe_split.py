@@ -4,7 +4,7 @@ block of config 2 (Milksad, compressed) and per 2^25-input block of config 3 (sh
 after one untimed block (a variant may size its workspace on first use).  Digests are printed so that two variants can be
 compared: they must be equal.
 
-    VUKE_HIP_LIB=vuke_amd/lib/variants/libvuke_hip_split.so python3 tools/probe_split.py [blocks=4]"""
+    VUKE_HIP_LIB=vuke_amd/lib/variants/libvuke_hip_split.so python3 tools/probe_split.py [blocks=4] [blocks_per_cu=2]"""
 import os
 import sys
 import time
@@ -15,7 +15,10 @@ from vuke_amd import _ffi as ffi
 import bench_workloads as wl
 
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-eng = vuke_amd.Engine(0, layout=1, batch=256, blocks_per_cu=2)
+bpc = int(sys.argv[2]) if len(sys.argv) > 2 else 2          # resident workgroups per CU the grid and the workspace are sized for
+# PROBE_GEOM="layout,window_bits,batch": another table geometry (default: the bench's nine signed windows, batch 256)
+geom = [int(x) for x in os.environ.get("PROBE_GEOM", "1,0,256").split(",")]
+eng = vuke_amd.Engine(0, layout=geom[0], window_bits=geom[1], batch=geom[2], blocks_per_cu=bpc)
 tag = os.path.basename(os.environ.get("VUKE_HIP_LIB", "shipped"))
 for name, spec, flags, log2, per in (("c2 milksad", ffi.spec(ffi.T_MILKSAD), 1, 28, 1), ("c3 sha256", ffi.spec(ffi.T_SHA256), 3, 25, 3)):
     if name.startswith("c3"):
@@ -33,6 +36,6 @@ for name, spec, flags, log2, per in (("c2 milksad", ffi.spec(ffi.T_MILKSAD), 1, 
         ks += st["kernel_seconds"]
         keys += st["keys"]
         dg = st["digest"]
-    print(f"{tag:32s} {name}: {keys / wall / 1e9:.4f} G keys/s wall, {keys / ks / 1e9:.4f} G keys/s kernel, {1e3 * wall / blocks:.2f} ms/block, "
+    print(f"{tag:32s} geom={geom} bpc={bpc} {name}: {keys / wall / 1e9:.4f} G keys/s wall, {keys / ks / 1e9:.4f} G keys/s kernel, {1e3 * wall / blocks:.2f} ms/block, "
           f"clock {st['shader_clock_ghz']:.3f} GHz, last digest {dg[0]:016x}", flush=True)
 eng.close()

@@ -95,7 +95,10 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_table_seed_kernel(uint4 *table, v
 
 // combine phase, persistent waves striding over the work items of all windows: item = (window, block of 64 low digits, run
 // of K high digits).  `ws` holds K x 2 rows of 64 uint4 per wave of the grid.
-__global__ void __launch_bounds__(VK_BLOCK) vk_table_combine_kernel(uint4 *table, vk_tbl_jobs jobs, uint4 *ws)
+#ifndef VK_TBL_WAVES
+#define VK_TBL_WAVES 3 /* 138 VGPRs with the inversion chain inlined: three waves per SIMD, no spills (128 for four would spill 10) */
+#endif
+__global__ void __launch_bounds__(VK_BLOCK, VK_TBL_WAVES) vk_table_combine_kernel(uint4 *table, vk_tbl_jobs jobs, uint4 *ws)
 {
     const u32 lane = threadIdx.x & 63u;
     const u32 wave = __builtin_amdgcn_readfirstlane((blockIdx.x * VK_BLOCK + threadIdx.x) >> 6);
@@ -138,8 +141,7 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_table_combine_kernel(uint4 *table
             my[(u64)k * 128] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
             my[(u64)k * 128 + 64] = make_uint4(c.v[4], c.v[5], c.v[6], c.v[7]);
         }
-        fe inv;
-        fe_inv(inv, c);
+        fe inv = fe_inv_chain(c); // inlined: the kernel's register budget covers it (as a call its 178 VGPRs set the kernel's occupancy)
         // backward: 1 / dx of step k = inv * (product before k); the addition; the entries of the step, 4 KB per wave
 #pragma unroll 1
         for (u32 kk = K; kk > 0; kk--) {

@@ -238,12 +238,41 @@ VK_DEV void hmac512_outer(u64 out[8], const u64 ost[8], const u64 inner[8])
 // PBKDF2-HMAC-SHA512 up to U1: key schedule of the staged password (RFC 2104: a key longer than the 128-byte block is
 // hashed first) and U1 = HMAC(salt || INT(1)), the salt message given as `salt_nblk` ready-padded blocks of big-endian
 // words (built on the host: "mnemonic" || passphrase || 00 00 00 01 || SHA-512 padding for 128 + len bytes).
-VK_DEV void pbkdf2_begin(u64 ist[8], u64 ost[8], u64 u1[8], const u64 *stage, u32 pwlen, const u64 *__restrict__ salt, u32 salt_nblk)
+// SHA-512 of `len` bytes read from the caller's input itself (any length, any alignment): the key of a password that does not
+// fit the staging slice.  Rare (a mnemonic line of more than VK_STAGE_MAX_STRING bytes), one byte load per message byte.
+VK_DEV void sha512_bytes(u64 st[8], const unsigned char *__restrict__ p, u32 len)
+{
+    const u32 nblk = (len + 17 + 127) / 128;
+#pragma unroll 1
+    for (u32 b = 0; b < nblk; b++) {
+        u64 w[16];
+#pragma unroll 1
+        for (u32 i = 0; i < 16; i++) {
+            u64 v = 0;
+            for (u32 j = 0; j < 8; j++) {
+                const u32 k = 128 * b + 8 * i + j;
+                const u64 byte = k < len ? p[k] : (k == len ? 0x80u : 0u);
+                v = (v << 8) | byte;
+            }
+            if (16 * b + i == 16 * nblk - 1) v |= (u64)len << 3;
+            w[i] = v;
+        }
+        sha512_compress(st, w);
+    }
+}
+
+#define VK_STAGE_MAX_STRING 448u /* bytes of a string the 512-byte staging slice holds with its SHA-512 padding */
+
+// pw_bytes: the password where the caller gave it, read instead of the staging slice when pwlen > VK_STAGE_MAX_STRING (may be
+// nullptr when the caller's strings always fit: the rebuilt mnemonics)
+VK_DEV void pbkdf2_begin(u64 ist[8], u64 ost[8], u64 u1[8], const u64 *stage, u32 pwlen, const u64 *__restrict__ salt, u32 salt_nblk,
+                         const unsigned char *__restrict__ pw_bytes = nullptr)
 {
     u64 key[16];
     if (pwlen > 128) {
         u64 st[8] = VK_SHA512_IV;
-        sha512_absorb_stage(st, stage, pwlen, 0);
+        if (pwlen > VK_STAGE_MAX_STRING) sha512_bytes(st, pw_bytes, pwlen);
+        else sha512_absorb_stage(st, stage, pwlen, 0);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             key[i] = st[i];

@@ -1270,18 +1270,16 @@ static int strings_to_device_keys(vk_engine *e, const vk_transform_spec *t, cons
                                   u32 **d_keys_out, unsigned char **d_valid_out, size_t *overlong, double *kernel_seconds)
 {
     const bool kdf = t->kind == VK_T_ELECTRUM || t->kind == VK_T_MULTIBIT;
-    // Electrum takes a seed of ANY length (src/electrum.rs:57-78 hashes the whole slice): beyond the register-resident 64 bytes
-    // a seed runs on the one-lane path that reads the caller's bytes.  MultiBit's password is the line as given and is staged in
-    // a 512-byte slice: a valid mnemonic has at most 24 words of at most 8 letters (215 bytes with single spaces), so only a line
-    // with more than ~230 redundant white-space characters BETWEEN its words (the sources trim the ends) can exceed the limit.
-    const u32 max_len = t->kind == VK_T_MULTIBIT ? VK_MULTIBIT_MAX_MNEMONIC : 0xFFFFFFFFu;
+    // No transform limits the length of a string: Electrum hashes the whole seed (src/electrum.rs:57-78; beyond the
+    // register-resident 64 bytes a seed runs on the one-lane path that reads the caller's bytes), MultiBit's password is the line
+    // as given (src/multibit.rs:87-101; beyond the 448 bytes of the staging slice its HMAC key is hashed from the caller's bytes).
+    // `overlong` stays in the interface and is always 0 since ABI 5.
     *overlong = 0;
     size_t n_long = 0; // electrum seeds beyond the register-resident fast path
     for (size_t i = 0; i < n; i++) {
         if (offsets[i + 1] < offsets[i]) return fail(e, VK_E_INVALID_ARG, "offsets must be non-decreasing");
         const u32 len = offsets[i + 1] - offsets[i];
         if (t->kind == VK_T_ELECTRUM && len > VK_ELECTRUM_FAST_SEED) n_long++;
-        if (len > max_len) (*overlong)++;
     }
     HIPCHK(e, hipSetDevice(e->device));
     const size_t bytes = offsets[n], items = n * slots;
@@ -1377,7 +1375,7 @@ chain_done:
 static void note_overlong(vk_engine *e, const vk_transform_spec *t, size_t overlong)
 {
     (void)t;
-    if (overlong) e->warn = "warning: " + std::to_string(overlong) + " multibit line(s) longer than the device limit (448 bytes) produced no keys";
+    if (overlong) e->warn = "warning: " + std::to_string(overlong) + " input string(s) produced no keys"; // unreachable since ABI 5: no length limits
 }
 
 extern "C" size_t vk_last_warning(vk_engine *e, char *buf, size_t cap)

@@ -20,7 +20,6 @@
 #pragma once
 #include "vk_chain.cuh"
 
-#define VK_MULTIBIT_MAX_MNEMONIC 448 /* bytes: the staging slice minus SHA-512 padding, rounded down */
 #define VK_MULTIBIT_MAX_PASS 96      /* "mnemonic" || passphrase || INT(1) stays inside one SHA-512 block */
 #define VK_BITIMAGE_MAX_PASS 256     /* three blocks */
 
@@ -74,8 +73,10 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_mb_prepare_kernel(const unsigned 
     ok_out[idx] = 0;
     const u32 len = offs[idx + 1] - offs[idx];
     const unsigned char *mn = data + offs[idx];
-    if (len > VK_MULTIBIT_MAX_MNEMONIC) return;
-    // ---- split_whitespace + validate_mnemonic; the password is the string as given
+    // ---- split_whitespace + validate_mnemonic; the password is the string as given, of ANY length (src/multibit.rs:87-101: the
+    // reference hashes what it is given): up to 448 bytes it is staged, a longer line -- a valid mnemonic is at most 24 words of
+    // at most 8 letters, so only hundreds of redundant blanks between the words get there -- is hashed from the input bytes
+    const bool staged = len <= VK_STAGE_MAX_STRING;
     u64 *stage = stage_all + idx * VK_STAGE_WORDS;
     vk_stage_writer wr;
     wr.init(stage);
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_mb_prepare_kernel(const unsigned 
     bool ok = true, nul = false;
     for (u32 i = 0; i <= len; i++) {
         const unsigned char c = i < len ? mn[i] : (unsigned char)' ';
-        if (i < len) wr.put(c, 1);
+        if (i < len && staged) wr.put(c, 1);
         if (mb_is_ws(c)) {
             if (wl) { // a word ends: in the list?  (no list word is longer than 8 bytes or holds a NUL byte)
                 nwords++;
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_mb_prepare_kernel(const unsigned 
     wr.finish();
     if (!ok || !(nwords == 12 || nwords == 15 || nwords == 18 || nwords == 21 || nwords == 24)) return;
     u64 ist[8], ost[8], u1[8];
-    pbkdf2_begin(ist, ost, u1, stage, len, salt, salt_nblk);
+    pbkdf2_begin(ist, ost, u1, stage, len, salt, salt_nblk, mn);
     pb_state_store(state, idx, ist, ost, u1);
     ok_out[idx] = 1;
 }

@@ -392,13 +392,10 @@ void Transform::apply_batch(vk_engine *e, const std::vector<std::string> &inputs
 {
     const uint32_t k = string_slots();
     if (inputs.empty() || k == 0) return; // k == 0: a transform that needs Input::u64_val pushes nothing
-    // a multibit line the device entry point cannot take (longer than 448 bytes: only a mnemonic padded with hundreds of
-    // redundant blanks between its words can be that long and valid) is reported, not silently dropped; electrum seeds have no limit
+    // strings of any length: no transform has a device limit any more (ABI 5)
     std::vector<uint8_t> data;
     std::vector<uint32_t> offs{0};
     for (const std::string &s : inputs) {
-        if (spec_.kind == VK_T_MULTIBIT && s.size() > 448u)
-            throw std::invalid_argument("input string too long for the device path (multibit: 448 bytes)");
         data.insert(data.end(), s.begin(), s.end());
         offs.push_back((uint32_t)data.size());
     }
