@@ -505,6 +505,9 @@ def main():
     full_after = w.full_sweep_steps() if (args.config == "2" and not args.emulate_gpus) else 0
     t_full = 0.0
     step_ms = []
+    import gc
+    gc.collect()
+    gc.disable()   # no collector pause inside the timed region (the steps allocate only small per-step records)
     sync()
     t0 = time.perf_counter()
     t_prev = t0
@@ -525,6 +528,7 @@ def main():
         digest = wl.fold_digests([digest, st["digest"]])
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
 
     # counters: one tiny all-reduce over RCCL (the only collective on this path)
     red_dev = dev if (not use_dist or args.backend == "nccl") else torch.device("cpu")
