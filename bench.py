@@ -20,7 +20,7 @@ Other configs under the same contract (inputs in bench_workloads
 end-to-end wall time from before the engine (table build) exists to after the counters are reduced.
 The default config-2 line carries that measurement too, as `strong`: AFTER the timed region (never inside it, never part of
 `value`; the 120 GB engine stays alive beside it) the same ranks share one whole 2^32 sweep on the geometry the product picks for a
-single sweep (43 GB W = 26 table on one GPU, 11.8 GB W = 24 from two), timed from before vk_engine_create to after the counter
+single sweep (ten signed windows = 18 GB on one GPU, eleven = 4 GB from two), timed from before vk_engine_create to after the counter
 all-reduce -- `strong.wall_s`, `covers_full_2p32: true` (--no-strong-after skips it).
 
 Every expected value comes from the CPU oracle through committed fixtures (tests/golden/): planted hash160s, the
@@ -433,8 +433,8 @@ def main():
         if args.strong:
             # ONE 2^32 sweep end to end: allocating and building the 120 GB table costs 0.4-5 s (hipMalloc of 120 GB varies
             # that much between boxes), more than it saves; by measured wall time (profiles/r02_strong_geometry.txt) the
-            # 43 GB W=26 table wins on one GPU and the 11.8 GB W=24 table from two GPUs up
-            args.layout, args.window_bits = 0, (26 if world_hint == 1 else 24)
+            # ten-window table wins on one GPU and the eleven-window table from two GPUs up
+            args.layout, args.window_bits = 1, (26 if world_hint == 1 else 24)   # signed windows: 18 GB / 4 GB (round 4; unsigned 43 / 11.8 GB before)
         else:
             args.layout, args.window_bits = 1, 0   # sustained throughput: 9 signed windows, 120 GB
     args.layout = args.layout or 0
@@ -560,9 +560,12 @@ def main():
         a2.strong = True
         sync()
         ts0 = time.perf_counter()
-        g_bits = 26 if world == 1 else 24     # by measured wall time, profiles/r02_strong_geometry.txt: the big table cannot pay for itself inside one sweep
+        # by measured wall time (profiles/r02_strong_geometry.txt) the big table cannot pay for itself inside one sweep: ten signed
+        # windows on one GPU (18 GB: the rate of the unsigned 26-bit table at 0.4 of its size, profiles/r04_signed_geometries.txt),
+        # eleven (4 GB) from two GPUs
+        g_bits = 26 if world == 1 else 24
         try:
-            eng = vuke_amd.Engine(local_rank, window_bits=g_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=0)
+            eng = vuke_amd.Engine(local_rank, window_bits=g_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=1)
             created = 1
         except vuke_amd.VkError as exc:   # the headline is already measured: a rank that cannot get the second table must not take the line down
             print(f"bench.py: rank {rank}: no engine for the one-sweep run ({exc}); skipping it", file=sys.stderr)
@@ -600,8 +603,8 @@ def main():
         if sm != se or sdb:
             print(f"bench.py: PARITY FAILURE in the one-sweep run: {sm} matches / {se} planted, {sdb} of {sdc} digests differ", file=sys.stderr)
             sys.exit(3)
-        strong_after = {"covers_full_2p32": sk == 1 << 32, "keys": sk, "blocks_per_rank": w2.step_total(), "window_bits": s_info["window_bits"],
-                        "table_gb": s_info["table_bytes"] / 1e9, "engine_create_s": s_create_max,
+        strong_after = {"covers_full_2p32": sk == 1 << 32, "keys": sk, "blocks_per_rank": w2.step_total(), "layout": s_info["layout"],
+                        "window_bits": s_info["window_bits"], "windows": s_info["windows"], "table_gb": s_info["table_bytes"] / 1e9, "engine_create_s": s_create_max,
                         "engine_create_split_rank0": {"hip_runtime_s": s_info["runtime_init_seconds"], "alloc_s": s_info["alloc_seconds"],
                                                       "table_build_s": s_info["table_build_seconds"], "table_wall_s": s_info["table_wall_seconds"]},
                         "targets_and_fixtures_s": s_setup_max, "sweep_s": s_sweep_max, "wall_s": s_wall, "keys_per_s_end_to_end": sk / s_wall,

@@ -128,14 +128,19 @@ typedef struct vk_engine vk_engine;
 
 /* table layouts */
 #define VK_LAYOUT_UNIFORM 0u
-#define VK_LAYOUT_SIGNED9 1u /* 9 signed-digit windows (4 x 29 + 5 x 28 bits): 8 additions per key, 120 GB table */
+#define VK_LAYOUT_SIGNED9 1u /* signed-digit windows: a digit above half its range is replaced by its negative (y negated on the fly)
+                                and a carry, so a window of b bits needs 2^(b-1) + 1 entries.  window_bits = 0 (or 29): the nine
+                                windows of the name (4 x 29 + 5 x 28 bits), 8 additions per key, 120 GB table.  ABI 5: any
+                                window_bits in 8..29 -> ceil(256 / window_bits) windows, e.g. 26 -> ten windows, 9 additions, 18.3 GB
+                                (the unsigned 26-bit table needs 43 GB for the same), 24 -> eleven windows, 10 additions, 4.0 GB */
 
 /* summation of the table points */
 #define VK_ALGO_CHAIN 0u /* one chain of additions: the first two table points in affine form, then an XYZZ accumulator */
 /* (1 was VK_ALGO_TREE in ABI versions 1-2: removed in round 3 -- vk_engine_create_ex answers VK_E_UNSUPPORTED) */
 
 typedef struct vk_engine_opts {
-    uint32_t window_bits;  /* fixed-base window width of the k*G table: 4..26 (0 = default 24: 11.8 GB) */
+    uint32_t window_bits;  /* fixed-base window width of the k*G table: 4..28 for the uniform layout (0 = default 24: 11.8 GB),
+                              8..29 for the signed layout (0 = 29: nine windows, 120 GB) */
     uint32_t batch;        /* keys per lane sharing one field inversion (0 = default 128; the workspace, 128 B x batch x
                               lanes, is allocated when the engine is created) */
     uint32_t blocks_per_cu;/* 256-thread workgroups per CU to launch (0 = what the sweep kernel's occupancy allows);

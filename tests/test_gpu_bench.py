@@ -64,7 +64,8 @@ def test_default_config_two_steps_digest_checked_against_the_oracle():
         assert 200 <= o["roofline"]["vgpr"] <= 256 and o["roofline"]["waves_per_simd"] == 2
     # the one-sweep run that follows the timed region: the whole 2^32 space on the geometry the product picks for it
     s = o["strong"]
-    assert s["covers_full_2p32"] is True and s["keys"] == 2**32 and s["window_bits"] == 26 and s["matches"] == 1026
+    assert s["covers_full_2p32"] is True and s["keys"] == 2**32 and s["matches"] == 1026
+    assert (s["layout"], s["window_bits"], s["windows"]) == (1, 26, 10) and 18 < s["table_gb"] < 18.5     # ten signed windows
     assert s["digests_checked_against_oracle"] == 16 and s["wall_s"] > s["sweep_s"] > 1.5 and s["wall_s"] < 12
     import bench_workloads as wl
     assert s["digest"] == wl.load_golden("milksad_2p32.json")["digest"]
@@ -128,7 +129,8 @@ def test_plain_gpus_2_starts_its_own_ranks():
     # the N-GPU line carries BOTH the sustained rate (value, 120 GB geometry -- here the fallback table, two ranks
     # share one card) and a full-sweep wall time the product would deliver: the two ranks share one 2^32 sweep on W = 24 tables
     s = o["strong"]
-    assert s["covers_full_2p32"] is True and s["keys"] == 2**32 and s["blocks_per_rank"] == 8 and s["window_bits"] == 24
+    assert s["covers_full_2p32"] is True and s["keys"] == 2**32 and s["blocks_per_rank"] == 8
+    assert (s["layout"], s["window_bits"], s["windows"]) == (1, 24, 11) and 3.9 < s["table_gb"] < 4.1        # eleven signed windows
     assert s["matches"] == 1026 and s["digests_checked_against_oracle"] == 16 and s["digest"] == g["digest"]
     assert s["wall_s"] >= s["sweep_s"] > 0 and s["wall_s"] >= s["engine_create_s"]
 

@@ -346,6 +346,63 @@ def test_signed_nine_window_layout(eng, vko):
     e.close()
 
 
+def test_signed_layout_of_any_width(eng, vko):
+    """Round 4: VK_LAYOUT_SIGNED9 takes window_bits 8..29 -> ceil(256 / W) signed-digit windows of floor / ceil(256 / windows) bits,
+    the last one unsigned with the inclusive top entry.  Window geometry, table entries through the test hooks (first / last entries,
+    the top entry 2^256 mod n, the builder's seams, random ones) and the product against the oracle: edge keys that drive the
+    recoding through every corner (digits exactly half, half + 1, all ones, carries into the top window) and sweep digests."""
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+    rnd = random.Random(77)
+    for W, batch in ((26, 64), (24, 16), (13, 8), (8, 4), (29, 32)):
+        nwin = -(-256 // W)
+        lo_bits, extra = divmod(256, nwin)
+        bits = [lo_bits + (1 if i < extra else 0) for i in range(nwin)]
+        offs = [sum(bits[:i]) for i in range(nwin)]
+        tbs = [b - 1 for b in bits[:-1]] + [bits[-1]]
+        assert sum(bits) == 256 and max(bits) <= W
+        if W == 29:
+            assert bits == [29] * 4 + [28] * 5      # the nine windows the layout is named after
+        h = vuke_amd.Engine(0, layout=ffi.LAYOUT_SIGNED9, window_bits=W, batch=batch, hooks=True)
+        info = h.info()
+        assert (info["layout"], info["windows"], info["window_bits"]) == (1, nwin, W)
+        assert info["table_bytes"] == sum((1 << tb) + 1 for tb in tbs) * 64
+        picks = [(i, d) for i in (0, 1, nwin // 2, nwin - 2, nwin - 1) for d in (1, 2, (1 << tbs[i]) - 1, 1 << tbs[i], 1 << (tbs[i] // 2), (3 << (tbs[i] // 2)) | 5)]
+        picks += [(i, rnd.randrange(1, (1 << tbs[i]) + 1)) for i in range(nwin) for _ in range(6)]
+        for i, d in picks:
+            k = d << offs[i]
+            if k >> 256:
+                assert i == nwin - 1 and d == 1 << tbs[i]
+                k %= N                                   # the top entry: 2^256 mod n
+            _, p65 = vko.pubkey(be(k))
+            x, y = h.table_entry(i, d)
+            assert x + y == p65[1:], (W, i, d)
+        assert h.table_entry(nwin // 2, 0) == (bytes(32), bytes(32))
+        h.close()
+        e = vuke_amd.Engine(0, layout=ffi.LAYOUT_SIGNED9, window_bits=W, batch=batch)     # the shipped library from here on
+        keys = [be(1), be(N - 1), be(N - 2), be(2**256 - 1), be(N), bytes(32), be(2**255), be(int("1" * 256, 2) >> 1), be(int("10" * 128, 2)), be(int("01" * 128, 2))]
+        for i in range(nwin):
+            half = 1 << (bits[i] - 1)
+            keys += [be((half << offs[i]) % N or 1), be(((half + 1) << offs[i]) % N or 1), be(((half - 1) << offs[i]) | 1), be((((1 << bits[i]) - 1) << offs[i]) % N or 1)]
+        keys += [be(rnd.getrandbits(256)) for _ in range(1500)]
+        norm, hc, hu = e.derive_batch(keys)
+        rn, rc, ru = eng.derive_batch(keys)          # default layout, itself checked against the oracle elsewhere
+        assert (norm, hc, hu) == (rn, rc, ru), W
+        for k, c, u in list(zip(keys, hc, hu))[:10 + 4 * nwin]:
+            assert (c, u) == vko.derive_h160(k), (W, k.hex())
+        st, _ = e.sweep(ffi.spec(ffi.T_MILKSAD), 1000, 2999, flags=3)
+        ost, _ = vko.sweep(vko.spec(vko.T_MILKSAD), 1000, 2999, flags=3, nthreads=8)
+        assert st["digest"] == ost["digest"] and st["keys"] == 2000, W
+        a, _ = e.sweep(ffi.spec(ffi.T_XORSHIFT), 7 * 10**9, 7 * 10**9 + 2**19 - 1, flags=3)
+        b, _ = eng.sweep(ffi.spec(ffi.T_XORSHIFT), 7 * 10**9, 7 * 10**9 + 2**19 - 1, flags=3)
+        assert a["digest"] == b["digest"] and a["keys"] == b["keys"] == 4 * 2**19, W
+        e.close()
+    with pytest.raises(vuke_amd.VkError):
+        vuke_amd.Engine(0, layout=ffi.LAYOUT_SIGNED9, window_bits=30)
+    with pytest.raises(vuke_amd.VkError):
+        vuke_amd.Engine(0, layout=ffi.LAYOUT_SIGNED9, window_bits=7)
+
+
 def test_electrum_strings_and_scan_keys(eng, vko):
     """Electrum v1 chain (100 000-round stretch, mpk, sequence, child keys) on the device."""
     from vuke_amd import _ffi as ffi

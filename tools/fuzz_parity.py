@@ -12,7 +12,8 @@ rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 vko.build()
 threads = min(16, len(os.sched_getaffinity(0)))
 engines = [vuke_amd.Engine(0), vuke_amd.Engine(0, layout=1, batch=256, blocks_per_cu=2), vuke_amd.Engine(0, window_bits=13, batch=24, blocks_per_cu=3),
-           vuke_amd.Engine(0, layout=1, batch=32, blocks_per_cu=2)]
+           vuke_amd.Engine(0, layout=1, batch=32, blocks_per_cu=2), vuke_amd.Engine(0, layout=1, window_bits=26, batch=96),
+           vuke_amd.Engine(0, layout=1, window_bits=11, batch=8, blocks_per_cu=1)]
 edges = [0, 2**31 - 1, 2**31, 2**32 - 1, 2**32, 2**63, 2**64 - 1, 10**9, 10**18]
 bad = 0
 t0 = time.time()

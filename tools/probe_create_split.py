@@ -1,7 +1,7 @@
 """Where vk_engine_create's wall time goes for the bench geometry (120 GB nine-window table, batch 256, 2 workgroups per CU):
 vk_engine_info's split -- HIP runtime start, the two large hipMallocs, the table kernels (hipEvent time and host wall).
 
-    python3 tools/probe_create_split.py [repeats=3] [layout=1] [window_bits=0]
+    python3 tools/probe_create_split.py [repeats=3] [layout=1] [window_bits=0]      (layout 1 = signed windows: 0 / 29 = nine, 26 = ten, 24 = eleven)
 
 Under rocprofv3 (tools/profile_create.sh) the same run gives the per-kernel times and PMC counters of the table builder."""
 import os
@@ -14,7 +14,7 @@ import vuke_amd
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 layout = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 wbits = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-kw = dict(layout=1, batch=256, blocks_per_cu=2) if layout == 1 else dict(window_bits=wbits)
+kw = dict(layout=1, window_bits=wbits, batch=256, blocks_per_cu=2) if layout == 1 else dict(window_bits=wbits)
 for r in range(reps):
     t = time.perf_counter()
     e = vuke_amd.Engine(0, **kw)

@@ -1,13 +1,20 @@
 // vk_ec.cuh -- secp256k1 group operations for gfx950 lanes.
 //
 // Fixed-base k*G with a precomputed table of (d * 2^off_w) * G affine points that lives in HBM (vk_win_desc below:
-// uniform W-bit windows -- library default W = 24, 11 windows, 11.8 GB -- or the 9 signed-digit windows of the bench
-// geometry, 4 x 29 + 5 x 28 bits, 120 GB of the 288 GB part).  One lane owns one key: one 64-byte table gather per
-// window and windows - 1 point additions, no doublings.  The sweep uses ecmult_table_lds_xyzz (XYZZ accumulator, entries
-// fetched by lane quads straight into LDS); ecmult_table / ecmult_table_coop / ecmult_table_lds are the Jacobian forms
-// kept for the small kernels and as A/B references.  Why no special cases are needed in any of them: with k normalised
-// to [1, n) the accumulator after windows 0..w-1 is s*G with |s| < 2^off_w, and the addend is t*G with |t| >= 2^off_w,
-// so s != +-t and |s + t| < n.
+// uniform W-bit windows -- library default W = 24, 11 windows, 11.8 GB -- or signed-digit windows: the 9 of the bench
+// geometry, 4 x 29 + 5 x 28 bits, 120 GB of the 288 GB part, or 10 / 11 narrower ones at 18 / 4 GB).  One lane owns one
+// key: one 64-byte table gather per window and windows - 1 point additions, no doublings.  The sweep uses
+// ecmult_table_lds_xyzz (XYZZ accumulator, entries fetched by lane quads straight into LDS); ecmult_table is the Jacobian
+// form with per-lane loads kept for the small kernels.
+//
+// Why no special cases are needed in the adders (P = +-Q never occurs): k is normalised to [1, n).  After windows 0..w-1 the
+// accumulator is s*G and window w adds T*G with T = t * 2^off_w, t != 0, where k's bits below off_w + bits_w equal s + T as
+// INTEGERS.  Unsigned windows: 0 <= s < 2^off_w <= T, so s != T, and s + T <= k < n, so s != -T (mod n).  Signed windows: a
+// digit above half its range is replaced by its negative and a carry, so |s| <= 2^(off_w - 1) + 2^(off_w - bits_{w-1}) < 2^off_w
+// <= |T| and the integers differ; modulo n they could only meet as s = T - n (or -T + n), i.e. n - |T| = |s| < 2^off_w, which
+// needs |T| > n - 2^off_w: only the last (unsigned) window reaches that far, with T = 2^256 (then k = s + T > n: not a
+// normalised key) or T = 2^256 - 2^off_w, where n - T = 2^off_w - (2^256 - n) > 2^(off_w - 1) + 2^(off_w - bits) because
+// 2^256 - n < 2^129 and off_w >= 200 in every layout the engine accepts (window_bits <= 29).
 //
 // Stands in for libsecp256k1's ecmult_gen reached from src/derive.rs:97 (reference).
 #pragma once

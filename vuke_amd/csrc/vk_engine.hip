@@ -242,24 +242,31 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
         return VK_E_NO_DEVICE;
     }
     e->cu_count = prop.multiProcessorCount;
-    if (opts && opts->window_bits) {
-        if (opts->window_bits < 4 || opts->window_bits > 28) return fail(e, VK_E_INVALID_ARG, "window_bits must be in 4..28");
-        e->W = opts->window_bits;
-    }
     if (opts && opts->layout > VK_LAYOUT_SIGNED9) return fail(e, VK_E_INVALID_ARG, "unknown table layout");
     e->layout = opts ? opts->layout : 0;
+    if (opts && opts->window_bits) {
+        const u32 lim = e->layout == VK_LAYOUT_SIGNED9 ? 29u : 28u;
+        if (opts->window_bits < (e->layout == VK_LAYOUT_SIGNED9 ? 8u : 4u) || opts->window_bits > lim)
+            return fail(e, VK_E_INVALID_ARG, e->layout == VK_LAYOUT_SIGNED9 ? "window_bits must be in 8..29 for the signed layout" : "window_bits must be in 4..28");
+        e->W = opts->window_bits;
+    } else if (e->layout == VK_LAYOUT_SIGNED9) {
+        e->W = 29;
+    }
     memset(e->wins, 0, sizeof e->wins);
     if (e->layout == VK_LAYOUT_SIGNED9) {
-        // 4 x 29 + 5 x 28 = 256 bits; windows 0..7 signed (2^(bits-1) + 1 entries), window 8 unsigned with the
-        // inclusive top entry: (4*2^28 + 4*2^27 + 2^28 + 9) * 64 B = 120 GB
-        e->nwin = 9;
-        e->W = 29;
+        // Signed-digit windows: ceil(256 / W) windows of floor / ceil(256 / windows) bits, all but the last signed (2^(bits-1) + 1
+        // entries); the last one unsigned with the inclusive top entry (it absorbs the final carry).  W = 29 (the default of this
+        // layout): 4 x 29 + 5 x 28 bits = nine windows, (4*2^28 + 4*2^27 + 2^28 + 9) * 64 B = 120 GB, 8 additions per key.  Since
+        // round 4 any W in 8..29: W = 26 -> ten windows (6 x 26 + 4 x 25 bits), 18.3 GB, 9 additions -- what the unsigned W = 26
+        // table does with 43 GB; W = 24 -> eleven windows, 4.0 GB, 10 additions like the default 11.8 GB table.
+        e->nwin = (256 + e->W - 1) / e->W;
+        const u32 lo_bits = 256 / e->nwin, extra = 256 % e->nwin;
         u32 off = 0;
         u64 base = 0;
-        for (u32 i = 0; i < 9; i++) {
+        for (u32 i = 0; i < e->nwin; i++) {
             vk_win_desc &w = e->wins[i];
-            w.bits = i < 4 ? 29 : 28;
-            w.sgn = i < 8 ? 1 : 0;
+            w.bits = lo_bits + (i < extra ? 1u : 0u);
+            w.sgn = i + 1 < e->nwin ? 1 : 0;
             w.tb = w.bits - w.sgn;
             w.off = off;
             w.base = base;

@@ -47,8 +47,9 @@ static int usage(const char *msg)
                     "  --device <N>         GPU index (default 0)\n"
                     "  --devices <LIST|all> several GPUs: a range source is cut into one contiguous block per GPU\n"
                     "  --window-bits <W>    k*G table window width (default 24)\n"
-                    "  --layout <L>         auto (default: signed9 for range sources of 2^30 inputs or more, else uniform) |\n"
-                    "                       uniform (11.8 GB table, 10 additions per key) | signed9 (120 GB table, 8 additions per key)\n");
+                    "  --layout <L>         auto (default: by the job's key count -- nine signed windows from 2^34 keys, ten from 2^31, else uniform) |\n"
+                    "                       uniform (11.8 GB table, 10 additions per key) | signed9 (120 GB table, 8 additions per key) |\n"
+                    "                       signed (with --window-bits W: ceil(256 / W) signed windows, e.g. 26 -> 18 GB, 9 additions)\n");
     return 2;
 }
 
@@ -304,9 +305,9 @@ int main(int argc, char **argv)
             else if (a == "--window-bits") window_bits = (unsigned)atoi(need("--window-bits"));
             else if (a == "--layout") {
                 const std::string l = need("--layout");
-                if (l != "auto" && l != "uniform" && l != "signed9") throw std::invalid_argument("--layout takes auto, uniform or signed9");
+                if (l != "auto" && l != "uniform" && l != "signed9" && l != "signed") throw std::invalid_argument("--layout takes auto, uniform, signed or signed9");
                 layout_auto = l == "auto";
-                layout = l == "signed9" ? VK_LAYOUT_SIGNED9 : VK_LAYOUT_UNIFORM;
+                layout = (l == "signed9" || l == "signed") ? VK_LAYOUT_SIGNED9 : VK_LAYOUT_UNIFORM; // signed + --window-bits W: ceil(256 / W) signed windows
             }
             else if (a == "range") have_range = true;
             else if (a == "wordlist") have_wordlist = true;
@@ -375,12 +376,16 @@ int main(int argc, char **argv)
         // (profiles/r02_strong_geometry.txt, profiles/r03_probe_c2_cli.txt): the 120 GB signed-window table sweeps a 2^32-key scan in
         // 2.6 s instead of 3.4 s, but allocating and releasing 120 GB costs 0.4 s on a quiet box and 2 - 6 s when the memory has just
         // been freed by another process (the driver scrubs VRAM), so it only pays from several sweeps' worth of keys on; in between
-        // the 43 GB W = 26 table (built in 0.1 s) is the fastest whole run; small jobs keep the 11.8 GB default.
+        // ten signed windows (18 GB, built in 15 ms; until round 4 the unsigned W = 26 table, 43 GB, at the same sweep rate) are the
+        // fastest whole run; small jobs keep the 11.8 GB default.
         if (layout_auto && window_bits == 0 && have_range) {
             long double keys = 0;
             for (const Transform &t : transforms) keys += (long double)(end - start) * (t.takes_strings() ? t.string_slots() : t.slots());
             if (keys >= 0x1p34L) layout = VK_LAYOUT_SIGNED9;
-            else if (keys >= 0x1p31L) opts.window_bits = 26;
+            else if (keys >= 0x1p31L) { // round 4: ten SIGNED windows (18 GB) sweep at the rate of the unsigned 26-bit table (43 GB)
+                layout = VK_LAYOUT_SIGNED9;
+                opts.window_bits = 26;
+            }
         }
         opts.layout = layout;
         // scan: the targets file is read and decoded on its own thread while the engines start (the HIP runtime's start and the table
@@ -426,8 +431,9 @@ int main(int argc, char **argv)
                     vk_engine_destroy(e);
                     e = nullptr;
                 }
-                fprintf(stderr, "9-window table unavailable (%s); using the default 24-bit uniform table\n", msgs[bad].c_str());
+                fprintf(stderr, "signed-window table unavailable (%s); using the default 24-bit uniform table\n", msgs[bad].c_str());
                 opts.layout = VK_LAYOUT_UNIFORM;
+                opts.window_bits = 0;
                 continue;
             }
             fprintf(stderr, "GPU engine unavailable (device %d): %s\n", devs[bad], msgs[bad].c_str());
