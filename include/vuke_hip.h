@@ -128,6 +128,7 @@ typedef struct vk_engine vk_engine;
 
 /* table layouts */
 #define VK_LAYOUT_UNIFORM 0u
+#define VK_LAYOUT_SIGNED 1u  /* = VK_LAYOUT_SIGNED9, the name of ABI 2-4 when nine windows were the only signed geometry */
 #define VK_LAYOUT_SIGNED9 1u /* signed-digit windows: a digit above half its range is replaced by its negative (y negated on the fly)
                                 and a carry, so a window of b bits needs 2^(b-1) + 1 entries.  window_bits = 0 (or 29): the nine
                                 windows of the name (4 x 29 + 5 x 28 bits), 8 additions per key, 120 GB table.  ABI 5: any

@@ -19,6 +19,7 @@ F_COMPRESSED, F_UNCOMPRESSED = 1, 2
 ADDR_P2PKH_C, ADDR_P2PKH_U, ADDR_P2WPKH = 0, 1, 2
 TARGET_P2PKH, TARGET_P2WPKH = 0, 1
 LAYOUT_UNIFORM, LAYOUT_SIGNED9 = 0, 1
+LAYOUT_SIGNED = LAYOUT_SIGNED9    # signed-digit windows of any width (window_bits 8..29; 0 = the nine windows the old name stands for)
 
 
 class TransformSpec(C.Structure):
