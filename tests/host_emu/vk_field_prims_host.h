@@ -21,6 +21,8 @@ static inline void emu_mad(u64 &d, u64 &c, u32 a, u32 b, u64 add)
     c = (u64)(t >> 64) & 1u;
 }
 static inline void emu_add_co(u32 &d, u64 &c, u32 x, u32 y) { const u64 t = (u64)x + y; d = (u32)t; c = t >> 32; }
+// low half of a pinned (counter, 0) pair (tools/gen_field.py, VK_GEN_PIN): the host is little-endian
+static inline u32 &emu_lo32(u64 &v) { return *reinterpret_cast<u32 *>(&v); }
 static inline void emu_addc_co(u32 &d, u64 &co, u32 x, u32 y, u64 ci) { const u64 t = (u64)x + y + (ci & 1u); d = (u32)t; co = t >> 32; }
 static inline void emu_sub_co(u32 &d, u64 &c, u32 x, u32 y) { c = x < y; d = x - y; }
 static inline void emu_subb_co(u32 &d, u64 &co, u32 x, u32 y, u64 ci) { const u64 s = (u64)y + (ci & 1u); const u64 b = (u64)x < s; d = (u32)((u64)x - s); co = b; }

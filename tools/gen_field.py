@@ -34,6 +34,12 @@ OUT_HOST = os.path.join(os.environ.get("VK_GEN_OUT_DIR", os.path.join(_ROOT, "te
 # and holds it to python integers on the edge operands of the GPU field test: the arithmetic of the generated code -- carry
 # accounting, flagged and exact paths, aliasing -- is checked on a machine without a GPU.  (Hardware hazards are not: those
 # are what the GPU tests and the coalescer lint are for.)
+# VK_GEN_PIN=1 (round 4 experiment): the carry counters of the even / odd columns live in the low halves
+# of two u64 variables pinned to physical register pairs ("+{v[2:3]}" / "+{v[4:5]}"), whose high halves stay zero: the pair
+# (counter, 0) a column starts from is then the pinned pair itself, and the nine `v_mov_b32 v, 0` per product that put a zero
+# next to a compiler-allocated counter become two `v_mov_b64 pair, 0` at the top of the product.
+PIN = os.environ.get("VK_GEN_PIN", "0") == "1"
+PIN_REG = {"cpe": 2, "cpo": 4}
 HOST = {}
 EMU = {"v_mad_u64_u32": "emu_mad", "v_add_co_u32": "emu_add_co", "v_addc_co_u32": "emu_addc_co", "v_sub_co_u32": "emu_sub_co",
        "v_subb_co_u32": "emu_subb_co", "v_cndmask_b32": "emu_cndmask", "v_add_u32": "emu_add", "v_mul_u32_u24": "emu_mul_u24",
@@ -56,6 +62,8 @@ def host_register(asm_text, body, exprs):
                 cpp.append("vcc")
             elif o == "s[100:101]":
                 cpp.append("emu_dead")
+            elif o in ("v%d" % PIN_REG["cpe"], "v%d" % PIN_REG["cpo"]):   # low half of a pinned counter pair
+                cpp.append("emu_lo32(%s)" % ("cpe" if o == "v%d" % PIN_REG["cpe"] else "cpo"))
             else:
                 cpp.append(o + ("ull" if (mn == "v_mad_u64_u32" and o == "0") else "u"))
         out.append(f"        {EMU[mn]}({', '.join(cpp)});")
@@ -87,14 +95,22 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, z
         ops_out.append((c, e))
 
     have_e, have_o = bool(prods_e), bool(prods_o)
+    cnt_e, cnt_o = f"cy[{ke}]", f"cy[{ko}]"      # what the carry-count instructions of the two columns write
     if have_e:
         out("=&v" if (zero_e or start_e) else "+v", f"acc[{ke}]")
-        if len(prods_e) > 1:
+        if PIN and (len(prods_e) > 1 or start_e):
+            out("+{v[%d:%d]}" % (PIN_REG["cpe"], PIN_REG["cpe"] + 1), "cpe")
+            cnt_e = "v%d" % PIN_REG["cpe"]
+        elif len(prods_e) > 1:
             out("=&v", f"cy[{ke}]")
     if have_o:
         out("=&v" if (zero_o or start_o) else "+v", f"acc[{ko}]")
-        if len(prods_o) > 1:
+        if PIN and (len(prods_o) > 1 or start_o):
+            out("+{v[%d:%d]}" % (PIN_REG["cpo"], PIN_REG["cpo"] + 1), "cpo")
+            cnt_o = "v%d" % PIN_REG["cpo"]
+        elif len(prods_o) > 1:
             out("=&v", f"cy[{ko}]")
+        if len(prods_o) > 1:
             out("=&s", "sc")
     used = []
     for (i, j) in prods_e + prods_o:
@@ -106,7 +122,7 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, z
         idx[nm] = base + n
         ops_in.append(("v", f"{nm[0]}.v[{nm[1]}]"))
     for st in (start_e, start_o):
-        if st:
+        if st and st not in idx:      # (pinned pairs are read-write outputs already)
             idx[st] = len(ops_out) + len(ops_in)
             ops_in.append(("v", st))
 
@@ -125,12 +141,14 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, z
             sd = r("sc") if no > 1 else "vcc"
             add = "0" if (zero_o and step == 0) else (r(start_o) if (start_o and step == 0) else r(f'acc[{ko}]'))
             body.append(f"v_mad_u64_u32 {r(f'acc[{ko}]')}, {sd}, {r((a_name, i))}, {r((a_name if same else b_name, j))}, {add}")
+        ce = cnt_e if cnt_e.startswith("v") else r(cnt_e) if cnt_e in idx else None
+        co = cnt_o if cnt_o.startswith("v") else r(cnt_o) if cnt_o in idx else None
         if step < ne and step > 0:
-            prev = "0" if step == 1 else r(f'cy[{ke}]')
-            body.append(f"v_addc_co_u32 {r(f'cy[{ke}]')}, vcc, 0, {prev}, vcc")
+            prev = "0" if step == 1 else ce
+            body.append(f"v_addc_co_u32 {ce}, vcc, 0, {prev}, vcc")
         if step < no and step > 0:
-            prev = "0" if step == 1 else r(f'cy[{ko}]')
-            body.append(f"v_addc_co_u32 {r(f'cy[{ko}]')}, {r('sc')}, 0, {prev}, {r('sc')}")
+            prev = "0" if step == 1 else co
+            body.append(f"v_addc_co_u32 {co}, {r('sc')}, 0, {prev}, {r('sc')}")
     # vcc hazard: if the odd column has a single product it would write vcc between the even
     # column's multiply and its carry add -> route it through a dead SGPR pair instead
     if no == 1 and ne > 1:
@@ -151,7 +169,10 @@ def gen_cols(name, prods_fn, same):
     sig = "const fe &a" if same else "const fe &a, const fe &b"
     L.append(f"// acc[k] = pair (limb k, limb k+1) of column k; returns limb 15 of the odd number\n")
     L.append(f"VK_DEV u32 {name}(u64 acc[15], {sig})\n{{\n")
-    L.append("    u32 cy[15];\n    vk_carry sc;\n    (void)sc;\n")
+    if PIN:
+        L.append("    u64 cpe = 0, cpo = 0; // (carry counter, 0) of the even / odd columns, pinned to v[2:3] / v[4:5]: the high halves stay zero\n    vk_carry sc;\n    (void)sc;\n")
+    else:
+        L.append("    u32 cy[15];\n    vk_carry sc;\n    (void)sc;\n")
     has_cy = [len(prods_fn(k)) > 1 for k in range(15)]   # columns with one product cannot overflow
     for ke in range(0, 15, 2):
         pe, po = prods_fn(ke), (prods_fn(ke + 1) if ke + 1 < 15 else [])
@@ -159,16 +180,20 @@ def gen_cols(name, prods_fn, same):
         for k in (ke, ke + 1):
             if k < 15:
                 zero[k] = not (k >= 2 and has_cy[k - 2])
+                pin = "cpe" if k % 2 == 0 else "cpo"
                 if not zero[k] and prods_fn(k):
                     # the counter pair (cy, 0) is a SOURCE of the column's first multiply-add, not its tied accumulator
-                    L.append(f"    const u64 cz{k} = (u64)cy[{k - 2}];\n")
-                    start[k] = f"cz{k}"
+                    if PIN:
+                        start[k] = pin
+                    else:
+                        L.append(f"    const u64 cz{k} = (u64)cy[{k - 2}];\n")
+                        start[k] = f"cz{k}"
                 elif not (zero[k] and prods_fn(k)):
-                    L.append(f"    acc[{k}] = {'0ull' if zero[k] else '(u64)cy[%d]' % (k - 2)};\n")
+                    L.append(f"    acc[{k}] = {'0ull' if zero[k] else (pin if PIN else '(u64)cy[%d]' % (k - 2))};\n")
         if pe or po:
             emit_pair(L, ke, pe, po, "a", "b", same, zero_e=zero.get(ke, False), zero_o=zero.get(ke + 1, False),
                       start_e=start.get(ke), start_o=start.get(ke + 1))
-    L.append(f"    return {'cy[13]' if has_cy[13] else '0u'};\n}}\n\n")
+    L.append(f"    return {('(u32)cpo' if PIN else 'cy[13]') if has_cy[13] else '0u'};\n}}\n\n")
     return "".join(L)
 
 
