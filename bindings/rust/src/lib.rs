@@ -1,4 +1,4 @@
-//! Bindings to `libvuke_hip.so` (`include/vuke_hip.h`, ABI version 4) and, behind the `vuke-source` feature, the
+//! Bindings to `libvuke_hip.so` (`include/vuke_hip.h`, ABI version 5) and, behind the `vuke-source` feature, the
 //! `HipRangeSource` that plugs the engine into vuke's `Source` seam (`src/source/mod.rs:23-31` of the reference).
 pub mod ffi;
 #[cfg(feature = "vuke-source")]
@@ -24,6 +24,12 @@ impl Engine {
     pub fn new(device: i32) -> Result<Self, String> {
         let mut e: *mut ffi::VkEngine = std::ptr::null_mut();
         check(std::ptr::null(), unsafe { ffi::vk_engine_create(device, &mut e) })?;
+        Ok(Engine(e))
+    }
+    /// An engine with a chosen table geometry (`vk_engine_create_ex`): e.g. `layout: 1, window_bits: 26` = ten signed windows, 18 GB.
+    pub fn with_opts(device: i32, opts: &ffi::VkEngineOpts) -> Result<Self, String> {
+        let mut e: *mut ffi::VkEngine = std::ptr::null_mut();
+        check(std::ptr::null(), unsafe { ffi::vk_engine_create_ex(device, opts, &mut e) })?;
         Ok(Engine(e))
     }
     pub fn last_warning(&self) -> String {

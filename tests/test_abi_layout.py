@@ -57,6 +57,62 @@ def test_rust_extern_block_lists_the_headers_functions():
     assert rs == hdr
 
 
+def _c_to_rust(ctype):
+    """Rust spelling of a C parameter / return type of include/vuke_hip.h (the subset the header uses)."""
+    t = re.sub(r"/\*.*?\*/", "", ctype, flags=re.S)
+    t = re.sub(r"\b[a-z_0-9]+\s*(\[[^\]]*\])?$", lambda m: "*" if m.group(1) else "", t.strip()) if re.search(r"[\w\]]$", t.strip()) and not re.fullmatch(
+        r"(const\s+)?(unsigned\s+)?[a-z_0-9]+(\s*\*+)?", t.strip()) else t
+    t = " ".join(t.replace("*", " * ").split())
+    base = {"int": "c_int", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "uint8_t": "u8", "char": "c_char", "double": "f64",
+            "void": "c_void", "vk_engine": "VkEngine"}
+    base.update(NAMES)
+    toks = t.split()
+    const = False
+    if toks and toks[0] == "const":
+        const, toks = True, toks[1:]
+    name, rest = toks[0], toks[1:]
+    out = base[name]
+    # every '*' adds a pointer level; `const` binds to what is left of it ("const char *const *" = *const *const c_char)
+    pending_const = const
+    for tok in rest:
+        if tok == "*":
+            out = ("*const " if pending_const else "*mut ") + out
+            pending_const = False
+        elif tok == "const":
+            pending_const = True
+    return out
+
+
+def test_rust_extern_block_types_equal_the_headers_types():
+    """Beyond names and argument counts: every parameter and return TYPE of the extern block is the Rust spelling of the header's C
+    type (a `*const` where the header says `const`, `usize` for `size_t`, `u64` for `uint64_t` ...).  The crate cannot be compiled
+    here; a wrong width or a dropped `const` would otherwise first show at a maintainer's link time -- or never."""
+    decl = re.findall(r"^((?:const\s+)?(?:int|uint32_t|size_t|void|char)\s*\**)\s*(vk_\w+)\(([^;]*?)\);", HDR, re.M | re.S)
+    ext = RS[RS.index('extern "C" {'):]
+    rs = {}
+    for name, args, ret in re.findall(r"pub fn (vk_\w+)\(([^)]*)\)(?:\s*->\s*([^;]+))?;", ext, re.S):
+        rs[name] = ([" ".join(a.split(":", 1)[1].split()) for a in args.split(",") if a.strip()], " ".join(ret.split()) if ret else "()")
+    checked = 0
+    for ret, name, args in decl:
+        args = re.sub(r"/\*.*?\*/", "", args, flags=re.S).strip()
+        want_args = []
+        if args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                m = re.fullmatch(r"(.*?)(\w+)(\s*\[[^\]]*\])?", a)          # type, parameter name, optional array suffix
+                ctype = m.group(1).strip() + (" *" if m.group(3) else "")
+                want_args.append(_c_to_rust(ctype))
+        want_ret = "()" if ret.strip() == "void" else _c_to_rust(ret)
+        assert name in rs, name
+        assert rs[name][0] == want_args, (name, rs[name][0], want_args)
+        assert rs[name][1] == want_ret, (name, rs[name][1], want_ret)
+        checked += len(want_args) + 1
+    assert checked > 150
+    # the translation itself, on the shapes the header uses
+    assert [_c_to_rust(t) for t in ("const uint8_t *", "uint8_t *", "const char *const *", "vk_engine **", "size_t *", "const vk_transform_spec *", "uint64_t", "int")] == [
+        "*const u8", "*mut u8", "*const *const c_char", "*mut *mut VkEngine", "*mut usize", "*const VkTransformSpec", "u64", "c_int"]
+
+
 def test_rust_constants_equal_the_headers_defines():
     for name, val in re.findall(r"pub const (VK_[A-Z0-9_]+): \w+ = (-?\w+);", RS):
         if name == "VK_ABI_VERSION":
