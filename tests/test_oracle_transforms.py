@@ -88,6 +88,31 @@ def test_mt64_vs_python(vko):
         assert vko.mt64_key(s) == exp, s
 
 
+def test_mt64_against_libstdcxx_mt19937_64(vko, tmp_path):
+    """A second reading of MT19937-64 that neither the oracle's nor the device's author wrote: libstdc++'s std::mt19937_64
+    (ISO C++ [rand.eng.mers], the same init_genrand64 seeding as rand_mt::Mt64::new, src/mt64.rs:15-20), compiled here with g++.
+    2 000 seeds x the first four outputs, little-endian (rand_core's fill_bytes order) = the 32-byte key."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = tmp_path / "mt64.cpp"
+    src.write_text("""#include <cstdint>
+#include <cstdio>
+#include <random>
+int main() { unsigned long long s; while (std::scanf("%llu", &s) == 1) { std::mt19937_64 g(s); for (int i = 0; i < 4; i++) { uint64_t v = g();
+    for (int b = 0; b < 8; b++) std::printf("%02x", (unsigned)((v >> (8 * b)) & 0xff)); } std::printf("\\n"); } }
+""")
+    exe = tmp_path / "mt64"
+    subprocess.run(["g++", "-O2", "-o", str(exe), str(src)], check=True)
+    rnd = random.Random(64)
+    seeds = SEEDS64 + [rnd.getrandbits(64) for _ in range(1500)] + [rnd.getrandbits(rnd.randrange(1, 64)) for _ in range(500)]
+    out = subprocess.run([str(exe)], input="\n".join(map(str, seeds)) + "\n", capture_output=True, text=True, check=True).stdout.split()
+    assert len(out) == len(seeds)
+    for s, h in zip(seeds, out):
+        assert vko.mt64_key(s).hex() == h, s
+
+
 def test_lcg_reference_kats(vko):
     # src/lcg.rs:135-174
     k = vko.lcg_key(1, 0)
