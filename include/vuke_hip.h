@@ -155,8 +155,10 @@ typedef struct vk_engine_opts {
 typedef struct vk_engine_info_t {
     int32_t device;
     uint32_t cu_count;
-    uint32_t window_bits;   /* W */
-    uint32_t windows;       /* ceil(256 / W) table lookups + (windows - 1) point additions per key */
+    uint32_t window_bits;   /* W: the width of the widest window of the table that was built.  Signed layout: windows are
+                               floor / ceil(256 / windows) bits wide, so several requests name one geometry (27 and 28 build the
+                               ten 26/25-bit windows of 26, 25 the eleven of 24) and the request's own number is not echoed */
+    uint32_t windows;       /* table lookups per key (ceil(256 / requested width)); windows - 1 point additions */
     uint32_t batch;         /* keys per lane per field inversion */
     uint32_t blocks_per_cu;
     uint32_t layout;

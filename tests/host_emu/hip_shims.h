@@ -34,6 +34,7 @@ static inline uint32_t emu_bitop3(uint32_t a, uint32_t b, uint32_t c, uint32_t t
     return r;
 }
 #define __builtin_amdgcn_alignbit(hi, lo, n) emu_alignbit32((hi), (lo), (n))
+#define __builtin_amdgcn_alignbyte(hi, lo, n) emu_alignbit32((hi), (lo), 8u * ((n) & 3u))
 #define __builtin_amdgcn_bitop3_b32(a, b, c, t) emu_bitop3((a), (b), (c), (t))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)

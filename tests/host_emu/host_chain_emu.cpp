@@ -155,19 +155,25 @@ int main(int argc, char **argv)
             pb_state_result(seed, state.data(), 0);
             print_words("seed", seed, 8);
         } else if (!strcmp(cmd, "electrum")) { // seed string (hex), rounds (decimal in a2): ok, stretched key
-            std::vector<unsigned char> data = x;
-            const u32 offs[2] = {0, (u32)x.size()};
+            // "rounds" or "rounds@k": the seed starts k bytes into the input buffer (the aligned-dword reads of the long path)
             const u32 rounds = (u32)atoi(a2);
+            const char *at = strchr(a2, '@');
+            const u32 shift = at ? (u32)atoi(at + 1) : 0u;
+            std::vector<unsigned char> data(shift, (unsigned char)'f');
+            data.insert(data.end(), x.begin(), x.end());
+            const u32 offs[2] = {shift, shift + (u32)x.size()};
             std::vector<u64> stage(VK_STAGE_WORDS);
             std::vector<u32> state(VK_EL_WORDS * 64, 0);
             unsigned char ok = 7;
-            data.push_back(0);
+            data.resize(data.size() + VK_STRING_SLACK, 0); // what the engine's device copy of the input carries behind the last string
             vk_electrum_prepare_kernel(data.data(), offs, 1, stage.data(), state.data(), &ok);
             printf("ok %u\n", ok);
             if (!ok) continue;
             vk_electrum_body::args a = {state.data(), 0, 0};
             if (rounds > 1) run_stretch<vk_electrum_body>(a, 1, rounds - 1, 37);
-            if (ok == 2) vk_electrum_long_kernel(data.data(), offs, 1, rounds, state.data(), &ok);
+            if (ok == 2) { // the host's loop over bounded launches (vk_engine.hip), with slices of 7 rounds so that a short run has many
+                for (u32 r = 0; r < rounds; r += 7) vk_electrum_long_kernel(data.data(), offs, 1, r, std::min(rounds, r + 7), rounds, state.data(), &ok);
+            }
             printf("x ");
             for (int i = 0; i < 8; i++) printf("%08x", state[64 * i]);
             printf("\n");

@@ -55,6 +55,31 @@ def test_shipped_library_exports_no_test_hooks(built):
     assert "getenv" not in eng_src
 
 
+def test_hooks_library_is_resolved_on_its_own(built, tmp_path):
+    """with VUKE_HIP_LIB naming an A/B variant that has no hooks twin, Engine(hooks=True) must fall back to the in-tree
+    hooks build instead of looking for variants/libvuke_hip_<name>_hooks.so; a twin beside the variant, or VUKE_HIP_HOOKS_LIB, wins."""
+    import shutil
+    import subprocess
+    import sys
+    in_tree = os.path.join(ROOT, "vuke_amd", "lib", "libvuke_hip_hooks.so")
+    variant = tmp_path / "libvuke_hip_x.so"
+    shutil.copy(os.path.join(ROOT, "vuke_amd", "lib", "libvuke_hip.so"), variant)
+
+    def resolved(env):
+        e = dict(os.environ, **env)
+        code = "from vuke_amd import _ffi; _ffi.load(hooks=True); print(_ffi.LIB_PATH); print(_ffi.HOOKS_LIB_PATH)"
+        out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, check=True, capture_output=True, text=True).stdout.split()
+        return out
+
+    assert resolved({"VUKE_HIP_LIB": str(variant)}) == [str(variant), in_tree]
+    twin = tmp_path / "libvuke_hip_x_hooks.so"
+    shutil.copy(in_tree, twin)
+    assert resolved({"VUKE_HIP_LIB": str(variant)}) == [str(variant), str(twin)]
+    other = tmp_path / "elsewhere_hooks.so"
+    shutil.copy(in_tree, other)
+    assert resolved({"VUKE_HIP_LIB": str(variant), "VUKE_HIP_HOOKS_LIB": str(other)}) == [str(variant), str(other)]
+
+
 def test_struct_layouts_match_header():
     import ctypes as C
     from vuke_amd import _ffi

@@ -354,7 +354,7 @@ def test_signed_layout_of_any_width(eng, vko):
     import vuke_amd
     from vuke_amd import _ffi as ffi
     rnd = random.Random(77)
-    for W, batch in ((26, 64), (24, 16), (13, 8), (8, 4), (29, 32)):
+    for W, batch in ((26, 64), (24, 16), (13, 8), (8, 4), (29, 32), (17, 8)):
         nwin = -(-256 // W)
         lo_bits, extra = divmod(256, nwin)
         bits = [lo_bits + (1 if i < extra else 0) for i in range(nwin)]
@@ -365,7 +365,10 @@ def test_signed_layout_of_any_width(eng, vko):
             assert bits == [29] * 4 + [28] * 5      # the nine windows the layout is named after
         h = vuke_amd.Engine(0, layout=ffi.LAYOUT_SIGNED9, window_bits=W, batch=batch, hooks=True)
         info = h.info()
-        assert (info["layout"], info["windows"], info["window_bits"]) == (1, nwin, W)
+        # a request that names another request's geometry (17 -> the sixteen 16-bit windows of 16; 27 and 28 -> the ten windows of 26)
+        # is reported with the width its widest window really has
+        assert (info["layout"], info["windows"], info["window_bits"]) == (1, nwin, max(bits))
+        assert (max(bits) == W) == (W != 17)
         assert info["table_bytes"] == sum((1 << tb) + 1 for tb in tbs) * 64
         picks = [(i, d) for i in (0, 1, nwin // 2, nwin - 2, nwin - 1) for d in (1, 2, (1 << tbs[i]) - 1, 1 << tbs[i], 1 << (tbs[i] // 2), (3 << (tbs[i] // 2)) | 5)]
         picks += [(i, rnd.randrange(1, (1 << tbs[i]) + 1)) for i in range(nwin) for _ in range(6)]

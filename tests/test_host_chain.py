@@ -123,6 +123,13 @@ def test_electrum_prepare_stretch_and_long_seeds(emu):
         assert out[2 * i] == ("ok 1" if len(s) <= 64 else "ok 2"), s
         assert out[2 * i + 1] == "x " + electrum_stretch(s, 150).hex(), s
     assert out[2 * len(seeds):] == ["ok 0", "ok 0", "ok 1", "x " + electrum_stretch(b"5" * 32, 1).hex()]
+    # round 5: the long path takes every word that lies inside the seed from the two aligned dwords around it and runs in slices
+    # of a bounded number of rounds (7 here): seeds that start 1..3 bytes into the buffer, lengths of every residue mod 4
+    rnd = random.Random(5)
+    cases = [(bytes(rnd.choice(b"0123456789abcdefABCDEF") for _ in range(n)), k) for k in (1, 2, 3, 5) for n in (65, 66, 67, 68, 119, 120, 121, 250, 997)]
+    out = emu([f"electrum {hx(s)} 23@{k}" for s, k in cases])
+    for i, (s, k) in enumerate(cases):
+        assert out[2 * i: 2 * i + 2] == ["ok 2", "x " + electrum_stretch(s, 23).hex()], (len(s), k)
 
 
 def test_ring_bookkeeping_with_one_worker(emu):

@@ -23,3 +23,10 @@ done
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$root/vuke_amd/lib/variants/libvuke_hip_$name.so" "${objs[@]}"
 echo "built libvuke_hip_$name.so"
+# the hooks twin (same sweep objects + the engine compiled with -DVK_TEST_HOOKS), so that tools which look inside an engine
+# (probe_ring.py, fuzz_geometries.py) measure the variant and not the shipped kernels
+if [ -f "$b/vk_engine_hooks.o" ]; then
+    objs[0]="$b/vk_engine_hooks.o"
+    "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$root/vuke_amd/lib/variants/libvuke_hip_${name}_hooks.so" "${objs[@]}"
+    echo "built libvuke_hip_${name}_hooks.so"
+fi

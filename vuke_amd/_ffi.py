@@ -9,7 +9,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvuke_hip.so")
 LIB_PATH = os.environ.get("VUKE_HIP_LIB") or LIB_PATH  # A/B runs of two builds of the same library (tools/), nothing else
-HOOKS_LIB_PATH = LIB_PATH[:-3] + "_hooks.so"          # the same sources built with -DVK_TEST_HOOKS (include/vuke_hip_test_hooks.h): tests / tools only
+# the same sources built with -DVK_TEST_HOOKS (include/vuke_hip_test_hooks.h): tests / tools only.  Resolved on its own: an explicit
+# VUKE_HIP_HOOKS_LIB, else the hooks build next to the library in use (tools/build_variant.sh links one beside every variant), else
+# the in-tree hooks build -- a variant without a hooks twin must not turn Engine(hooks=True) into an OSError
+_IN_TREE_HOOKS = os.path.join(_HERE, "lib", "libvuke_hip_hooks.so")
+HOOKS_LIB_PATH = os.environ.get("VUKE_HIP_HOOKS_LIB") or (LIB_PATH[:-3] + "_hooks.so" if os.path.exists(LIB_PATH[:-3] + "_hooks.so") else _IN_TREE_HOOKS)
 
 VK_OK = 0
 VK_E_NO_DEVICE, VK_E_HIP, VK_E_INVALID_ARG, VK_E_UNSUPPORTED, VK_E_NOMEM = -1, -2, -3, -4, -5

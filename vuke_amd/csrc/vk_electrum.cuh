@@ -13,7 +13,11 @@
 //   vk_ring_kernel<electrum>    99 999 rounds in chunks: only the 8 chaining words change, the tail stays in registers (hot)
 //   vk_electrum_long_kernel     the same rounds for seeds of more than 64 bytes -- ANY length, as the reference hashes the whole
 //                               slice (src/electrum.rs:57-78,150-168); such lines are rare: tail words read from the caller's
-//                               input bytes every round, one lane per seed (ceil((41 + len) / 64) compressions per round)   (cold)
+//                               input bytes every round, one lane per seed (ceil((41 + len) / 64) compressions per round), the
+//                               rounds cut into launches of a bounded number of compressions (x parked in the state between
+//                               them): a SHA-256 chain has no parallelism to give a wave, so a very long line costs what
+//                               100 000 x len / 64 serial compressions cost one lane (~3 us each) -- but no single dispatch
+//                               holds the GPU for more than about a second, and the process stays killable between them   (cold)
 //   vk_electrum_final_kernel    master * G, 20 sequence hashes, child keys                                         (cold, vk_chain_keys.cuh)
 #pragma once
 #include "vk_chain.cuh"
@@ -21,9 +25,18 @@
 #define VK_ELECTRUM_FAST_SEED 64 /* bytes: x || seed || padding then spans at most two SHA-256 blocks (register-resident tail) */
 
 // big-endian word i of seed || 0x80 || 0.. || 64-bit bit length of (prefix + len) bytes, read from the input bytes themselves
-// (any length, any alignment); `last` = index of the low word of the length field
+// (any length, any alignment); `last` = index of the low word of the length field.  A word that lies entirely inside the seed
+// comes from the two aligned dwords around it (v_alignbyte_b32 + byte swap): the second dword may reach up to three bytes
+// beyond the seed, which is why the device copy of the input carries VK_STRING_SLACK bytes behind the last string.
+#define VK_STRING_SLACK 8
 VK_DEV u32 electrum_tail_word_bytes(const unsigned char *__restrict__ seed, u32 i, u32 len, u32 last, u32 prefix)
 {
+    if (4 * i + 3 < len) {
+        const u64 a = (u64)(seed + 4 * (u64)i);
+        const u32 sh = (u32)a & 3u;
+        const u32 *p = reinterpret_cast<const u32 *>(a - sh);
+        return bswap32(__builtin_amdgcn_alignbyte(p[1], p[0], sh));
+    }
     u32 v = 0;
 #pragma unroll
     for (u32 j = 0; j < 4; j++) {
@@ -150,18 +163,21 @@ struct vk_electrum_body {
     }
 };
 
-// Seeds of more than 64 bytes, any length: x0 is in the state (the ring has meanwhile stretched it with a wrong tail: recomputed
-// from the input here).  One lane per such seed, all rounds in one go, every message word assembled from the caller's input bytes
-// (no staging slice: no length limit); launched only when the host saw one.
-__global__ void __launch_bounds__(VK_BLOCK) vk_electrum_long_kernel(const unsigned char *__restrict__ data, const u32 *__restrict__ offs, u64 n, u32 rounds,
-                                                                      u32 *__restrict__ state, unsigned char *__restrict__ ok)
+// Seeds of more than 64 bytes, any length.  One lane per such seed; rounds [r_begin, r_end) of the rounds_total the stretch has
+// (round 0 = x0 = SHA256(seed || seed), recomputed from the input: the state's copy was advanced by the ring with a harmless
+// tail), x parked in the state rows between launches, ok[] stays 2 until the last slice has run.  Every message word is assembled
+// from the caller's input bytes (no staging slice: no length limit); launched only when the host saw such a seed.
+#define VK_EL_LONG_BUDGET (1u << 17) /* SHA-256 compressions of one lane per launch: a few tenths of a second */
+__global__ void __launch_bounds__(VK_BLOCK) vk_electrum_long_kernel(const unsigned char *__restrict__ data, const u32 *__restrict__ offs, u64 n, u32 r_begin,
+                                                                      u32 r_end, u32 rounds_total, u32 *__restrict__ state, unsigned char *__restrict__ ok)
 {
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
     if (idx >= n || ok[idx] != 2) return;
     const u32 len = offs[idx + 1] - offs[idx];
     const unsigned char *seed = data + offs[idx];
+    u32 *s = state + (idx >> 6) * (VK_EL_WORDS * 64) + (idx & 63u);
     u32 x[8] = VK_SHA256_IV;
-    { // x0 again (the state's copy was advanced by the ring)
+    if (r_begin == 0) {
         const u32 mlen = 2 * len, nb0 = (mlen + 9 + 63) / 64;
 #pragma unroll 1
         for (u32 b = 0; b < nb0; b++) {
@@ -180,10 +196,14 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_electrum_long_kernel(const unsign
             }
             sha256_compress(x, w);
         }
+        r_begin = 1;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = s[64 * i];
     }
     const u32 nblk = (32 + len + 9 + 63) / 64, last = 16 * nblk - 9; // tail word index of the length field
 #pragma unroll 1
-    for (u32 r = 1; r < rounds; r++) {
+    for (u32 r = r_begin; r < r_end; r++) {
         u32 st[8] = VK_SHA256_IV;
 #pragma unroll 1
         for (u32 b = 0; b < nblk; b++) {
@@ -198,8 +218,7 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_electrum_long_kernel(const unsign
 #pragma unroll
         for (int i = 0; i < 8; i++) x[i] = st[i];
     }
-    u32 *s = state + (idx >> 6) * (VK_EL_WORDS * 64) + (idx & 63u);
 #pragma unroll
     for (int i = 0; i < 8; i++) s[64 * i] = x[i];
-    ok[idx] = 1;
+    if (r_end >= rounds_total) ok[idx] = 1;
 }

@@ -274,6 +274,9 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
             base += (1ull << w.tb) + 1;
         }
         e->table_entries = base;
+        // several requests name the same geometry (27 and 28 give the ten windows of 26, 25 the eleven of 24): the engine
+        // reports the width its widest window really has, so window_bits x windows always describes the table that was built
+        e->W = lo_bits + (extra ? 1u : 0u);
     } else {
         e->nwin = (256 + e->W - 1) / e->W;
         for (u32 i = 0; i < e->nwin; i++) {
@@ -1283,14 +1286,18 @@ static int strings_to_device_keys(vk_engine *e, const vk_transform_spec *t, cons
     // `overlong` stays in the interface and is always 0 since ABI 5.
     *overlong = 0;
     size_t n_long = 0; // electrum seeds beyond the register-resident fast path
+    u32 max_long = 0;  // the longest of them
     for (size_t i = 0; i < n; i++) {
         if (offsets[i + 1] < offsets[i]) return fail(e, VK_E_INVALID_ARG, "offsets must be non-decreasing");
         const u32 len = offsets[i + 1] - offsets[i];
-        if (t->kind == VK_T_ELECTRUM && len > VK_ELECTRUM_FAST_SEED) n_long++;
+        if (t->kind == VK_T_ELECTRUM && len > VK_ELECTRUM_FAST_SEED) {
+            n_long++;
+            max_long = std::max(max_long, len);
+        }
     }
     HIPCHK(e, hipSetDevice(e->device));
     const size_t bytes = offsets[n], items = n * slots;
-    SCRATCH(e, d_data, unsigned char *, 0, bytes);
+    SCRATCH(e, d_data, unsigned char *, 0, bytes + VK_STRING_SLACK); // aligned dword reads may reach a few bytes beyond the last string
     SCRATCH(e, d_offs, u32 *, 2, (n + 1) * 4);
     SCRATCH(e, d_keys, u32 *, 1, items * 32);
     SCRATCH(e, d_valid, unsigned char *, 4, items);
@@ -1358,8 +1365,16 @@ static int strings_to_device_keys(vk_engine *e, const vk_transform_spec *t, cons
         vk_electrum_body::args a = {d_state, 0, 0};
         const int rc = run_ring<vk_electrum_body>(e, groups, 100000u - 1u, 500, a);
         if (rc) return rc;
-        if (n_long) // seeds of more than 64 bytes: rare, stretched one lane each outside the ring
-            hipLaunchKernelGGL(vk_electrum_long_kernel, grid, block, 0, e->stream, d_data, d_offs, (u64)n, 100000u, d_state, d_ok);
+        if (n_long) {
+            // seeds of more than 64 bytes: rare, stretched one lane each outside the ring.  The rounds are cut so that no launch runs
+            // more than VK_EL_LONG_BUDGET compressions per lane: a megabyte of hex digits on one line is 1.6 x 10^9 serial
+            // compressions (the reference spends a minute on it, one lane of a GPU more than an hour) -- slow, but never ONE
+            // dispatch that cannot be told from a hung GPU, and a killed process gives the card back at the next boundary
+            const u32 nblk_max = (32 + max_long + 9 + 63) / 64, rounds = 100000u;
+            const u32 per = std::max(1u, VK_EL_LONG_BUDGET / nblk_max);
+            for (u32 r = 0; r < rounds; r += per)
+                hipLaunchKernelGGL(vk_electrum_long_kernel, grid, block, 0, e->stream, d_data, d_offs, (u64)n, r, std::min(rounds, r + per), rounds, d_state, d_ok);
+        }
         hipLaunchKernelGGL(vk_electrum_final_kernel, grid, block, 0, e->stream, (u64)n, t->variant, t->chain_depth, d_state, d_ok, d_stage, e->table, e->d_wins,
                            e->nwin, d_keys, d_valid);
     }
