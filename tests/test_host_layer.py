@@ -496,3 +496,65 @@ def test_line_reader_follows_rust_lines_and_trim(host, tmp_path):
     assert host.vkh_matcher_load(str(t).encode(), h160, kind, 4, C.byref(n)) == 1 and n.value == 1
     t.write_bytes(b"1BgGZ9tcN4rm9KBzDn7KprQz87SZ26SAMH\ncaf\xe9\n")
     assert host.vkh_matcher_load(str(t).encode(), h160, kind, 4, C.byref(n)) == -1
+
+
+def test_line_reader_batches_respect_the_device_bounds_and_the_references_cut_off(host, tmp_path):
+    """the stdin source (strict) hands out a group of 1000 lines only once the whole group is read and valid -- in as many
+    device batches as max_lines / max_bytes ask for, never more lines or bytes than that whatever the lines' lengths -- and a line
+    that is not UTF-8 loses exactly the lines of its own group (src/source/stdin.rs:45-60); the wordlist source drops the line
+    (src/source/wordlist.rs:33-36).  Until round 4 a strict batch grew to the next multiple of 1000 lines past both limits."""
+    host.vkh_line_batches.argtypes = [C.c_char_p, C.c_int, C.c_size_t, C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t]
+    rnd = random.Random(11)
+
+    def run(blob, strict, max_lines, max_bytes):
+        src, dst = tmp_path / "in.txt", tmp_path / "out.txt"
+        src.write_bytes(blob)
+        err = C.create_string_buffer(256)
+        rc = host.vkh_line_batches(str(src).encode(), strict, max_lines, max_bytes, str(dst).encode(), err, 256)
+        batches, cur = [], []
+        for ln in dst.read_bytes().split(b"\n")[:-1]:
+            if ln == b"--":
+                batches.append(cur)
+                cur = []
+            else:
+                cur.append(ln)
+        assert cur == []
+        return rc, err.value.decode(), batches
+
+    def lines(n, bad_at=None, longest=40):
+        out = [b"  w%06d-%s \t" % (i, bytes(rnd.choice(b"abcdefgh") for _ in range(rnd.randrange(0, longest)))) for i in range(n)]
+        if bad_at is not None:
+            out[bad_at] = b"caf\xe9"
+        return out
+
+    for n, bad_at, max_lines, max_bytes in ((3500, None, 1000, 1 << 20), (3500, 2700, 1000, 1 << 20), (3500, 2700, 300, 1 << 20), (3500, 2700, 7, 1 << 20),
+                                            (3500, 999, 64, 1 << 20), (3500, 1000, 64, 1 << 20), (2500, 2499, 100000, 4096), (2500, None, 100000, 100),
+                                            (1700, 1650, 100000, 1 << 30), (5, None, 2, 50), (0, None, 10, 10)):
+        raw = lines(n, bad_at)
+        blob = b"\n".join(raw) + (b"\n" if raw else b"") + b"\n\n   \n"       # empty / blank lines are skipped by both sources
+        good = [ln.strip() for ln in raw]
+        # strict (stdin): whole groups of 1000 before the invalid line, the error afterwards
+        rc, err, batches = run(blob, 1, max_lines, max_bytes)
+        want = good if bad_at is None else good[:bad_at - bad_at % 1000]
+        assert [ln for b in batches for ln in b] == want, (n, bad_at, max_lines, max_bytes)
+        assert (rc, err) == ((0, "") if bad_at is None else (1, "stream did not contain valid UTF-8"))
+        for b in batches:
+            assert 0 < len(b) <= max_lines and (len(b) == 1 or sum(map(len, b)) <= max_bytes)
+        # the wordlist source: the invalid line is dropped, nothing else
+        rc, err, batches = run(blob, 0, max_lines, max_bytes)
+        assert [ln for b in batches for ln in b] == [ln for i, ln in enumerate(good) if i != bad_at] and rc == 0
+        for b in batches:
+            assert 0 < len(b) <= max_lines and (len(b) == 1 or sum(map(len, b)) <= max_bytes)
+    # a line of many bytes inside a group: the group is cut around it, no batch but its own exceeds the byte limit
+    raw = [b"a" * 10] * 400 + [b"B" * 50000] + [b"c" * 10] * 800
+    rc, err, batches = run(b"\n".join(raw) + b"\n", 1, 512, 4096)
+    assert rc == 0 and [ln for b in batches for ln in b] == raw and max(len(b) for b in batches) <= 512
+    assert [len(b) for b in batches if sum(map(len, b)) > 4096] == [1]
+    # no final newline, CRLF line ends (trimmed like any white space)
+    rc, err, batches = run(b"one\r\ntwo\r\nthree", 1, 10, 100)
+    assert rc == 0 and batches == [[b"one", b"two", b"three"]]
+    # lines that straddle the reader's 8 MB reads
+    raw = [b"%07d" % i + b"z" * 990 for i in range(10500)]
+    for strict in (0, 1):
+        rc, err, batches = run(b"\n".join(raw) + b"\n", strict, 4000, 1 << 30)
+        assert rc == 0 and [ln for b in batches for ln in b] == raw and max(len(b) for b in batches) <= 4000

@@ -50,6 +50,19 @@ int vkh_segwit_decode(const char *hrp, const char *addr, int *ver, uint8_t *out,
 }
 void vkh_sha256(const uint8_t *p, size_t n, uint8_t out[32]) { sha256(p, n, out); }
 
+// the device batches the wordlist (strict = 0) / stdin (strict = 1) source cuts this file into: lines + "--" per batch into `out_path`;
+// returns 0, or 1 with the reader's error in err (the run ends with it after the batches written)
+int vkh_line_batches(const char *in_path, int strict, size_t max_lines, size_t max_bytes, const char *out_path, char *err, size_t err_cap)
+{
+    FILE *in = fopen(in_path, "rb"), *out = fopen(out_path, "wb");
+    if (!in || !out) return -1;
+    const std::string e = line_reader_batches(in, strict != 0, max_lines, max_bytes, out);
+    fclose(in);
+    fclose(out);
+    put(e, err, err_cap);
+    return e.empty() ? 0 : 1;
+}
+
 // what the wordlist / stdin sources make of one raw line: -2 = dropped (not UTF-8), else the length of the trimmed text in out
 int vkh_line_filter(const char *line, size_t n, char *out, size_t cap)
 {

@@ -104,21 +104,40 @@ public:
     // UTF-8 and returns the error; lines are handed to the transforms in batches of 1000 there, so the (fewer than 1000) lines
     // read since the last full batch are never processed.  The wordlist source drops such a line and goes on
     // (`filter_map(Result::ok)`, src/source/wordlist.rs:33-36).
+    //
+    // Strict mode therefore reads a whole group of 1000 lines (the reference's `batch`), checks it, and only then hands its lines
+    // out -- in as many device batches as the caller's limits ask for: a batch never exceeds max_lines (the device bound on
+    // lines x slots) nor the 4 GiB the C ABI's uint32 offsets can address, whatever the lines' lengths, and a line that is not
+    // UTF-8 still loses exactly the lines of its own group (until round 4 a batch grew to the next multiple of 1000).
     explicit LineReader(FILE *fp, bool strict = false) : fp_(fp), strict_(strict), buf_(8u << 20) {}
     bool failed() const { return failed_; }
-    // appends lines to `b` until it holds max_lines or max_bytes; false at end of input
+    const std::string &error() const { return err_; }
+    // appends lines to `b` until it holds max_lines or max_bytes (one line may exceed max_bytes on its own); false at end of input
     bool fill(LineBatch &b, size_t max_lines, size_t max_bytes)
     {
-        // strict mode: a batch ends only where the reference's batches of 1000 lines end (whatever limit cut it -- lines or bytes),
-        // so that a line that is not UTF-8 loses exactly the lines the reference never processes (src/source/stdin.rs:45-60)
-        auto full = [&]() { return (b.n() >= max_lines || b.data.size() >= max_bytes) && (!strict_ || accepted_ % 1000 == 0); };
-        while (!failed_ && !full()) {
+        for (;;) {
+            // ---- lines that are checked and waiting
+            while (ready_next_ < ready_.n()) {
+                const size_t len = ready_.offs[ready_next_ + 1] - ready_.offs[ready_next_];
+                const int a = admit(b, len, max_lines, max_bytes);
+                if (a < 0) return false;
+                if (a == 0) return true;
+                b.data.insert(b.data.end(), ready_.data.begin() + (std::ptrdiff_t)ready_.offs[ready_next_], ready_.data.begin() + (std::ptrdiff_t)ready_.offs[ready_next_ + 1]);
+                b.offs.push_back((uint32_t)b.data.size());
+                ready_next_++;
+            }
+            if (failed_ || eof_) return false;
+            if (b.n() >= max_lines || b.data.size() >= max_bytes) return true;
+            // ---- the next line of the input
             if (pos_ == len_) {
                 len_ = fread(buf_.data(), 1, buf_.size(), fp_);
                 pos_ = 0;
                 if (len_ == 0) {
-                    if (!line_.empty()) push(b);
-                    return false;
+                    if (!line_.empty()) take(b, line_.data(), line_.data() + line_.size(), max_lines, max_bytes);
+                    line_.clear();
+                    eof_ = true;
+                    if (strict_ && !failed_) publish(); // `if !batch.is_empty()` after the loop: the last, shorter group
+                    continue;
                 }
             }
             const char *p = buf_.data() + pos_, *e = buf_.data() + len_;
@@ -128,48 +147,109 @@ public:
                 pos_ = len_;
                 continue;
             }
+            pos_ = (size_t)(nl - buf_.data()) + 1;
             if (line_.empty()) {
-                push(b, p, nl);
+                take(b, p, nl, max_lines, max_bytes);
             } else {
                 line_.append(p, nl);
-                push(b);
+                take(b, line_.data(), line_.data() + line_.size(), max_lines, max_bytes);
+                line_.clear();
             }
-            pos_ = (size_t)(nl - buf_.data()) + 1;
         }
-        return !failed_;
     }
 
 private:
-    void push(LineBatch &b, const char *a, const char *e)
+    // lines held back: strict mode's group being read (`group_`) and the checked lines not yet handed out (`ready_`: a complete
+    // group, or in the other mode the one line that did not fit the batch it arrived in)
+    struct Lines {
+        std::vector<uint8_t> data;
+        std::vector<size_t> offs{0};
+        size_t n() const { return offs.size() - 1; }
+        void clear()
+        {
+            data.clear();
+            offs.assign(1, 0);
+        }
+        void add(const char *a, const char *e)
+        {
+            data.insert(data.end(), a, e);
+            offs.push_back(data.size());
+        }
+    };
+    static constexpr size_t kHardBytes = 0xFFFFFF00u; // one call's strings are addressed by uint32 offsets (include/vuke_hip.h)
+    // 1: the line goes into this batch; 0: the batch is full, the line waits; -1: no batch can ever take it
+    int admit(const LineBatch &b, size_t len, size_t max_lines, size_t max_bytes)
+    {
+        if (len > kHardBytes) {
+            failed_ = true;
+            err_ = "an input line of more than 4 GiB cannot be handed to the device";
+            return -1;
+        }
+        if (b.n() >= max_lines) return 0;
+        if (b.n() && b.data.size() + len > std::min(max_bytes, kHardBytes)) return 0;
+        return 1;
+    }
+    void publish()
+    {
+        std::swap(ready_, group_);
+        group_.clear();
+        ready_next_ = 0;
+    }
+    void take(LineBatch &b, const char *a, const char *e, size_t max_lines, size_t max_bytes)
     {
         if (!utf8_valid(a, (size_t)(e - a))) {
             if (!strict_) return; // .lines().filter_map(Result::ok): a line that is not UTF-8 is dropped
             failed_ = true;       // `line?`: the lines since the last batch of 1000 are lost with it
-            const size_t drop = std::min<size_t>(b.n(), (size_t)(accepted_ % 1000));
-            b.offs.resize(b.offs.size() - drop);
-            b.data.resize(b.offs.back());
-            accepted_ -= drop;
+            err_ = "stream did not contain valid UTF-8"; // io::Error of BufRead::lines(), src/source/stdin.rs:46
+            group_.clear();
             return;
         }
         trim_unicode(a, e);                           // str::trim(): Unicode White_Space, not only ASCII
         if (a == e) return;
-        b.data.insert(b.data.end(), a, e);
-        b.offs.push_back((uint32_t)b.data.size());
-        accepted_++;
-    }
-    void push(LineBatch &b)
-    {
-        push(b, line_.data(), line_.data() + line_.size());
-        line_.clear();
+        if (strict_) {
+            group_.add(a, e);
+            if (group_.n() == 1000) publish();
+            return;
+        }
+        if (admit(b, (size_t)(e - a), max_lines, max_bytes) == 1) {
+            b.data.insert(b.data.end(), a, e);
+            b.offs.push_back((uint32_t)b.data.size());
+        } else if (!failed_) { // rare: the line would carry the batch past what uint32 offsets address -- it opens the next one
+            ready_.clear();
+            ready_.add(a, e);
+            ready_next_ = 0;
+        }
     }
     FILE *fp_;
-    bool strict_, failed_ = false;
-    uint64_t accepted_ = 0; // lines handed out so far
+    bool strict_, failed_ = false, eof_ = false;
+    std::string err_;
+    Lines group_, ready_;
+    size_t ready_next_ = 0;
     std::vector<char> buf_;
     size_t pos_ = 0, len_ = 0;
     std::string line_; // a line that straddles two reads
 };
 } // namespace
+
+// test access (capi.cpp: vkh_line_batches): the batches the wordlist / stdin source would hand to the device for this input,
+// written one line per line with "--" between batches; returns the reader's error text (empty when it ended normally)
+std::string line_reader_batches(FILE *in, bool strict, size_t max_lines, size_t max_bytes, FILE *out)
+{
+    LineReader reader(in, strict);
+    LineBatch b;
+    bool more = true;
+    while (more) {
+        b.clear();
+        more = reader.fill(b, max_lines, max_bytes);
+        if (b.n() == 0) continue;
+        for (size_t i = 0; i < b.n(); i++) {
+            fwrite(b.data.data() + b.offs[i], 1, b.offs[i + 1] - b.offs[i], out);
+            fputc('\n', out);
+        }
+        fputs("--\n", out);
+    }
+    return reader.failed() ? reader.error() : std::string();
+}
 
 ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms, const Matcher *matcher, Output &output)
 {
@@ -202,7 +282,6 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
     uint32_t max_slots = 1;
     for (const Transform &t : transforms) max_slots = std::max(max_slots, t.string_slots());
     size_t max_lines = std::max<size_t>(1, std::min<size_t>(1u << 20, (1u << 27) / max_slots));
-    if (max_lines >= 1000) max_lines -= max_lines % 1000; // batches end where the reference's batches of 1000 end (strict mode's cut-off)
     // bytes per device batch (the CLI's knob, tests/test_golden.py cuts batches short with it; the library reads no environment)
     size_t batch_bytes = 256u << 20;
     if (const char *v = getenv("VUKE_HIP_BATCH_BYTES")) {
@@ -423,7 +502,7 @@ ProcessStats HipWordlistSource::process(const std::vector<Transform> &transforms
     }
     if (matcher)
         for (vk_engine *e : engines_) check_rc(e, vk_targets_set(e, nullptr, nullptr, 0));
-    if (reader.failed()) throw std::runtime_error("stream did not contain valid UTF-8"); // io::Error of BufRead::lines(), src/source/stdin.rs:46
+    if (reader.failed()) throw std::runtime_error(reader.error()); // io::Error of BufRead::lines(), src/source/stdin.rs:46 (or a line no batch can carry)
     return st;
 }
 

@@ -503,4 +503,7 @@ struct EngineError : std::runtime_error {
 void check_rc(vk_engine *e, int rc);
 std::string last_warning(vk_engine *e); // vk_last_warning of the last successful string call (empty = nothing to report)
 
+// test access to the line reader of the wordlist / stdin sources (source.cpp)
+std::string line_reader_batches(FILE *in, bool strict, size_t max_lines, size_t max_bytes, FILE *out);
+
 } // namespace vuke
