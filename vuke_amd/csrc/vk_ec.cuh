@@ -147,16 +147,30 @@ VK_DEV u32 window_digit(const u32 k[8], const vk_win_desc &wd, u32 &carry, bool 
     return neg ? (1u << wd.bits) - raw : raw;
 }
 
-// y = p - y for lanes with neg (y canonical and non-zero for table points)
+// y = p - y for lanes with neg (y canonical and non-zero for table points).
+// p - y = (2^256 - 1 - y) - (C - 1) with C = 2^256 - p = 2^32 + 977: the complement is a lane-masked XOR (plain VOP2, the fast
+// issue class), the subtraction of C - 1 = 0x1000003D0 touches limbs 0 and 1 and borrows beyond them only when the low 64 bits
+// of ~y are below C - 1 (one table point in 2^31: a divergent ripple).  ~y >= C because y < p, so the result is p - y itself,
+// canonical.  (Until round 4 this was a 256-bit subtraction p - y + eight selects: 40 instructions per window as compiled;
+// with the leaner address arithmetic of lds_gather_issue: -2 % instructions per key, +0.6 % keys/s same box, profiles/r05_lean_glue_experiment.txt.)
 VK_DEV void fe_cond_negate(fe &y, bool neg)
 {
-    const u32 pl[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    u64 bw = 0;
+    const u32 m = neg ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 d = (u64)pl[i] - y.v[i] - bw;
-        bw = (d >> 32) & 1;
-        y.v[i] = neg ? (u32)d : y.v[i];
+    for (int i = 0; i < 8; i++) y.v[i] ^= m;
+    const u32 s0 = m & 0x3D0u, s1 = m & 1u;
+    const u32 l0 = y.v[0], l1 = y.v[1];
+    y.v[0] = l0 - s0;
+    const u32 b0 = l0 < s0 ? 1u : 0u;
+    y.v[1] = l1 - s1 - b0;
+    if (l1 < s1 + b0) { // s1 + b0 <= 2: no wrap
+        u32 bw = 1u;
+#pragma unroll
+        for (int i = 2; i < 8; i++) {
+            const u32 t = y.v[i];
+            y.v[i] = t - bw;
+            bw = t < bw ? 1u : 0u;
+        }
     }
 }
 
@@ -179,17 +193,27 @@ VK_DEV void fe_cond_negate(fe &y, bool neg)
 typedef const void __attribute__((address_space(1))) *vk_gptr;
 typedef void __attribute__((address_space(3))) *vk_lptr;
 VK_DEV void lds_gather_reuse_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Address of round r = table + 64 * (entry of quad lane r) + 16 * (lane & 3): one DPP move (all lanes are written, so no old value
+// has to be prepared) and one v_mad_u64_u32 with the lane's loop-invariant table + 16 * (lane & 3) as the addend -- as compiled from
+// C++ it was a zeroing move, the DPP move, a 64-bit shift and a 64-bit add per round.  `slot` must be wave-uniform IN AN SGPR (the
+// kernel derives it from readfirstlane(threadIdx.x >> 6)): M0 then comes from the scalar unit instead of four v_readfirstlane.
+VK_DEV u64 table_entry_addr(u32 e, u64 tq)
+{
+    u64 a;
+    asm("v_mad_u64_u32 %0, vcc, %1, 64, %2" : "=v"(a) : "v"(e), "v"(tq) : "vcc");
+    return a;
+}
 VK_DEV void lds_gather_issue(uint4 *slot, const uint4 *__restrict__ table, u32 entry)
 {
-    const u32 q = threadIdx.x & 3u;
-    const u32 e0 = __builtin_amdgcn_update_dpp(0u, entry, 0x00, 0xF, 0xF, false);
-    const u32 e1 = __builtin_amdgcn_update_dpp(0u, entry, 0x55, 0xF, 0xF, false);
-    const u32 e2 = __builtin_amdgcn_update_dpp(0u, entry, 0xAA, 0xF, 0xF, false);
-    const u32 e3 = __builtin_amdgcn_update_dpp(0u, entry, 0xFF, 0xF, 0xF, false);
-    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e0 << 2) + q), (vk_lptr)(slot + 0 * VK_LTILE_ROUND), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e1 << 2) + q), (vk_lptr)(slot + 1 * VK_LTILE_ROUND), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e2 << 2) + q), (vk_lptr)(slot + 2 * VK_LTILE_ROUND), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((vk_gptr)(table + ((u64)e3 << 2) + q), (vk_lptr)(slot + 3 * VK_LTILE_ROUND), 16, 0, 0);
+    const u64 tq = (u64)(table + (threadIdx.x & 3u));
+    const u32 e0 = __builtin_amdgcn_mov_dpp(entry, 0x00, 0xF, 0xF, true);
+    const u32 e1 = __builtin_amdgcn_mov_dpp(entry, 0x55, 0xF, 0xF, true);
+    const u32 e2 = __builtin_amdgcn_mov_dpp(entry, 0xAA, 0xF, 0xF, true);
+    const u32 e3 = __builtin_amdgcn_mov_dpp(entry, 0xFF, 0xF, 0xF, true);
+    __builtin_amdgcn_global_load_lds((vk_gptr)table_entry_addr(e0, tq), (vk_lptr)(slot + 0 * VK_LTILE_ROUND), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((vk_gptr)table_entry_addr(e1, tq), (vk_lptr)(slot + 1 * VK_LTILE_ROUND), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((vk_gptr)table_entry_addr(e2, tq), (vk_lptr)(slot + 2 * VK_LTILE_ROUND), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((vk_gptr)table_entry_addr(e3, tq), (vk_lptr)(slot + 3 * VK_LTILE_ROUND), 16, 0, 0);
 }
 VK_DEV void lds_gather_read(fe &x, fe &y, const uint4 *slot)
 {

@@ -289,7 +289,8 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
     uint4 *wk = p.work + (u64)blockIdx.x * ((u64)B * 8 * VK_BLOCK) + tid;
     __shared__ u64 s_tile;
     __shared__ uint4 s_gather[(VK_BLOCK / 64) * VK_LDS_DEPTH * VK_LTILE_FULL]; // whole-entry slots per wave (lds_gather_issue)
-    uint4 *gtile = s_gather + (tid >> 6) * (VK_LDS_DEPTH * VK_LTILE_FULL);
+    // the wave's slot, as a scalar: the LDS-direct loads take their LDS address from M0
+    uint4 *gtile = s_gather + __builtin_amdgcn_readfirstlane(tid >> 6) * (VK_LDS_DEPTH * VK_LTILE_FULL);
 
 #pragma unroll 1
     for (;;) {
