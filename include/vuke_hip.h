@@ -291,7 +291,7 @@ int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words /* 16384 bytes */);
 
 /* BIP-39 passphrase of the multibit chain: salt = "mnemonic" || passphrase in both stretches (src/multibit.rs:87-101,
  * 165-168).  Empty by default -- MultibitTransform always passes "" (src/transform/multibit.rs:15-21); the multibit-hd
- * analyzer takes one (src/analyze/multibit.rs:47-52).  At most 96 bytes; stays set until changed. */
+ * analyzer takes one (src/analyze/multibit.rs:47-52).  Any length (96 bytes at most until round 5); stays set until changed. */
 int vk_multibit_passphrase_set(vk_engine *e, const uint8_t *passphrase, size_t len);
 
 /* BitimageTransform::apply_batch once the caller has reduced every file to its entropy = SHA-256(base64(file bytes))
@@ -300,8 +300,9 @@ int vk_multibit_passphrase_set(vk_engine *e, const uint8_t *passphrase, size_t l
  * (src/bitimage.rs:45-74,119-275), then `count` keys whose last path index is index, index + 1, ... as
  * BitimageTransform::derive_keys_for_passphrase walks increment_path_index (src/transform/bitimage.rs:71-97,
  * src/bitimage.rs:277-293).  path[i] = index | 0x80000000 for hardened components; depth = 0 is "m" (count copies of
- * the master key); depth <= 16.  Passphrases: n_pass >= 1 strings in pass_data[pass_offsets[j] .. pass_offsets[j+1]),
- * each at most 256 bytes (the single --bitimage-passphrase, possibly empty, or the lines of the passphrase wordlist).
+ * the master key); any depth (16 levels at most until round 5).  Passphrases: n_pass >= 1 strings in pass_data[pass_offsets[j] .. pass_offsets[j+1]),
+ * of any length (256 bytes at most until round 5; the single --bitimage-passphrase, possibly empty, or the lines of the
+ * passphrase wordlist).
  * keys_out = n_files * n_pass * count * 32 bytes in (file, passphrase, index) order; valid = one byte per key, 0 where
  * the reference emits nothing: any error of derive_path (parent key 0 or >= n, IL >= n, child key 0, last index
  * reaching 2^31) -- and every later index of that (file, passphrase), because the reference does not advance the path

@@ -7,6 +7,7 @@
  * (src/multibit.rs:171-200).  Pinned against hashlib in tests/test_oracle_hashes.py.
  */
 #include "vko.h"
+#include <stdlib.h>
 #include <string.h>
 
 static inline uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
@@ -289,8 +290,9 @@ void vko_pbkdf2_hmac_sha512(const uint8_t *pw, size_t pwlen, const uint8_t *salt
 {
     hmac512_ctx h;
     hmac512_init(&h, pw, pwlen);
-    uint8_t sbuf[512];
-    if (saltlen > sizeof sbuf - 4) saltlen = sizeof sbuf - 4;
+    /* salt || INT(block): any salt length (until round 5 a salt beyond 508 bytes was cut short without a word -- no caller had one) */
+    uint8_t sbuf_small[512], *sbuf = saltlen + 4 <= sizeof sbuf_small ? sbuf_small : (uint8_t *)malloc(saltlen + 4);
+    if (!sbuf) { memset(out, 0, outlen); return; }
     memcpy(sbuf, salt, saltlen);
     uint32_t blk = 1;
     size_t done = 0;
@@ -308,6 +310,7 @@ void vko_pbkdf2_hmac_sha512(const uint8_t *pw, size_t pwlen, const uint8_t *salt
         memcpy(out + done, t, take);
         done += take; blk++;
     }
+    if (sbuf != sbuf_small) free(sbuf);
 }
 
 /* ------------------------------------------------------------------ MD5 (RFC 1321)

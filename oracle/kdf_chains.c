@@ -139,16 +139,28 @@ int vko_multibit_keys(const char *const *wl, const uint8_t *mnemonic, size_t len
     return vko_multibit_keys_pass(wl, mnemonic, len, (const uint8_t *)"", 0, count, keys, valid, seed1_out, seed2_out);
 }
 
+static int vko_multibit_keys_salt(const char *const *wl, const uint8_t *mnemonic, size_t len, const uint8_t *salt, size_t saltlen, uint32_t count,
+                                  uint8_t *keys, uint8_t *valid, uint8_t seed1_out[64], uint8_t seed2_out[64]);
+
 /* The same with a BIP-39 passphrase: salt = "mnemonic" || passphrase for both stretches (src/multibit.rs:87-101,165-168);
  * the transform always passes "", the multibit-hd analyzer takes --passphrase (src/analyze/multibit.rs:47-52). */
 int vko_multibit_keys_pass(const char *const *wl, const uint8_t *mnemonic, size_t len, const uint8_t *pass, size_t passlen, uint32_t count,
                            uint8_t *keys, uint8_t *valid, uint8_t seed1_out[64], uint8_t seed2_out[64])
 {
-    uint8_t salt[8 + 256];
-    if (passlen > 256) return 0;
+    /* a passphrase of any length, as the reference takes it (round 5; 256 bytes at most before) */
+    uint8_t salt_small[8 + 256], *salt = passlen <= 256 ? salt_small : (uint8_t *)malloc(8 + passlen);
+    if (!salt) return 0;
     memcpy(salt, "mnemonic", 8);
-    memcpy(salt + 8, pass, passlen);
+    if (passlen) memcpy(salt + 8, pass, passlen);
     memset(valid, 0, count);
+    int rc = vko_multibit_keys_salt(wl, mnemonic, len, salt, 8 + passlen, count, keys, valid, seed1_out, seed2_out);
+    if (salt != salt_small) free(salt);
+    return rc;
+}
+
+static int vko_multibit_keys_salt(const char *const *wl, const uint8_t *mnemonic, size_t len, const uint8_t *salt, size_t saltlen, uint32_t count,
+                                  uint8_t *keys, uint8_t *valid, uint8_t seed1_out[64], uint8_t seed2_out[64])
+{
     /* split_whitespace + validate_mnemonic (:143-160) */
     size_t nwords = 0, i = 0;
     while (i < len) {
@@ -163,11 +175,11 @@ int vko_multibit_keys_pass(const char *const *wl, const uint8_t *mnemonic, size_
     if (!(nwords == 12 || nwords == 15 || nwords == 18 || nwords == 21 || nwords == 24)) return 0;
     /* NB the reference checks the count first; both are errors, so the order does not matter */
     uint8_t seed1[64], seed2[64], I[64];
-    vko_pbkdf2_hmac_sha512(mnemonic, len, salt, 8 + passlen, 2048, seed1, 64); /* password = the string as given */
+    vko_pbkdf2_hmac_sha512(mnemonic, len, salt, saltlen, 2048, seed1, 64); /* password = the string as given */
     char buggy[512];
     size_t bl = vko_multibit_buggy_mnemonic(wl, seed1, buggy, sizeof buggy);
     if (!bl) return 0;
-    vko_pbkdf2_hmac_sha512((const uint8_t *)buggy, bl, salt, 8 + passlen, 2048, seed2, 64);
+    vko_pbkdf2_hmac_sha512((const uint8_t *)buggy, bl, salt, saltlen, 2048, seed2, 64);
     if (seed1_out) memcpy(seed1_out, seed1, 64);
     if (seed2_out) memcpy(seed2_out, seed2, 64);
     vko_hmac_sha512((const uint8_t *)"Bitcoin seed", 12, seed2, 64, I); /* :242-254 */
@@ -349,19 +361,22 @@ uint32_t vko_bitimage_keys(const char *const *wl, const uint8_t entropy[32], con
                            uint32_t count, uint8_t *keys, uint8_t *valid)
 {
     char mn[512], cur[512], nxt[512];
-    uint8_t salt[8 + 1024], seed[64];
+    uint8_t seed[64];
     uint32_t emitted = 0;
     memset(valid, 0, count);
-    if (passlen > 1024 || strlen(path) >= sizeof cur - 16) return 0;
+    if (strlen(path) >= sizeof cur - 16) return 0;
     size_t ml = vko_bip39_mnemonic(wl, entropy, 32, mn, sizeof mn);
     if (!ml) return 0;
+    uint8_t *salt = (uint8_t *)malloc(8 + passlen); /* a passphrase of any length (1024 bytes at most until round 5) */
+    if (!salt) return 0;
     memcpy(salt, "mnemonic", 8);
-    memcpy(salt + 8, pass, passlen);
+    if (passlen) memcpy(salt + 8, pass, passlen);
     vko_pbkdf2_hmac_sha512((const uint8_t *)mn, ml, salt, 8 + passlen, 2048, seed, 64);
+    free(salt);
     snprintf(cur, sizeof cur, "%s", path);
     for (uint32_t i = 0; i < count; i++) {
-        uint32_t comps[64];
-        int depth = vko_bip32_parse_path(cur, comps, 64);
+        uint32_t comps[256]; /* more components than a 512-character path text can hold */
+        int depth = vko_bip32_parse_path(cur, comps, 256);
         if (depth < 0 || !vko_bip32_derive(seed, comps, depth, keys + 32 * i)) continue; /* Err(_) => continue: the path is NOT advanced */
         valid[i] = 1;
         emitted++;

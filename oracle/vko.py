@@ -352,8 +352,8 @@ def bip39_mnemonic(wl, entropy):
 
 def bip32_parse_path(path):
     """Component list (index | 0x80000000 when hardened) or a negative error code (-1 prefix, -2 index, -3 limit)."""
-    comps = (C.c_uint32 * 64)()
-    d = lib().vko_bip32_parse_path(path.encode() if isinstance(path, str) else path, comps, 64)
+    comps = (C.c_uint32 * 256)()
+    d = lib().vko_bip32_parse_path(path.encode() if isinstance(path, str) else path, comps, 256)
     return d if d < 0 else [comps[i] for i in range(d)]
 
 

@@ -123,7 +123,8 @@ int main(int argc, char **argv)
         } else if (!strcmp(cmd, "multibit")) { // mnemonic (hex), passphrase (hex): ok, seed1, the 48-word string, seed2
             std::vector<unsigned char> data = x;
             const u32 offs[2] = {0, (u32)x.size()};
-            u64 salt[VK_SALT_WORDS];
+            std::vector<u64> saltv((size_t)vk_salt_nblk(y.size()) * 16);
+            u64 *salt = saltv.data();
             const u32 nblk = vk_salt_blocks(salt, y.data(), y.size());
             std::vector<u64> stage(VK_STAGE_WORDS), state(VK_PB_WORDS * 64, 0);
             unsigned char ok = 7;
@@ -142,12 +143,14 @@ int main(int argc, char **argv)
             pb_state_result(seed, state.data(), 0);
             print_words("seed2", seed, 8);
         } else if (!strcmp(cmd, "bitimage")) { // entropy (32 bytes hex), passphrase (hex): mnemonic, seed
-            u64 salt[VK_SALT_WORDS];
+            std::vector<u64> saltv((size_t)vk_salt_nblk(y.size()) * 16);
+            u64 *salt = saltv.data();
             const u32 nblk = vk_salt_blocks(salt, y.data(), y.size());
             std::vector<u64> stage(VK_STAGE_WORDS), state(VK_PB_WORDS * 64, 0);
             alignas(8) unsigned char ent[32];
             memcpy(ent, x.data(), 32);
-            vk_bitimage_prepare_kernel(ent, 1, 1, wordlist.data(), salt, &nblk, stage.data(), state.data());
+            const u32 salt_off[2] = {0, 16 * nblk};
+            vk_bitimage_prepare_kernel(ent, 1, 1, wordlist.data(), salt, salt_off, stage.data(), state.data());
             printf("words %s\n", std::string((const char *)stage.data()).c_str());
             vk_pbkdf2_body::args a = {state.data(), 0, 0};
             run_stretch<vk_pbkdf2_body>(a, 1, 2047, 2047);

@@ -637,13 +637,12 @@ def test_multibit_passphrase(eng, vko):
     ms = [" ".join(rnd.choice(words) for _ in range(n)) for n in (12, 24, 18)]
     spec = ffi.spec(ffi.T_MULTIBIT, 0, 0, 4)
     try:
-        for pw in (b"TREZOR", b"p" * 96, b""):
+        # any length since round 5 (96 bytes at most before): one, two and many salt blocks, then back to a short one
+        for pw in (b"TREZOR", b"p" * 96, b"q" * 97, b"r" * 100, bytes(range(1, 256)) * 3, b"s", b""):
             eng.multibit_passphrase_set(pw)
             got = eng.transform_strings(spec, [m.encode() for m in ms])
             for m, row in zip(ms, got):
                 assert row == [k for _, k in vko.multibit_keys(wl, m, count=4, passphrase=pw)[2]], (pw, m)
-        with pytest.raises(Exception):
-            eng.multibit_passphrase_set(b"q" * 97)
     finally:
         eng.multibit_passphrase_set(b"")
 
@@ -1252,11 +1251,18 @@ def test_bitimage_chain(eng, vko):
                 assert [k for k in got[fi][pj] if k is not None] == want, (path, fi, pj)
                 nvalid = len(want)
                 assert all(k is not None for k in got[fi][pj][:nvalid]) and all(k is None for k in got[fi][pj][nvalid:])
-    # argument errors: path too deep, passphrase too long
-    with pytest.raises(vuke_amd.VkError):
-        eng.bitimage_keys(ents[:1], [b""], [0] * 17, 1)
-    with pytest.raises(vuke_amd.VkError):
-        eng.bitimage_keys(ents[:1], [b"x" * 257], [0], 1)
+    # passphrases of any length since round 5 (256 bytes at most before), mixed in one call
+    pws = [b"x" * 257, b"", b"y" * 356, bytes(range(1, 256)) * 9, b"z"]
+    got = eng.bitimage_keys(ents[:2], pws, [0x80000054, 0x80000000, 0], 2)
+    for fi, e in enumerate(ents[:2]):
+        for pj, pw in enumerate(pws):
+            assert [k for k in got[fi][pj] if k is not None] == [k for _, k in vko.bitimage_keys(wl, e, pw, "m/84'/0'/0", 2)], (fi, pj)
+    # a path of any depth since round 5 (16 levels at most before): 17 and 40 levels, hardened and normal mixed
+    for path in ("m/" + "/".join(str(i) + ("'" if i % 3 == 0 else "") for i in range(17)), "m/" + "/".join(str(7 * i) + ("'" if i % 2 else "") for i in range(40))):
+        got = eng.bitimage_keys(ents[:3], [b"", b"pw"], vko.bip32_parse_path(path), 2)
+        for fi, e in enumerate(ents[:3]):
+            for pj, pw in enumerate((b"", b"pw")):
+                assert [k for k in got[fi][pj] if k is not None] == [k for _, k in vko.bitimage_keys(wl, e, pw, path, 2)], (path, fi, pj)
     assert eng.bitimage_keys([], [b""], [0], 1) == []
 
 

@@ -72,7 +72,10 @@ def test_multibit_prepare_stretch_and_repacking(emu):
     for n in (12, 15, 24):
         cases.append((" ".join(rnd.choice(words) for _ in range(n)), b""))
     cases.append(("  " + "\t\t".join(rnd.choice(words) for _ in range(12)) + " \n", b"TREZOR"))            # password = the string as given
-    cases.append(((" " * 30).join(rnd.choice(words) for _ in range(12)), b"p" * 96))                        # key > 128 bytes, longest salt
+    cases.append(((" " * 30).join(rnd.choice(words) for _ in range(12)), b"p" * 96))                        # key > 128 bytes, one salt block
+    # round 5: a BIP-39 passphrase of any length (96 bytes at most before): around the block boundaries of the salt message
+    for pl in (97, 99, 100, 227, 228, 1000):
+        cases.append((" ".join(rnd.choice(words) for _ in range(12)), bytes(rnd.randrange(1, 256) for _ in range(pl))))
     # beyond the 448 bytes of the staging slice: the HMAC key is hashed from the input bytes (sha512_bytes); lengths around the slice
     # limit and the SHA-512 block / padding boundaries (a 12-word mnemonic padded with blanks between and behind its words)
     base = (" " * 33).join(rnd.choice(words) for _ in range(12))
@@ -97,7 +100,7 @@ def test_bitimage_prepare_and_stretch(emu):
     words = words2048()
     rnd = random.Random(13)
     lines, want = [], []
-    for p in (b"", b"x", b"q" * 100, b"z" * 229, b"s" * 256):     # one, two and three salt blocks
+    for p in (b"", b"x", b"q" * 100, b"z" * 229, b"s" * 256, b"t" * 257, b"u" * 355, b"v" * 356, b"w" * 5000):     # one, two, three ... forty salt blocks
         ent = bytes(rnd.randrange(256) for _ in range(32))
         bits = int.from_bytes(ent + hashlib.sha256(ent).digest()[:1], "big")
         mn = " ".join(words[(bits >> (11 * (23 - k))) & 0x7FF] for k in range(24))

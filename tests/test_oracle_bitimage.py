@@ -59,7 +59,7 @@ def test_bip39_published_vectors():
     assert m32 == "abandon " * 23 + "art"
     assert vko.bip39_mnemonic(wl, b"\xff" * 32) == "zoo " * 23 + "vote"
     # and the whole bitimage chain on that list against the standard-library transcription
-    for data, pw in ((b"hello world", b""), (b"hello world", b"secret"), (b"", b""), (b"test", b"x" * 200)):
+    for data, pw in ((b"hello world", b""), (b"hello world", b"secret"), (b"", b""), (b"test", b"x" * 200), (b"test", b"y" * 1025), (b"t", b"z" * 4000)):
         got = vko.bitimage_keys(wl, vko.bitimage_entropy(data), pw, "m/84'/0'/0'/0/0", 2)
         assert [k for _, k in got] == [pyref.bitimage_key(words, data, pw, comps_of(p)) for p in ("m/84'/0'/0'/0/0", "m/84'/0'/0'/0/1")]
 

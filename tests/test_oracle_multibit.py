@@ -71,7 +71,7 @@ def test_synthetic_wordlist_vs_python(vko):
         assert vko.multibit_buggy_mnemonic(wl, seed1) == buggy
         assert [k for _, k in got[2]] == keys
     # BIP-39 passphrase (multibit-hd analyzer, src/analyze/multibit.rs:47-52): salt = "mnemonic" || passphrase, both stretches
-    for pw in (b"TREZOR", b"x" * 96, "z\u00fc".encode()):
+    for pw in (b"TREZOR", b"x" * 96, "z\u00fc".encode(), b"y" * 257, bytes(range(1, 256)) * 5):     # any length (round 5)
         seed1, seed2, _, keys = py_multibit(words, cases[0], 3, pw)
         got = vko.multibit_keys(wl, cases[0], count=3, passphrase=pw)
         assert (got[0], got[1], [k for _, k in got[2]]) == (seed1, seed2, keys), pw

@@ -297,24 +297,28 @@ VK_DEV void pbkdf2_begin(u64 ist[8], u64 ost[8], u64 u1[8], const u64 *stage, u3
 }
 
 // Host side of pbkdf2_begin's salt argument: "mnemonic" || passphrase || INT(1) as the blocks the inner hash absorbs after
-// the ipad block -- big-endian words, SHA-512 padding for 128 + len bytes.  Returns the number of blocks (1 for passphrases
-// up to 96 bytes, at most 3 up to 256 bytes).
-#define VK_SALT_WORDS 48u
-static inline u32 vk_salt_blocks(u64 out[VK_SALT_WORDS], const unsigned char *pass, size_t pl)
+// the ipad block -- big-endian words, SHA-512 padding for 128 + len bytes.  A passphrase of any length (round 5; until then the
+// message had to fit 48 words: 96 bytes for multibit, 256 for bitimage): vk_salt_nblk blocks of 16 words each.
+static inline u32 vk_salt_nblk(size_t pl) { return (u32)((8 + pl + 4 + 17 + 127) / 128); }
+static inline u32 vk_salt_blocks(u64 *out /* 16 * vk_salt_nblk(pl) words */, const unsigned char *pass, size_t pl)
 {
-    unsigned char m[VK_SALT_WORDS * 8] = {0};
     const char *tag = "mnemonic";
-    for (int i = 0; i < 8; i++) m[i] = (unsigned char)tag[i];
-    for (size_t i = 0; i < pl; i++) m[8 + i] = pass[i];
     const size_t len = 8 + pl + 4;
-    m[len - 1] = 1;
-    m[len] = 0x80;
-    const u32 nblk = (u32)((len + 17 + 127) / 128);
-    const u64 bits = (128 + len) * 8;
-    for (int i = 0; i < 8; i++) m[nblk * 128 - 1 - i] = (unsigned char)(bits >> (8 * i));
-    for (u32 i = 0; i < VK_SALT_WORDS; i++) {
+    const u32 nblk = vk_salt_nblk(pl);
+    const u64 bits = (u64)(128 + len) * 8;
+    const size_t total = (size_t)nblk * 128;
+    for (size_t i = 0; i < total / 8; i++) {
         u64 w = 0;
-        for (int j = 0; j < 8; j++) w = (w << 8) | m[8 * i + j];
+        for (size_t j = 0; j < 8; j++) {
+            const size_t k = 8 * i + j;
+            unsigned char c = 0;
+            if (k < 8) c = (unsigned char)tag[k];
+            else if (k < 8 + pl) c = pass[k - 8];
+            else if (k == len - 1) c = 1;
+            else if (k == len) c = 0x80;
+            else if (k >= total - 8) c = (unsigned char)(bits >> (8 * (total - 1 - k)));
+            w = (w << 8) | c;
+        }
         out[i] = w;
     }
     return nblk;

@@ -154,12 +154,12 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_mb_final_kernel(u64 n, u32 count,
 }
 
 // ------------------------------------------------------------------------------------------------------ bitimage: final
-#define VK_BIP32_MAX_DEPTH 16
+// the path's components (bit 31 = hardened) come from HBM: any depth, as the reference's derive_path walks any Vec (src/bitimage.rs:76-116;
+// 16 levels in the kernel arguments until round 5)
 struct vk_bip32_path {
     u32 depth;
-    u32 comp[VK_BIP32_MAX_DEPTH]; // bit 31 = hardened
+    const u32 *comp;
 };
-
 
 __global__ void __launch_bounds__(VK_BLOCK) vk_bitimage_final_kernel(u64 n_items, const vk_bip32_path path, u32 count, const u64 *__restrict__ state,
                                                                        const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin,

@@ -42,6 +42,7 @@ struct vk_engine {
     u64 *d_wordlist = nullptr;     // BIP-39 list, 2048 x 8 bytes (vk_bip39_wordlist_set), then the same words as an open-addressed set
     u64 *d_mb_salt = nullptr;      // PBKDF2 salt message of the multibit chain, ready-padded blocks (vk_multibit_passphrase_set; "" by default)
     u32 mb_salt_nblk = 0;
+    size_t mb_salt_cap = 0; // words of d_mb_salt
     int ring_waves_per_simd = 0;   // resident worker waves per SIMD of the chain ring (occupancy query, once)
     int chain_stop = 99;           // vk_debug_chain_stop (test-hook build only; 99 = run every stage)
     u32 dbg_ring_chunk = 0, dbg_ring_wps = 0, dbg_ring_workers = 0; // vk_debug_ring_knobs (test-hook build only; 0 = library's choice)
@@ -1208,11 +1209,19 @@ extern "C" int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words)
 
 static int set_mb_salt(vk_engine *e, const uint8_t *pass, size_t len)
 {
-    u64 w[VK_SALT_WORDS];
-    const u32 nblk = vk_salt_blocks(w, pass, len);
+    std::vector<u64> w((size_t)vk_salt_nblk(len) * 16);
+    const u32 nblk = vk_salt_blocks(w.data(), pass, len);
     HIPCHK(e, hipSetDevice(e->device));
-    if (!e->d_mb_salt) HIPCHK(e, hipMalloc(&e->d_mb_salt, sizeof w));
-    HIPCHK(e, hipMemcpy(e->d_mb_salt, w, sizeof w, hipMemcpyHostToDevice));
+    if (e->d_mb_salt && e->mb_salt_cap < w.size()) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        HIPCHK(e, hipFree(e->d_mb_salt));
+        e->d_mb_salt = nullptr;
+    }
+    if (!e->d_mb_salt) {
+        e->mb_salt_cap = std::max<size_t>(w.size(), 48);
+        HIPCHK(e, hipMalloc(&e->d_mb_salt, e->mb_salt_cap * 8));
+    }
+    HIPCHK(e, hipMemcpy(e->d_mb_salt, w.data(), w.size() * 8, hipMemcpyHostToDevice));
     e->mb_salt_nblk = nblk;
     return VK_OK;
 }
@@ -1222,7 +1231,6 @@ extern "C" int vk_multibit_passphrase_set(vk_engine *e, const uint8_t *passphras
     if (!e) return VK_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(e->mu);
     if (len && !passphrase) return fail(e, VK_E_INVALID_ARG, "passphrase is NULL");
-    if (len > VK_MULTIBIT_MAX_PASS) return fail(e, VK_E_UNSUPPORTED, "multibit passphrase longer than 96 bytes");
     return set_mb_salt(e, passphrase, len);
 }
 
@@ -1632,24 +1640,28 @@ extern "C" int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy, size_t n_f
     if (!e->d_wordlist) return fail(e, VK_E_INVALID_ARG, "bitimage needs the BIP-39 word list: call vk_bip39_wordlist_set first");
     if (n_files == 0 || count == 0) return VK_OK;
     if (!entropy || !pass_offsets || !keys_out || !valid || n_pass == 0) return fail(e, VK_E_INVALID_ARG, "entropy / pass_offsets / keys_out / valid is NULL or n_pass is 0");
-    if (depth > VK_BIP32_MAX_DEPTH) return fail(e, VK_E_UNSUPPORTED, "derivation path deeper than 16 levels");
+    if (depth > (1u << 20)) return fail(e, VK_E_INVALID_ARG, "derivation path of more than 2^20 levels");
     if (depth && !path) return fail(e, VK_E_INVALID_ARG, "path is NULL");
     for (size_t i = 0; i < n_pass; i++) {
         if (pass_offsets[i + 1] < pass_offsets[i]) return fail(e, VK_E_INVALID_ARG, "pass_offsets must be non-decreasing");
-        if (pass_offsets[i + 1] - pass_offsets[i] > VK_BITIMAGE_MAX_PASS) return fail(e, VK_E_UNSUPPORTED, "passphrase longer than 256 bytes");
     }
     const u64 items = (u64)n_files * n_pass;
     if (items > (1ull << 28) || items * count > (1ull << 28)) return fail(e, VK_E_INVALID_ARG, "too many keys for one vk_bitimage_keys call (max 2^28)");
     vk_bip32_path pd = {};
     pd.depth = depth;
-    for (u32 i = 0; i < depth; i++) pd.comp[i] = path[i];
     // salt message of every passphrase, ready-padded (pass_data may be NULL when every passphrase is empty)
-    std::vector<u64> salts(n_pass * VK_SALT_WORDS);
-    std::vector<u32> nblk(n_pass);
+    std::vector<u32> salt_off(n_pass + 1, 0); // in words: passphrases of any length (src/bitimage.rs:38-74 takes the string as given)
     for (size_t j = 0; j < n_pass; j++) {
         const size_t pl = pass_offsets[j + 1] - pass_offsets[j];
         if (pl && !pass_data) return fail(e, VK_E_INVALID_ARG, "pass_data is NULL");
-        nblk[j] = vk_salt_blocks(&salts[j * VK_SALT_WORDS], pl ? pass_data + pass_offsets[j] : nullptr, pl);
+        const u64 next = (u64)salt_off[j] + (u64)vk_salt_nblk(pl) * 16;
+        if (next > 0xFFFFFFFFull) return fail(e, VK_E_INVALID_ARG, "the passphrases of one vk_bitimage_keys call add up to more than 32 GiB of salt blocks");
+        salt_off[j + 1] = (u32)next;
+    }
+    std::vector<u64> salts(salt_off[n_pass]);
+    for (size_t j = 0; j < n_pass; j++) {
+        const size_t pl = pass_offsets[j + 1] - pass_offsets[j];
+        vk_salt_blocks(&salts[salt_off[j]], pl ? pass_data + pass_offsets[j] : nullptr, pl);
     }
     HIPCHK(e, hipSetDevice(e->device));
     const size_t outs = (size_t)(items * count); // the passphrases travel as their salt blocks (d_salts below)
@@ -1668,11 +1680,14 @@ extern "C" int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy, size_t n_f
         const u32 groups = (u32)((items + 63) / 64);
         SCRATCH(e, d_stage, u64 *, 6, (size_t)items * VK_STAGE_BYTES);
         SCRATCH(e, d_state, u64 *, 7, (size_t)groups * VK_PB_WORDS * 64 * 8);
-        SCRATCH(e, d_salts, u64 *, 8, n_pass * (VK_SALT_WORDS * 8 + 4));
-        u32 *d_nblk = (u32 *)(d_salts + n_pass * VK_SALT_WORDS);
-        HIPCHK(e, hipMemcpy(d_salts, salts.data(), n_pass * VK_SALT_WORDS * 8, hipMemcpyHostToDevice));
-        HIPCHK(e, hipMemcpy(d_nblk, nblk.data(), n_pass * 4, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(vk_bitimage_prepare_kernel, grid, block, 0, e->stream, d_ent, items, (u32)n_pass, e->d_wordlist, d_salts, d_nblk, d_stage, d_state);
+        SCRATCH(e, d_salts, u64 *, 8, salts.size() * 8 + (n_pass + 1) * 4 + (size_t)depth * 4);
+        u32 *d_salt_off = (u32 *)(d_salts + salts.size());
+        u32 *d_comp = d_salt_off + n_pass + 1;
+        if (depth) HIPCHK(e, hipMemcpy(d_comp, path, (size_t)depth * 4, hipMemcpyHostToDevice));
+        pd.comp = d_comp;
+        HIPCHK(e, hipMemcpy(d_salts, salts.data(), salts.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(d_salt_off, salt_off.data(), (n_pass + 1) * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(vk_bitimage_prepare_kernel, grid, block, 0, e->stream, d_ent, items, (u32)n_pass, e->d_wordlist, d_salts, d_salt_off, d_stage, d_state);
         vk_pbkdf2_body::args a = {d_state, 0, 0};
         const int rc = run_ring<vk_pbkdf2_body>(e, groups, 2047, 64, a);
         if (rc) return rc;

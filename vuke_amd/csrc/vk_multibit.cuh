@@ -20,8 +20,6 @@
 #pragma once
 #include "vk_chain.cuh"
 
-#define VK_MULTIBIT_MAX_PASS 96      /* "mnemonic" || passphrase || INT(1) stays inside one SHA-512 block */
-#define VK_BITIMAGE_MAX_PASS 256     /* three blocks */
 
 // ---- BIP-39 list as an open-addressed set (built by vk_bip39_wordlist_set): 4096 slots of packed words, 0 = empty
 #define VK_WORDSET_SLOTS 4096u
@@ -144,10 +142,10 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_mb_middle_kernel(u64 n, const u64
 // derive_count paths that differ in the last index (reference src/bitimage.rs:38-74, src/transform/bitimage.rs:71-97):
 // entropy -> 24-word mnemonic (8 checksum bits) -> PBKDF2 seed -> HMAC("Bitcoin seed") -> CKDpriv along the path.
 // One lane per (file, passphrase); the parent of the last level is derived once.
-// salt blocks of passphrase j: salts[j * VK_SALT_WORDS ..], block count in salt_nblk[j]
+// salt blocks of passphrase j: words salt_off[j] .. salt_off[j + 1] of salts (16 per block; passphrases of any length)
 __global__ void __launch_bounds__(VK_BLOCK) vk_bitimage_prepare_kernel(const unsigned char *__restrict__ entropy, u64 n_items, u32 n_pass,
                                                                          const u64 *__restrict__ wordlist, const u64 *__restrict__ salts,
-                                                                         const u32 *__restrict__ salt_nblk, u64 *__restrict__ stage_all, u64 *__restrict__ state)
+                                                                         const u32 *__restrict__ salt_off, u64 *__restrict__ stage_all, u64 *__restrict__ state)
 {
     const u64 idx = (u64)blockIdx.x * VK_BLOCK + threadIdx.x;
     if (idx >= n_items) return;
@@ -172,6 +170,6 @@ __global__ void __launch_bounds__(VK_BLOCK) vk_bitimage_prepare_kernel(const uns
     u64 *stage = stage_all + idx * VK_STAGE_WORDS;
     const u32 len = stage_words<24, 5>(stage, S, wordlist);
     u64 ist[8], ost[8], u1[8];
-    pbkdf2_begin(ist, ost, u1, stage, len, salts + (u64)pj * VK_SALT_WORDS, salt_nblk[pj]);
+    pbkdf2_begin(ist, ost, u1, stage, len, salts + salt_off[pj], (salt_off[pj + 1] - salt_off[pj]) / 16u);
     pb_state_store(state, idx, ist, ost, u1);
 }
