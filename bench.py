@@ -120,9 +120,9 @@ def load_pmc(tag):
 
 
 def kernel_meta(kernel):
-    """Code-object metadata of `kernel` from profiles/r04_kernel_meta.json (tools/kernel_meta.py) if it was taken from the kernel
+    """Code-object metadata of `kernel` from profiles/kernel_meta.json (tools/kernel_meta.py) if it was taken from the kernel
     sources in this tree, else None."""
-    path = os.path.join(ROOT, "profiles", "r04_kernel_meta.json")
+    path = os.path.join(ROOT, "profiles", "kernel_meta.json")
     if not os.path.exists(path):
         return None
     km = json.load(open(path))
