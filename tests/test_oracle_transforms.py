@@ -113,6 +113,40 @@ int main() { unsigned long long s; while (std::scanf("%llu", &s) == 1) { std::mt
         assert vko.mt64_key(s).hex() == h, s
 
 
+def test_lcg_glibc_and_minstd_against_the_c_and_cxx_libraries(vko, tmp_path):
+    """Two of the four LCG variants exist in libraries nobody here wrote (the reference's own tests pin three values of each,
+    src/lcg.rs:135-174): glibc's TYPE_0 generator -- random_r on an 8-byte state is `(1103515245 * s + 12345) & 0x7fffffff`, the
+    `glibc` variant (src/lcg.rs:68-76) -- and libstdc++'s std::minstd_rand0 (16807, 0, 2^31 - 1: `minstd`, src/lcg.rs:77-84).
+    Eight outputs after seeding = the eight big-endian words of the key (src/lcg.rs:107-128); seed 0 is left out (both libraries
+    replace it by 1, the reference multiplies zero)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = tmp_path / "lcg.cpp"
+    src.write_text("""#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+int main() { unsigned long long s; int which;
+  while (std::scanf("%d %llu", &which, &s) == 2) {
+    if (which == 0) { char st[8]; struct random_data rd; std::memset(&rd, 0, sizeof rd); initstate_r((unsigned)s, st, sizeof st, &rd);
+      for (int i = 0; i < 8; i++) { int32_t v; random_r(&rd, &v); std::printf("%08x", (unsigned)v); } }
+    else { std::minstd_rand0 g((uint_fast32_t)s); for (int i = 0; i < 8; i++) std::printf("%08x", (unsigned)g()); }
+    std::printf("\\n"); } }
+""")
+    exe = tmp_path / "lcg"
+    subprocess.run(["g++", "-O2", "-o", str(exe), str(src)], check=True)
+    rnd = random.Random(31)
+    cases = [(0, s) for s in [1, 2, 42, 12345, 2**31 - 2, 2**31 - 1] + [rnd.randrange(1, 2**31) for _ in range(1500)]]
+    cases += [(1, s) for s in [1, 2, 42, 12345, 2**31 - 3, 2**31 - 2] + [rnd.randrange(1, 2**31 - 1) for _ in range(1500)]]
+    out = subprocess.run([str(exe)], input="".join(f"{w} {s}\n" for w, s in cases), capture_output=True, text=True, check=True).stdout.split()
+    assert len(out) == len(cases)
+    for (which, s), h in zip(cases, out):
+        assert vko.lcg_key(s, which).hex() == h, (which, s)
+
+
 def test_lcg_reference_kats(vko):
     # src/lcg.rs:135-174
     k = vko.lcg_key(1, 0)
