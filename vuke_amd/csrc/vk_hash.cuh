@@ -112,6 +112,76 @@ VK_DEV void sha256_pub65(u32 out[8], const fe &x, const fe &y)
     for (int i = 0; i < 8; i++) out[i] = st[i];
 }
 
+// ---- the second block of a 65-byte SEC1 key from an LDS table (the sweep kernel, round 5) ------------------------------------------
+// That block is Y's last byte, 0x80, zeros and the bit length 520: its 48 schedule words W[16..63] depend on ONE byte.  A workgroup
+// builds W[t] + K[t] for all 256 values once per launch (row b = 52 words: 48 used, rows 16-byte aligned and spread over the banks);
+// the block then costs its 64 rounds and twelve 16-byte LDS reads, no schedule arithmetic: -450 VALU instructions per uncompressed
+// key, +2.1 % on config 3 same box (profiles/r05_sha_tail_lds_experiment.txt).  The table is DYNAMIC LDS (53 KB), requested only by
+// launches that hash uncompressed keys: a compressed-only sweep (config 2) runs with the 24.8 KB it always had.
+#define VK_TAIL_ROW4 13 /* 16-byte quads per row */
+#define VK_TAIL_LDS_BYTES (256 * VK_TAIL_ROW4 * 16)
+typedef u32 vk_u32x4 __attribute__((ext_vector_type(4)));
+typedef vk_u32x4 __attribute__((address_space(3))) *vk_lds_u4p;
+VK_DEV void sha256_tail65_build_row(vk_lds_u4p table, u32 b)
+{
+    u32 w[16];
+    w[0] = (b << 24) | 0x00800000u;
+#pragma unroll
+    for (int i = 1; i < 15; i++) w[i] = 0;
+    w[15] = 65 * 8;
+    u32 q[4];
+#pragma unroll
+    for (int i = 16; i < 64; i++) {
+        u32 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+        u32 s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+        u32 s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+        w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        q[i & 3] = w[i & 15] + VK_K256[i];
+        if ((i & 3) == 3) table[b * VK_TAIL_ROW4 + (i - 16) / 4] = (vk_u32x4){q[0], q[1], q[2], q[3]};
+    }
+}
+VK_DEV void sha256_compress_tail65(u32 st[8], u32 ylast, vk_lds_u4p table)
+{
+    const vk_lds_u4p row = table + ylast * VK_TAIL_ROW4;
+    u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    vk_u32x4 q = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        u32 kw;
+        if (i == 0) kw = ((ylast << 24) | 0x00800000u) + VK_K256[0];
+        else if (i < 15) kw = VK_K256[i];
+        else if (i == 15) kw = VK_K256[15] + 65u * 8u;
+        else {
+            if ((i & 3) == 0) q = row[(i - 16) / 4];
+            kw = (i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w;
+        }
+        u32 S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
+        u32 ch = bool_ch(e, f, g);
+        u32 t1 = h + S1 + ch + kw;
+        u32 S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
+        u32 mj = bool_maj(a, b, c);
+        u32 t2 = S0 + mj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+// SHA-256(0x04 || X || Y) with the second block from the table
+VK_DEV void sha256_pub65_lds(u32 out[8], const fe &x, const fe &y, vk_lds_u4p table)
+{
+    u32 w[16];
+    u32 st[8] = VK_SHA256_IV;
+    w[0] = (0x04u << 24) | (FE_BE(x, 0) >> 8);
+#pragma unroll
+    for (int i = 1; i < 8; i++) w[i] = (FE_BE(x, i - 1) << 24) | (FE_BE(x, i) >> 8);
+    w[8] = (FE_BE(x, 7) << 24) | (FE_BE(y, 0) >> 8);
+#pragma unroll
+    for (int i = 1; i < 8; i++) w[8 + i] = (FE_BE(y, i - 1) << 24) | (FE_BE(y, i) >> 8);
+    sha256_compress(st, w);
+    sha256_compress_tail65(st, FE_BE(y, 7) & 0xFFu, table);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = st[i];
+}
+
 // ------------------------------------------------------------------ RIPEMD-160
 VK_DEV u32 rmd_f1(u32 x, u32 y, u32 z) { return xor3(x, y, z); }
 VK_DEV u32 rmd_f2(u32 x, u32 y, u32 z) { return VK_BITOP3(x, y, z, 0xCA); } // (x&y)|(~x&z)
@@ -191,6 +261,12 @@ VK_DEV void hash160_pub65(u32 out[5], const fe &x, const fe &y)
 {
     u32 d[8];
     sha256_pub65(d, x, y);
+    ripemd160_of_digest(out, d);
+}
+VK_DEV void hash160_pub65_lds(u32 out[5], const fe &x, const fe &y, vk_lds_u4p table)
+{
+    u32 d[8];
+    sha256_pub65_lds(d, x, y, table);
     ripemd160_of_digest(out, d);
 }
 

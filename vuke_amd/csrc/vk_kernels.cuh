@@ -12,7 +12,8 @@
 //   pass 2  walk the items backwards: w_b = inv * c_{b-1} = 1 / e_b; inv *= e_b; y = Y * w, x = (X*ZZ^2) * w^2;
 //           SHA-256 + RIPEMD-160 of the SEC1 encoding(s); digest fold; open-address probe of the target table; hit
 //           record / generate-mode record.  e and c of the next item are requested one item ahead.
-// LDS: the tile index, one 4 160-byte landing slot per wave and the per-lane digest accumulators (8 KB).  No MFMA: the path is integer-VALU bound; the memory
+// LDS: the tile index, one 4 160-byte landing slot per wave, the per-lane digest accumulators (8 KB) and, when uncompressed keys are hashed,
+// the 53 KB table of the second SHA-256 block's schedule (dynamic).  No MFMA: the path is integer-VALU bound; the memory
 // streams are the table gathers (64 B per window, random over the whole HBM table), the workspace (128 B written,
 // 160 B read per key) and one 32-byte probe slot per hash160.  Every field element lives in VGPRs; the 16 bytes of scratch
 // the code object reports are the argument frame of the rare exact-product calls (fe_mul_exact / fe_sqr_exact).
@@ -144,7 +145,7 @@ VK_DEV bool item_key(u32 kw[8], const vk_sweep_params &p, u64 off, u32 sub)
 // body wait for: they are requested one item ahead (16 registers), X and Y at the top of the body (needed two multiplies later).
 template <u32 KIND>
 VK_DEV void sweep_pass2(const vk_sweep_params &p, const uint4 *wk, const u32 B, const u64 tile_off, fe inv, u32 r, u32 sub, u64 *dg, u32 &n_keys,
-                        u32 &n_match)
+                        u32 &n_match, vk_lds_u4p tail)
 {
     const u32 tid = threadIdx.x;
     const u64 nth = VK_BLOCK;
@@ -195,7 +196,7 @@ VK_DEV void sweep_pass2(const vk_sweep_params &p, const uint4 *wk, const u32 B, 
             if (p.tgt) bits_c = probe_targets(p.tgt, p.tgt_mask, hc);
         }
         if (p.flags & VK_F_UNCOMPRESSED) {
-            hash160_pub65(hu, x, y);
+            hash160_pub65_lds(hu, x, y, tail);
             digest_fold(dg, hu);
             if (p.tgt) bits_u = probe_targets(p.tgt, p.tgt_mask, hu);
         }
@@ -291,6 +292,11 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
     __shared__ uint4 s_gather[(VK_BLOCK / 64) * VK_LDS_DEPTH * VK_LTILE_FULL]; // whole-entry slots per wave (lds_gather_issue)
     // the wave's slot, as a scalar: the LDS-direct loads take their LDS address from M0
     uint4 *gtile = s_gather + __builtin_amdgcn_readfirstlane(tid >> 6) * (VK_LDS_DEPTH * VK_LTILE_FULL);
+    // W[t] + K[t] of the second SHA-256 block of an uncompressed key, one row per value of Y's last byte (vk_hash.cuh): dynamic LDS,
+    // VK_TAIL_LDS_BYTES of it when the launch hashes uncompressed keys (vk_sweep_tu.hip), none otherwise
+    extern __shared__ vk_u32x4 s_tail[];
+    const vk_lds_u4p tail = (vk_lds_u4p)s_tail;
+    if (p.flags & VK_F_UNCOMPRESSED) sha256_tail65_build_row(tail, tid); // VK_BLOCK = 256 rows; made visible by the tile loop's first barrier
 
 #pragma unroll 1
     for (;;) {
@@ -347,7 +353,7 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
         // (as a kernel of its own, budgeted for 3 or 4 waves per SIMD, with every tile's items kept in HBM until it had read them,
         // pass 2 made the Milksad sweep 4.8 % SLOWER and the sha256 scan 0 - 1.5 % slower, same box, three rounds each:
         // profiles/r04_split_pass2_experiment.txt; the variant's last source is commit fe19f6c)
-        sweep_pass2<KIND>(p, wk, B, tile_off, inv, r, sub, dg, n_keys, n_match);
+        sweep_pass2<KIND>(p, wk, B, tile_off, inv, r, sub, dg, n_keys, n_match, tail);
     }
     // ------------------------------------------------------------------- counters
     if (blockIdx.x == 0 && tid == 0) {

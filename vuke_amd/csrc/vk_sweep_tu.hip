@@ -11,7 +11,17 @@
 template <u32 KIND>
 static void launch(const vk_sweep_params &p, u32 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(vk_sweep_kernel<KIND>, dim3(grid), dim3(VK_BLOCK), 0, s, p);
+    // dynamic LDS: the schedule table of the uncompressed key's second SHA-256 block, only where such keys are hashed (two resident
+    // workgroups then hold 2 x 78 KB of the CU's 160 KB; the register budget allows two either way)
+    const size_t dyn = (p.flags & VK_F_UNCOMPRESSED) ? (size_t)VK_TAIL_LDS_BYTES : 0;
+    static bool attr_set[64] = {}; // per device: the attribute belongs to the device's copy of the function (engines of several GPUs in one process)
+    int dev = 0;
+    if (dyn && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vk_sweep_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VK_TAIL_LDS_BYTES);
+        (void)hipGetLastError();
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(vk_sweep_kernel<KIND>, dim3(grid), dim3(VK_BLOCK), dyn, s, p);
 }
 
 #if VK_SWEEP_GROUP == 0
