@@ -111,7 +111,7 @@ if mix.get("SQ_INSTS_VALU"):
     # static mix of the code object (tools/kernel_meta.py: cycles per wave-instruction per SIMD with two waves resident,
     # profiles/r03_ubench_valu_rates.txt)
     out["valu_mix"] = {"int64_share": mix.get("SQ_INSTS_VALU_INT64", 0.0) / mix["SQ_INSTS_VALU"], "int32_share": mix.get("SQ_INSTS_VALU_INT32", 0.0) / mix["SQ_INSTS_VALU"]}
-    km_path = os.path.join(dst, "r04_kernel_meta.json")
+    km_path = os.path.join(dst, "kernel_meta.json")
     if os.path.exists(km_path):
         km = json.load(open(km_path))
         row = next((r for r in km["kernels"] if KERNELS[0] in r["kernel"] and "valu_static_mix" in r), None)
