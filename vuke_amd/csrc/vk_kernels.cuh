@@ -176,9 +176,8 @@ VK_DEV void sweep_pass2(const vk_sweep_params &p, const uint4 *wk, const u32 B, 
         } else {
             zinv = inv;
         }
-        u32 nzw = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) nzw |= P.x.v[i] | P.y.v[i];
+        // a lane without a key parked (0, 0); a real Y is a non-zero residue (no curve point has y = 0), so Y alone tells them apart
+        const u32 nzw = (P.y.v[0] | P.y.v[1] | P.y.v[2]) | (P.y.v[3] | P.y.v[4] | P.y.v[5]) | (P.y.v[6] | P.y.v[7]);
         if (nzw == 0) continue;
         fe x, y;
         fe_mul(y, P.y, zinv); // P.x = X*ZZ^2, P.y = Y, zinv = 1 / ZZZ
@@ -313,14 +312,18 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
 #pragma unroll 1
         for (u32 b = 0; b < B; b++) {
             const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
-            u32 kw[8];
+            u32 kw[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // stays zero where the reference emits nothing (item_key returns false)
             // parked per item: X*ZZ^2, Y, e = ZZZ and the running product of e: y = Y / e, x = X*ZZ^2 / e^2 (ZZ^3 = ZZZ^2)
             uint4 *it = wk + (u64)b * 8 * nth;
             {
                 const bool have = item_key<KIND>(kw, p, off, sub);
                 u32 k[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) k[i] = have ? kw[7 - i] : (i == 0 ? 1u : 0u); // lanes without a key walk the table with k = 1
+                for (int i = 0; i < 8; i++) k[i] = kw[7 - i];
+                if (__builtin_amdgcn_ballot_w64(!have) != 0) { // rare (the ragged end of a range, seeds beyond a ceiling): lanes without a key walk the table with k = 1
+#pragma unroll
+                    for (int i = 0; i < 8; i++) k[i] = have ? k[i] : (i == 0 ? 1u : 0u);
+                }
                 scalar_normalize(k);
                 xyzz Q;
                 ecmult_table_lds_xyzz(Q, k, p.table, p.wins, p.nwin, gtile);
