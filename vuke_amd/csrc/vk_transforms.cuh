@@ -61,6 +61,62 @@ VK_DEV u32 msg_put_decimal(u32 w[16], u32 pos, u64 v)
     return pos + nd;
 }
 
+// The decimal digits of v as the FIRST bytes of a big-endian packed message whose words the caller has zeroed, optionally followed
+// by the 0x80 padding marker; returns the number of digits.  Digits come out least significant first and each is pushed in front of
+// what is already there: a byte-wise right shift of a register window (one v_alignbit per word) with the new character entering at
+// the top -- no byte position to decode, no selects (msg_put_decimal above costs ~45 instructions per digit, this ~8).  The marker
+// starts out as byte 0 and ends up behind the last digit.  When every lane of the wave holds a value below 2^32 (every BASELINE
+// config) the arithmetic is 32-bit and the window three words; otherwise six words and 64-bit divisions.
+VK_DEV u32 msg_set_decimal(u32 w[16], u64 v, bool marker)
+{
+    u32 nd = 0;
+    bool more = true;
+    const u32 first = marker ? 0x80000000u : 0u;
+    if (__builtin_amdgcn_ballot_w64((v >> 32) != 0) == 0) {
+        u32 x = (u32)v, r0 = first, r1 = 0, r2 = 0; // at most 10 digits + the marker
+        do {
+            if (more) {
+                const u32 q = __umulhi(x, 0xCCCCCCCDu) >> 3; // x / 10
+                const u32 c = x - q * 10u + (u32)'0';
+                r2 = __builtin_amdgcn_alignbit(r1, r2, 8);
+                r1 = __builtin_amdgcn_alignbit(r0, r1, 8);
+                r0 = __builtin_amdgcn_alignbit(c, r0, 8);
+                x = q;
+                nd++;
+                more = x != 0;
+            }
+        } while (__builtin_amdgcn_ballot_w64(more) != 0);
+        w[0] = r0;
+        w[1] = r1;
+        w[2] = r2;
+    } else {
+        u64 x = v;
+        u32 r0 = first, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0; // at most 20 digits + the marker
+        do {
+            if (more) {
+                const u64 q = x / 10;
+                const u32 c = (u32)(x - q * 10) + (u32)'0';
+                r5 = __builtin_amdgcn_alignbit(r4, r5, 8);
+                r4 = __builtin_amdgcn_alignbit(r3, r4, 8);
+                r3 = __builtin_amdgcn_alignbit(r2, r3, 8);
+                r2 = __builtin_amdgcn_alignbit(r1, r2, 8);
+                r1 = __builtin_amdgcn_alignbit(r0, r1, 8);
+                r0 = __builtin_amdgcn_alignbit(c, r0, 8);
+                x = q;
+                nd++;
+                more = x != 0;
+            }
+        } while (__builtin_amdgcn_ballot_w64(more) != 0);
+        w[0] = r0;
+        w[1] = r1;
+        w[2] = r2;
+        w[3] = r3;
+        w[4] = r4;
+        w[5] = r5;
+    }
+    return nd;
+}
+
 VK_DEV void msg_finish(u32 w[16], u32 len)
 {
     msg_put(w, len, 0x80u);
@@ -240,8 +296,8 @@ VK_DEV bool transform_sha256(u32 kw[8], u64 seed, u32 sub)
 #pragma unroll
     for (int i = 0; i < 16; i++) w[i] = 0;
     if (sub == 0) {
-        u32 len = msg_put_decimal(w, 0, seed);
-        msg_finish(w, len);
+        const u32 len = msg_set_decimal(w, seed, true); // digits + 0x80; w[14] stays 0
+        w[15] = len * 8;
     } else if (sub == 1) {
         w[0] = (u32)(seed >> 32);
         w[1] = (u32)seed;
@@ -274,8 +330,7 @@ VK_DEV bool transform_md5(u32 kw[8], u64 seed)
     u32 w[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) w[i] = 0;
-    const u32 len = msg_put_decimal(w, 0, seed); // <= 20 bytes, big-endian packed
-    msg_put(w, len, 0x80u);
+    const u32 len = msg_set_decimal(w, seed, true); // <= 20 bytes + the marker, big-endian packed
     u32 m[16];
 #pragma unroll
     for (int i = 0; i < 14; i++) m[i] = bswap32(w[i]);
@@ -303,7 +358,7 @@ VK_DEV bool transform_direct(u32 kw[8], u64 seed, u32 sub)
         u32 w[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) w[i] = 0;
-        msg_put_decimal(w, 0, seed);
+        msg_set_decimal(w, seed, false);
 #pragma unroll
         for (int i = 0; i < 8; i++) kw[i] = w[i];
     } else {
@@ -327,7 +382,7 @@ VK_DEV bool transform_sha256_chain(u32 kw[8], u64 seed, u32 sub, u32 spec_varian
     for (int i = 0; i < 16; i++) w[i] = 0;
     u32 len;
     if (form == 0) {
-        len = msg_put_decimal(w, 0, seed);
+        len = msg_set_decimal(w, seed, false);
     } else {
         w[0] = (u32)seed;
         len = 4;
