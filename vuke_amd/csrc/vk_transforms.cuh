@@ -71,9 +71,11 @@ VK_DEV u32 msg_set_decimal(u32 w[16], u64 v, bool marker)
 {
     u32 nd = 0;
     bool more = true;
-    const u32 first = marker ? 0x80000000u : 0u;
+    // one set of window registers for both paths, stored to w[] once behind them: with a store per path the compiler merged the two
+    // tails into one store through a dynamic index and put the words into scratch
+    u32 r0 = marker ? 0x80000000u : 0u, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0;
     if (__builtin_amdgcn_ballot_w64((v >> 32) != 0) == 0) {
-        u32 x = (u32)v, r0 = first, r1 = 0, r2 = 0; // at most 10 digits + the marker
+        u32 x = (u32)v; // at most 10 digits + the marker: three words
         do {
             if (more) {
                 const u32 q = __umulhi(x, 0xCCCCCCCDu) >> 3; // x / 10
@@ -86,16 +88,12 @@ VK_DEV u32 msg_set_decimal(u32 w[16], u64 v, bool marker)
                 more = x != 0;
             }
         } while (__builtin_amdgcn_ballot_w64(more) != 0);
-        w[0] = r0;
-        w[1] = r1;
-        w[2] = r2;
     } else {
-        u64 x = v;
-        u32 r0 = first, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0; // at most 20 digits + the marker
+        u64 x = v; // at most 20 digits + the marker: six words
         do {
             if (more) {
-                const u64 q = x / 10;
-                const u32 c = (u32)(x - q * 10) + (u32)'0';
+                const u64 q = __umul64hi(x, 0xCCCCCCCCCCCCCCCDull) >> 3; // x / 10
+                const u32 c = (u32)x - (u32)q * 10u + (u32)'0';
                 r5 = __builtin_amdgcn_alignbit(r4, r5, 8);
                 r4 = __builtin_amdgcn_alignbit(r3, r4, 8);
                 r3 = __builtin_amdgcn_alignbit(r2, r3, 8);
@@ -107,13 +105,13 @@ VK_DEV u32 msg_set_decimal(u32 w[16], u64 v, bool marker)
                 more = x != 0;
             }
         } while (__builtin_amdgcn_ballot_w64(more) != 0);
-        w[0] = r0;
-        w[1] = r1;
-        w[2] = r2;
-        w[3] = r3;
-        w[4] = r4;
-        w[5] = r5;
     }
+    w[0] = r0;
+    w[1] = r1;
+    w[2] = r2;
+    w[3] = r3;
+    w[4] = r4;
+    w[5] = r5;
     return nd;
 }
 
