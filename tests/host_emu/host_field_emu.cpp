@@ -47,6 +47,11 @@ int main()
         case 13: r = x; fe_sub(r, y, r); break;
         case 14: r = x; fe_sub3(r, r, r, r); break;
         case 15: r = x; fe_sqr_n(r, r, 5); fe_mul(r, r, y); break;
+        case 16: fe_mul2(r, x, y, y, x); break;                        // 2xy: the 17-limb sum at its largest for x = y = 2^256 - 1
+        case 17: fe_mul2(r, x, x, y, y); break;                        // x^2 + y^2
+        case 18: r = x; fe_mul2(r, r, y, y, r); break;                 // result aliasing the first and the last operand
+        case 19: r = y; fe_sqr(r, r); fe_mul2(r, x, r, r, y); break;   // x y^2 + y^3: result aliasing the inner operands
+        case 102: r = fe_mul2_exact(x, y, y, x); break;
         case 100: r = fe_mul_exact(x, y); break; // the exact (three-chain) path on its own
         case 101: r = fe_sqr_exact(x); break;
         default: fe_sub(r, x, y); break;

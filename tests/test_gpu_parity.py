@@ -62,7 +62,10 @@ def field_cases():
            # one case per aliasing form of the generated statements (result = first / second / both operands)
            (8, lambda x, y: x * y % P), (9, lambda x, y: x * y % P), (10, lambda x, y: x * x % P), (11, lambda x, y: x * x % P),
            (12, lambda x, y: 2 * x % P), (13, lambda x, y: (y - x) % P), (14, lambda x, y: -2 * x % P),
-           (15, lambda x, y: pow(x, 32, P) * y % P), (1, lambda x, y: x * x % P)]
+           (15, lambda x, y: pow(x, 32, P) * y % P), (1, lambda x, y: x * x % P),
+           # fe_mul2 = a*b + c*d in one set of accumulators (17-limb sum), with its aliasing forms
+           (16, lambda x, y: 2 * x * y % P), (17, lambda x, y: (x * x + y * y) % P), (18, lambda x, y: 2 * x * y % P),
+           (19, lambda x, y: (x * y * y + y * y * y) % P)]
     return ops, a, b
 
 

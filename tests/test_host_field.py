@@ -46,7 +46,7 @@ def test_generated_files_are_what_the_generator_writes(tmp_path):
 def test_host_emulation_of_the_generated_field_code(tmp_path, defines):
     exe = build(tmp_path, *defines)
     ops, a, b = field_cases()
-    for op, f in ops + [(100, lambda x, y: x * y % P), (101, lambda x, y: x * x % P)]:   # 100 / 101: the exact product paths alone
+    for op, f in ops + [(100, lambda x, y: x * y % P), (101, lambda x, y: x * x % P), (102, lambda x, y: 2 * x * y % P)]:   # 100 - 102: the exact product paths alone
         got = run(exe, op, a, b)
         for x, y, g in zip(a, b, got):
             assert g == f(x, y), (op, hex(x), hex(y))

@@ -80,10 +80,14 @@ def col_products_sqr(k):
     return [(i, k - i) for i in range(max(0, k - 7), min(k, 7) + 1) if i < k - i]
 
 
-def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, zero_o=False, start_e=None, start_o=None):
+def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, zero_o=False, start_e=None, start_o=None, cont=None):
     """one asm statement: even column ke and odd column ke+1.  A column whose start value is zero takes the literal 0
     as the addend of its first multiply (no register to clear); the first carry of a column *sets* its counter
-    (0 + 0 + carry), so the counters need no clearing either."""
+    (0 + 0 + carry), so the counters need no clearing either.
+    cont = (counter_exists_e, counter_exists_o): the statement CONTINUES two columns an earlier statement began (the second
+    product of fe_mul2_cols): the accumulators are read-write, every multiply-add -- the first included, its addend is a full
+    64-bit pair -- has its carry counted, into the existing counter or, where the column had a single product so far, into a
+    fresh one."""
     ko = ke + 1
     # operand table
     ops_out = []   # (constraint, expr)
@@ -96,21 +100,26 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, z
 
     have_e, have_o = bool(prods_e), bool(prods_o)
     cnt_e, cnt_o = f"cy[{ke}]", f"cy[{ko}]"      # what the carry-count instructions of the two columns write
+    assert not (cont and PIN)
     if have_e:
         out("=&v" if (zero_e or start_e) else "+v", f"acc[{ke}]")
-        if PIN and (len(prods_e) > 1 or start_e):
+        if cont:
+            out("+v" if cont[0] else "=&v", f"cy[{ke}]")
+        elif PIN and (len(prods_e) > 1 or start_e):
             out("+{v[%d:%d]}" % (PIN_REG["cpe"], PIN_REG["cpe"] + 1), "cpe")
             cnt_e = "v%d" % PIN_REG["cpe"]
         elif len(prods_e) > 1:
             out("=&v", f"cy[{ke}]")
     if have_o:
         out("=&v" if (zero_o or start_o) else "+v", f"acc[{ko}]")
-        if PIN and (len(prods_o) > 1 or start_o):
+        if cont:
+            out("+v" if cont[1] else "=&v", f"cy[{ko}]")
+        elif PIN and (len(prods_o) > 1 or start_o):
             out("+{v[%d:%d]}" % (PIN_REG["cpo"], PIN_REG["cpo"] + 1), "cpo")
             cnt_o = "v%d" % PIN_REG["cpo"]
         elif len(prods_o) > 1:
             out("=&v", f"cy[{ko}]")
-        if len(prods_o) > 1:
+        if len(prods_o) > 1 or cont:
             out("=&s", "sc")
     used = []
     for (i, j) in prods_e + prods_o:
@@ -138,11 +147,19 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, z
             body.append(f"v_mad_u64_u32 {r(f'acc[{ke}]')}, vcc, {r((a_name, i))}, {r((a_name if same else b_name, j))}, {add}")
         if step < no:
             i, j = prods_o[step]
-            sd = r("sc") if no > 1 else "vcc"
+            sd = r("sc") if (no > 1 or cont) else "vcc"
             add = "0" if (zero_o and step == 0) else (r(start_o) if (start_o and step == 0) else r(f'acc[{ko}]'))
             body.append(f"v_mad_u64_u32 {r(f'acc[{ko}]')}, {sd}, {r((a_name, i))}, {r((a_name if same else b_name, j))}, {add}")
         ce = cnt_e if cnt_e.startswith("v") else r(cnt_e) if cnt_e in idx else None
         co = cnt_o if cnt_o.startswith("v") else r(cnt_o) if cnt_o in idx else None
+        if cont:
+            if step < ne:
+                prev = ce if (cont[0] or step > 0) else "0"
+                body.append(f"v_addc_co_u32 {ce}, vcc, 0, {prev}, vcc")
+            if step < no:
+                prev = co if (cont[1] or step > 0) else "0"
+                body.append(f"v_addc_co_u32 {co}, {r('sc')}, 0, {prev}, {r('sc')}")
+            continue
         if step < ne and step > 0:
             prev = "0" if step == 1 else ce
             body.append(f"v_addc_co_u32 {ce}, vcc, 0, {prev}, vcc")
@@ -151,7 +168,7 @@ def emit_pair(lines, ke, prods_e, prods_o, a_name, b_name, same, zero_e=False, z
             body.append(f"v_addc_co_u32 {co}, {r('sc')}, 0, {prev}, {r('sc')}")
     # vcc hazard: if the odd column has a single product it would write vcc between the even
     # column's multiply and its carry add -> route it through a dead SGPR pair instead
-    if no == 1 and ne > 1:
+    if no == 1 and ne > 1 and not cont:
         body = [b.replace(f"{r(f'acc[{ko}]')}, vcc,", f"{r(f'acc[{ko}]')}, s[100:101],") if b.startswith(f"v_mad_u64_u32 {r(f'acc[{ko}]')}") else b for b in body]
         clob = '"vcc", "s100", "s101"'
     else:
@@ -194,6 +211,63 @@ def gen_cols(name, prods_fn, same):
             emit_pair(L, ke, pe, po, "a", "b", same, zero_e=zero.get(ke, False), zero_o=zero.get(ke + 1, False),
                       start_e=start.get(ke), start_o=start.get(ke + 1))
     L.append(f"    return {('(u32)cpo' if PIN else 'cy[13]') if has_cy[13] else '0u'};\n}}\n\n")
+    return "".join(L)
+
+
+def gen_cols2():
+    """fe_mul2_cols: the columns of a*b + c*d in ONE set of accumulators (round 5: the y-coordinate of every point addition is
+    such a sum; one merge and one reduction instead of two, and no field subtraction).  Per column pair two statements (an asm
+    statement takes at most 30 operands): the a*b products exactly as fe_mul_cols emits them, then the c*d products continuing
+    the same accumulators with every carry counted.  The sum is below 2^513: column 14 gets a counter of its own (limb 16)."""
+    L = []
+    L.append("// acc[k] = pair (limb k, limb k+1) of column k of a*b + c*d; returns limb 15 of the odd number, top16 = limb 16 of the even one\n")
+    L.append("VK_DEV u32 fe_mul2_cols(u64 acc[15], u32 &top16, const fe &a, const fe &b, const fe &c, const fe &d)\n{\n")
+    L.append("    u32 cy[15];\n    vk_carry sc;\n    (void)sc;\n")
+    for ke in range(0, 15, 2):
+        cols = [k for k in (ke, ke + 1) if k < 15]
+        zero, start = {}, {}
+        for k in cols:
+            zero[k] = k < 2
+            if not zero[k]:
+                L.append(f"    const u64 cz{k} = (u64)cy[{k - 2}];\n")
+                start[k] = f"cz{k}"
+        pe, po = col_products_mul(ke), (col_products_mul(ke + 1) if ke + 1 < 15 else [])
+        emit_pair(L, ke, pe, po, "a", "b", False, zero_e=zero.get(ke, False), zero_o=zero.get(ke + 1, False),
+                  start_e=start.get(ke), start_o=start.get(ke + 1))
+        emit_pair(L, ke, pe, po, "c", "d", False, cont=(len(pe) > 1, len(po) > 1))
+    L.append("    top16 = cy[14];\n    return cy[13];\n}\n\n")
+    return "".join(L)
+
+
+def gen_merge17():
+    """merge_eo with the seventeenth limb of fe_mul2_cols' sum: limb 16 = the even number's counter + the chain's last carry."""
+    L = []
+    L.append("// t[0..16] = E + O for the columns of fe_mul2_cols (a sum below 2^513: t[16] is 0 or 1)\n")
+    L.append("VK_DEV void merge_eo17(u32 t[17], const u64 acc[15], u32 top, u32 top16)\n{\n")
+    L.append("    u32 e[16], o[16];\n#pragma unroll\n    for (int m = 0; m < 8; m++) {\n        e[2 * m] = (u32)acc[2 * m];\n        e[2 * m + 1] = (u32)(acc[2 * m] >> 32);\n    }\n")
+    L.append("#pragma unroll\n    for (int m = 0; m < 7; m++) {\n        o[2 * m + 1] = (u32)acc[2 * m + 1];\n        o[2 * m + 2] = (u32)(acc[2 * m + 1] >> 32);\n    }\n    o[15] = top;\n    t[0] = e[0];\n    vk_carry c;\n")
+    body = ["v_add_co_u32 %0, vcc, %8, %15"]
+    for j in range(2, 8):
+        last = j == 7
+        body.append(f"v_addc_co_u32 %{j - 1}, {'%7' if last else 'vcc'}, %{7 + j}, %{14 + j}, vcc")
+    s = '    asm("' + '\\n\\t"\n        "'.join(body) + '"\n'
+    s += "        : " + ", ".join(f'"=&v"(t[{j}])' for j in range(1, 8)) + ', "=&s"(c)\n'
+    s += "        : " + ", ".join(f'"v"(e[{j}])' for j in range(1, 8)) + ", " + ", ".join(f'"v"(o[{j}])' for j in range(1, 8)) + "\n"
+    s += '        : "vcc");\n'
+    host_register(s, body, [f"t[{j}]" for j in range(1, 8)] + ["c"] + [f"e[{j}]" for j in range(1, 8)] + [f"o[{j}]" for j in range(1, 8)])
+    L.append(s)
+    # second half: t8..t15 with the carry in %26, then limb 16 = top16 + carry
+    body = []
+    for j in range(8, 16):
+        first = j == 8
+        body.append(f"v_addc_co_u32 %{j - 8}, vcc, %{j + 1}, %{j + 9}, {'%26' if first else 'vcc'}")
+    body.append("v_addc_co_u32 %8, vcc, 0, %25, vcc")
+    s = '    asm("' + '\\n\\t"\n        "'.join(body) + '"\n'
+    s += "        : " + ", ".join(f'"=&v"(t[{j}])' for j in range(8, 17)) + "\n"
+    s += "        : " + ", ".join(f'"v"(e[{j}])' for j in range(8, 16)) + ", " + ", ".join(f'"v"(o[{j}])' for j in range(8, 16)) + ', "v"(top16), "s"(c)\n'
+    s += '        : "vcc");\n'
+    host_register(s, body, [f"t[{j}]" for j in range(8, 17)] + [f"e[{j}]" for j in range(8, 16)] + [f"o[{j}]" for j in range(8, 16)] + ["top16", "c"])
+    L.append(s + "}\n\n")
     return "".join(L)
 
 
@@ -526,8 +600,11 @@ def gen_sub3():
     return "".join(L)
 
 
-def gen_reduce_flags():
-    """fe_reduce16_flags: the reduction with NO precondition test in the instruction stream.  Every place where the short
+def gen_reduce_flags(limb16=False):
+    """(limb16: fe_reduce17_flags, the same reduction for the 17-limb sum of fe_mul2_cols -- limb 16, 0 or 1, is worth
+    2^512 = C^2 = 2^64 + 1954 * 2^32 + 954529 (mod p) and joins limbs 0..2 of the result in a second short chain whose carry-out
+    is one more flag.)
+    fe_reduce16_flags: the reduction with NO precondition test in the instruction stream.  Every place where the short
     form can lose a carry -- the eight multiply-adds t[8+i] * 977 + (t[8+i] : t[i]) (overflow of 64 bits: one product in
     2^22), the carry out of limb 8 of their sum, the multiply-add s8 * 977 + (s8 : s0) that folds limb 8, and the carry out
     of limb 2 of the fold (one in 2^31) -- writes its carry-out to an SGPR pair; the pairs are OR-ed on the scalar unit
@@ -537,7 +614,11 @@ def gen_reduce_flags():
     s8 * 977 product and limbs 3..7 of the fold's carry chain are gone."""
     L = []
     L.append("// r = t_lo + t_hi * (2^32 + 977) when the return value is 0; otherwise some lane lost a carry: recompute exactly\n")
-    L.append("VK_DEV vk_carry fe_reduce16_flags(fe &r, const u32 t[16])\n{\n")
+    if limb16:
+        L.append("// (17 limbs: t[16] * C^2 is added to limbs 0..2 at the end)\n")
+        L.append("VK_DEV vk_carry fe_reduce17_flags(fe &r, const u32 t[17])\n{\n")
+    else:
+        L.append("VK_DEV vk_carry fe_reduce16_flags(fe &r, const u32 t[16])\n{\n")
     L.append("    u64 v[8];\n#pragma unroll\n    for (int i = 0; i < 8; i++) v[i] = ((u64)t[8 + i] << 32) | t[i];\n")
     L.append("    vk_carry k0, k1, k2, k3, k4, k5, k6, k7, ka, kb, kc, kd, ovf;\n")
     # statement A: mads 0..3, carry-outs k0..k3
@@ -598,6 +679,33 @@ def gen_reduce_flags():
     host_register(one, ["v_mad_u64_u32 %0, %1, %2, %3, %0"], ["f", "kc", "s[8]", "VK_PC0"])
     L.append(one)
     L.append("    const u32 fl = (u32)f, fh = (u32)(f >> 32);\n")
+    if limb16:
+        # chain A: (r1a, r2a) = (s1 + f.hi, s2 + carry) -> flag kd; chain B: (r0, r1, r2) = (fl, r1a, r2a) + t16 * (954529, 1954, 1) -> flag ke
+        L.append("    u32 q0, q1, r1a, r2a;\n    vk_carry ke;\n")
+        a = Asm()
+        a.clob = ["vcc", "scc"]
+        for e in ("q0", "q1", "r1a", "r2a", "r.v[0]", "r.v[1]", "r.v[2]"):
+            a.out("=&v", e)
+        for e in ("kd", "ke", "ovf"):
+            a.out("=&s", e)
+        for e in ("s[1]", "s[2]", "fh", "fl", "t[16]"):
+            a.inp("v", e)
+        for x in ("ka", "kb", "kc"):
+            a.inp("s", x)
+        a.ins_("v_mul_u32_u24 {}, 0xE90A1, {}", "q0", "t[16]")              # 977^2
+        a.ins_("v_mul_u32_u24 {}, 1954, {}", "q1", "t[16]")                 # 2 * 977
+        a.ins_("v_add_co_u32 {}, vcc, {}, {}", "r1a", "s[1]", "fh")
+        a.ins_("v_addc_co_u32 {}, {}, 0, {}, vcc", "r2a", "kd", "s[2]")
+        a.ins_("v_add_co_u32 {}, vcc, {}, {}", "r.v[0]", "fl", "q0")
+        a.ins_("v_addc_co_u32 {}, vcc, {}, {}, vcc", "r.v[1]", "r1a", "q1")
+        a.ins_("v_addc_co_u32 {}, {}, {}, {}, vcc", "r.v[2]", "ke", "r2a", "t[16]")
+        a.ins_("s_or_b64 {}, {}, {}", "ovf", "ka", "kb")
+        a.ins_("s_or_b64 {}, {}, {}", "ovf", "ovf", "kc")
+        a.ins_("s_or_b64 {}, {}, {}", "ovf", "ovf", "kd")
+        a.ins_("s_or_b64 {}, {}, {}", "ovf", "ovf", "ke")
+        L.append(a.render())
+        L.append("#pragma unroll\n    for (int i = 3; i < 8; i++) r.v[i] = s[i];\n    return ovf;\n}\n\n")
+        return "".join(L)
     # r1 = s1 + f.hi, r2 = s2 + carry; the carry out of limb 2 is the last flag
     a = Asm()
     a.clob = ["vcc", "scc"]
@@ -623,7 +731,7 @@ def gen_reduce_flags():
 def main():
     hdr = "// GENERATED by tools/gen_field.py -- do not edit.  Column kernels of the 256-bit multiply / square\n"
     hdr += "// on v_mad_u64_u32 (see the scheme in vk_field.cuh).\n#pragma once\n\n"
-    txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_sqr_tail() + gen_addsub() + gen_sub3() + gen_reduce() + gen_reduce_fast() + gen_reduce_flags()
+    txt = hdr + gen_cols("fe_mul_cols", col_products_mul, False) + gen_cols("fe_sqr_cols", col_products_sqr, True) + gen_merge() + gen_sqr_tail() + gen_addsub() + gen_sub3() + gen_reduce() + gen_reduce_fast() + gen_reduce_flags() + gen_cols2() + gen_merge17() + gen_reduce_flags(limb16=True)
     open(OUT, "w").write(txt)
     print("wrote", OUT, len(txt.splitlines()), "lines")
     host = txt.replace("// GENERATED by tools/gen_field.py -- do not edit.", "// GENERATED by tools/gen_field.py -- do not edit.  HOST form: every asm statement of vuke_amd/csrc/vk_field_gen.cuh as\n// calls into the one-lane instruction emulator of vk_field_prims_host.h; test infrastructure, never part of the device build.", 1)

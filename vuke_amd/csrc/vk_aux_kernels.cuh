@@ -360,6 +360,11 @@ __global__ void vk_field_kernel(int op, const u32 *a, const u32 *b, u64 n, u32 *
     case 13: r = x; fe_sub(r, y, r); break;                  // r = y - x
     case 14: r = x; fe_sub3(r, r, r, r); break;              // r = x - x - 2x = -2x
     case 15: r = x; fe_sqr_n(r, r, 5); fe_mul(r, r, y); break; // x^32 * y: a loop-carried element feeding a multiply
+    // the fused sum of two products (the y-coordinate of the sweep's point additions)
+    case 16: fe_mul2(r, x, y, y, x); break;                        // 2xy
+    case 17: fe_mul2(r, x, x, y, y); break;                        // x^2 + y^2
+    case 18: r = x; fe_mul2(r, r, y, y, r); break;                 // result aliasing the first and the last operand
+    case 19: r = y; fe_sqr(r, r); fe_mul2(r, x, r, r, y); break;   // x y^2 + y^3: result aliasing the inner operands
     default: fe_sub(r, x, y); break;
     }
     fe_canon(r);

@@ -313,11 +313,17 @@ VK_DEV void jac_to_affine(fe &x, fe &y, const jac &p, const fe &zinv)
 // 8M + 3S of the Jacobian mixed addition (no Z^2 to recompute: "madd-2008-s").  Leaving the chain costs the same as
 // before: ZZZ goes through the batch inversion, y = Y / ZZZ, x = X * ZZ^2 / ZZZ^2 (ZZ^3 = ZZZ^2) -- 2S + 3M per key like
 // the Jacobian 1S + 3M plus one squaring -- so a k*G with seven such additions saves about 6S: 4 % of the sweep.
+// Round 5: the additions return the negative of the sum (xyzz_madd_flip), whose y is ONE fused pair of products.
 struct xyzz {
     fe x, y, zz, zzz;
 };
-// r += (qx, qy); r not infinity, q affine, r != +-q (same argument as jac_madd)
-VK_DEV void xyzz_madd(xyzz &r, const fe &qx, const fe &qy)
+// r = -(r + (qx, qy)); r not infinity, q affine, r != +-q (same argument as jac_madd).   7M + 2S + one fused pair of products
+// The NEGATIVE of the sum, because its y-coordinate is a sum of two products where the sum's own is a difference:
+//   Y3 = R (Q - X3) - Y1 P^3      -(Y3) = R (X3 - Q) + Y1 P^3
+// and a sum of two products is one trip through the multiplier's columns, one merge and one reduction (fe_mul2: 291 instructions,
+// 119 multiply-adds) instead of two multiplications and a field subtraction (324 and 146).  The caller keeps track of the sign the
+// accumulator stands for and hands in the table point with that sign (ecmult_table_lds_xyzz below): -(s A + s q) = -s (A + q).
+VK_DEV void xyzz_madd_flip(xyzz &r, const fe &qx, const fe &qy)
 {
     fe u2, s2, pp, ppp, q, t;
     fe_mul(u2, qx, r.zz);
@@ -330,28 +336,24 @@ VK_DEV void xyzz_madd(xyzz &r, const fe &qx, const fe &qy)
     fe_mul(r.zz, r.zz, pp);
     fe_mul(r.zzz, r.zzz, ppp);
     fe_sqr(t, s2);
-    fe_sub3(t, t, ppp, q);           // X3
-    fe_mul(ppp, ppp, r.y);     // Y1 * P^3
-    fe_sub(q, q, t);
-    fe_mul(q, q, s2);
-    fe_sub(r.y, q, ppp);
+    fe_sub3(t, t, ppp, q);     // X3
+    fe_sub(q, t, q);           // X3 - Q
+    fe_mul2(r.y, s2, q, r.y, ppp); // -(Y3)
     r.x = t;
 }
-// r = (r.x, r.y) + (qx, qy) for two affine points with different x (r.zz = r.zzz = 1 on entry).   4M + 2S
-VK_DEV void xyzz_aadd(xyzz &r, const fe &qx, const fe &qy)
+// r = -((r.x, r.y) + (qx, qy)) for two affine points with different x (r.zz = r.zzz = 1 on entry).   3M + 2S + one fused pair
+VK_DEV void xyzz_aadd_flip(xyzz &r, const fe &qx, const fe &qy)
 {
-    fe h, rr, q, t, yp;
+    fe h, rr, q, t;
     fe_sub(h, qx, r.x);
     fe_sub(rr, qy, r.y);
     fe_sqr(r.zz, h);
     fe_mul(r.zzz, r.zz, h);
     fe_mul(q, r.x, r.zz);
     fe_sqr(t, rr);
-    fe_sub3(t, t, r.zzz, q);           // x3
-    fe_mul(yp, r.zzz, r.y);
-    fe_sub(q, q, t);
-    fe_mul(q, q, rr);
-    fe_sub(r.y, q, yp);
+    fe_sub3(t, t, r.zzz, q);   // x3
+    fe_sub(q, t, q);
+    fe_mul2(r.y, rr, q, r.y, r.zzz);
     r.x = t;
 }
 // ecmult_table with the reads landing in LDS directly and the XYZZ accumulator (the whole wave calls it; lanes without a key
@@ -362,6 +364,11 @@ VK_DEV void xyzz_aadd(xyzz &r, const fe &qx, const fe &qy)
 VK_DEV void ecmult_table_lds_xyzz(xyzz &acc, const u32 k[8], const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin, uint4 *slots)
 {
     bool inf = true, zone = false;
+    // Every addition leaves the NEGATIVE of the sum in the accumulator (xyzz_madd_flip): `minus` says that the accumulator stands for
+    // minus the point accumulated so far; a table point goes in with the accumulator's sign.  The first entry is loaded with the
+    // sign that nwin - 1 additions turn into plus, so a key whose digits are all non-zero (all but one key in 2^25) ends with
+    // minus == false; the others pay the negation at the end.
+    bool minus = ((nwin - 1u) & 1u) != 0;
     fe_set_zero(acc.x);
     fe_set_zero(acc.y);
     fe_set_one(acc.zz);
@@ -393,18 +400,27 @@ VK_DEV void ecmult_table_lds_xyzz(xyzz &acc, const u32 k[8], const uint4 *__rest
             lds_gather_issue(slot, table, (u32)(wins[w + VK_LDS_DEPTH].base + dq[VK_LDS_DEPTH - 1]));
         }
         if (cd != 0) {
-            fe_cond_negate(cy, cneg);
+            fe_cond_negate(cy, cneg != minus);
             if (inf) {
                 acc.x = cx;
                 acc.y = cy;
                 inf = false;
                 zone = true;
             } else if (zone) {
-                xyzz_aadd(acc, cx, cy);
+                xyzz_aadd_flip(acc, cx, cy);
                 zone = false;
+                minus = !minus;
             } else {
-                xyzz_madd(acc, cx, cy);
+                xyzz_madd_flip(acc, cx, cy);
+                minus = !minus;
             }
         }
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(minus) != 0, 0)) { // a zero digit somewhere (or a lane without a key: k = 1)
+        fe ny;
+        fe_set_zero(ny);
+        fe_sub(ny, ny, acc.y);
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc.y.v[i] = minus ? ny.v[i] : acc.y.v[i];
     }
 }
