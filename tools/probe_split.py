@@ -20,7 +20,10 @@ bpc = int(sys.argv[2]) if len(sys.argv) > 2 else 2          # resident workgroup
 geom = [int(x) for x in os.environ.get("PROBE_GEOM", "1,0,256").split(",")]
 eng = vuke_amd.Engine(0, layout=geom[0], window_bits=geom[1], batch=geom[2], blocks_per_cu=bpc)
 tag = os.path.basename(os.environ.get("VUKE_HIP_LIB", "shipped"))
-for name, spec, flags, log2, per in (("c2 milksad", ffi.spec(ffi.T_MILKSAD), 1, 28, 1), ("c3 sha256", ffi.spec(ffi.T_SHA256), 3, 25, 3)):
+rows = [("c2 milksad", ffi.spec(ffi.T_MILKSAD), 1, 28, 1), ("c3 sha256", ffi.spec(ffi.T_SHA256), 3, 25, 3)]
+if os.environ.get("PROBE_MORE"):   # config 4 (all four LCG variants, compressed keys: 2^26 inputs = 2^28 keys per block) and a Milksad scan that hashes both key forms
+    rows = [("c4 lcg", ffi.spec(ffi.T_LCG), 1, 26, 4), ("milksad both forms", ffi.spec(ffi.T_MILKSAD), 3, 27, 1)]
+for name, spec, flags, log2, per in rows:
     if name.startswith("c3"):
         h, k = zip(*wl.c3_decoys())
         eng.targets_set(list(h), list(k))
