@@ -30,6 +30,9 @@
 #define VK_F_EMIT 0x10000u /* internal: generate-mode records */
 
 #define VK_BLOCK 256
+#ifndef VK_MILKSAD_PAIRS
+#define VK_MILKSAD_PAIRS 1 /* pass 1 of the Milksad instantiation transforms its items two at a time */
+#endif
 #ifndef VK_SWEEP_WAVES
 #define VK_SWEEP_WAVES 2 /* minimum waves per SIMD the sweep kernel is register-budgeted for */
 #endif
@@ -309,6 +312,8 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
         // ---------------------------------------------------------------- pass 1
         fe c;
         u32 r = 0, sub = 0;
+        u32 kw_next[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // Milksad: the key of item b + 1, made together with item b's (transform_milksad2)
+        bool have_next = false;
 #pragma unroll 1
         for (u32 b = 0; b < B; b++) {
             const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
@@ -316,7 +321,23 @@ __global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(cons
             // parked per item: X*ZZ^2, Y, e = ZZZ and the running product of e: y = Y / e, x = X*ZZ^2 / e^2 (ZZ^3 = ZZZ^2)
             uint4 *it = wk + (u64)b * 8 * nth;
             {
-                const bool have = item_key<KIND>(kw, p, off, sub);
+                bool have;
+                if (KIND == VK_T_MILKSAD && VK_MILKSAD_PAIRS) {
+                    // one slot per input: item b + 1 is the input VK_BLOCK further on.  Even items transform both (two interleaved
+                    // MT19937 chains), odd items take what the even one left
+                    if ((b & 1u) == 0) {
+                        const u64 off1 = off + VK_BLOCK, sa = p.lo + off, sb = p.lo + off1;
+                        transform_milksad2(kw, kw_next, (u32)sa, (u32)sb);
+                        have = off <= p.span && sa <= 0xFFFFFFFFull;          // transform_milksad's skip rule
+                        have_next = off1 <= p.span && sb <= 0xFFFFFFFFull;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) kw[i] = kw_next[i];
+                        have = have_next;
+                    }
+                } else {
+                    have = item_key<KIND>(kw, p, off, sub);
+                }
                 u32 k[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) k[i] = kw[7 - i];

@@ -166,6 +166,55 @@ VK_DEV bool transform_milksad(u32 kw[8], u64 seed)
     return true;
 }
 
+// Two seeds at once, the two init_genrand chains interleaved step by step.  A chain is 1212 dependent instructions; with two waves
+// on a SIMD a second wave adds nothing to such a chain (the older wave's cadence leaves no room for the other's instructions),
+// a second chain in the same lane makes a step 22 % cheaper (tools/ubench_chain.hip, profiles/r05_ubench_chain.txt) -- and no
+// statement is followed by its own consumer, so the hazard nop behind every single-step statement goes as well.  The sweep kernel
+// transforms its items in pairs (vk_kernels.cuh, pass 1).
+VK_DEV void transform_milksad2(u32 kwa[8], u32 kwb[8], u32 sa, u32 sb)
+{
+    u32 loa[9], hia[8], lob[9], hib[8];
+    u32 a = sa, b = sb;
+    loa[0] = a;
+    lob[0] = b;
+#pragma unroll
+    for (int i = 1; i <= 8; i++) {
+        a = mt_init_step(a, (u32)i);
+        b = mt_init_step(b, (u32)i);
+        loa[i] = a;
+        lob[i] = b;
+    }
+#pragma unroll 4
+    for (u32 i = 9; i < 397; i++) {
+        a = mt_init_step(a, i);
+        b = mt_init_step(b, i);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        a = mt_init_step(a, 397u + (u32)i);
+        b = mt_init_step(b, 397u + (u32)i);
+        hia[i] = a;
+        hib[i] = b;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 y = (loa[i] & 0x80000000u) | (loa[i + 1] & 0x7fffffffu);
+        u32 v = hia[i] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        v ^= v >> 11;
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= v >> 18;
+        kwa[i] = bswap32(v);
+        y = (lob[i] & 0x80000000u) | (lob[i + 1] & 0x7fffffffu);
+        v = hib[i] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        v ^= v >> 11;
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= v >> 18;
+        kwb[i] = bswap32(v);
+    }
+}
+
 // ---- MT19937-64 -------------------------------------------------------------------------
 VK_DEV u64 mt64_init_step(u64 prev, u64 i) { return 6364136223846793005ull * (prev ^ (prev >> 62)) + i; }
 
