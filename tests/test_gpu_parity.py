@@ -1279,3 +1279,30 @@ def test_large_chain_depth_keeps_the_workspace_bounded(eng, vko):
     st, _ = eng.sweep(sp, 4000, 4000 + 299, flags=1)
     ost, _ = vko.sweep(osp, 4000, 4000 + 299, flags=1 | vko.F_BATCHED, nthreads=8)
     assert st["keys"] == ost["keys"] == 300 * 8 * depth and st["digest"] == ost["digest"]
+
+
+def test_a_failed_engine_creation_does_not_poison_the_next_one():
+    """The HIP runtime keeps an error until it is read.  An engine whose table does not fit (here: the card's memory is held by a
+    plain hipMalloc) fails with a clean error, and the next engine of the same process must not find that "out of memory" behind its
+    first kernel launch (round 5: four ranks sharing one card, profiles/r05g_bench_four_ranks_shared_device.json)."""
+    import ctypes as C
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    keep = 24 << 30                      # leaves room for a default engine (11.8 GB table + 4.3 GB workspace), not for 120 GB
+    hog = C.c_void_p()
+    if free.value > keep + (8 << 30):
+        assert hip.hipMalloc(C.byref(hog), C.c_size_t(free.value - keep)) == 0
+    try:
+        with pytest.raises(ffi.VkError) as ei:
+            vuke_amd.Engine(0, layout=1)
+        assert "out of memory" in str(ei.value)
+        e = vuke_amd.Engine(0)           # same process, same thread: must come up
+        st, _ = e.sweep(ffi.spec(ffi.T_MILKSAD), 0, 1023)
+        assert st["keys"] == 1024
+        e.close()
+    finally:
+        if hog.value:
+            assert hip.hipFree(hog) == 0

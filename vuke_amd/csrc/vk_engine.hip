@@ -76,6 +76,15 @@ struct vk_engine {
     std::string warn; // what a successful call wants the caller to know (vk_last_warning); cleared on entry of every call that can set it
 };
 
+// The lock every entry point takes.  It also reads away whatever error an EARLIER runtime call of this process left behind (a failed
+// hipMalloc of another engine, another library in the process): the checks behind the kernel launches read hipGetLastError(), and the
+// runtime keeps an error until somebody reads it -- found by four ranks sharing one card in round 5: three 120 GB tables did not fit,
+// and the fall-back engine of the same process then reported the first attempt's "out of memory" at its first launch.
+struct vk_api_lock {
+    std::lock_guard<std::mutex> lk;
+    explicit vk_api_lock(std::mutex &m) : lk(m) { (void)hipGetLastError(); }
+};
+
 // slot `i` of the engine's scratch, at least `bytes` long (contents undefined); nullptr + e->err on failure
 static void *scratch(vk_engine *e, int i, size_t bytes)
 {
@@ -93,6 +102,7 @@ static void *scratch(vk_engine *e, int i, size_t bytes)
     if (c != hipSuccess) {
         e->scr[i] = nullptr;
         e->err = std::string("hipMalloc of ") + std::to_string(cap) + " scratch bytes failed: " + hipGetErrorString(c);
+        (void)hipGetLastError(); // read it away: see HIPCHK
         return nullptr;
     }
     e->scr_cap[i] = cap;
@@ -109,6 +119,7 @@ static void *scratch(vk_engine *e, int i, size_t bytes)
             char _b[512];                                                                           \
             snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
             (e)->err = _b;                                                                          \
+            (void)hipGetLastError(); /* the runtime keeps the error until it is read: a later launch check must not find it */ \
             return VK_E_HIP;                                                                        \
         }                                                                                           \
     } while (0)
@@ -235,6 +246,7 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(e, VK_E_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (device < 0 || device >= n) return fail(e, VK_E_INVALID_ARG, "device index out of range");
     HIPCHK(e, hipSetDevice(device));
+    (void)hipGetLastError(); // start from a clean "last error" (vk_api_lock)
     e->device = device;
     hipDeviceProp_t prop;
     HIPCHK(e, hipGetDeviceProperties(&prop, device));
@@ -428,7 +440,7 @@ extern "C" int vk_engine_info(const vk_engine *e, vk_engine_info_t *out)
 extern "C" int vk_targets_set(vk_engine *e, const uint8_t *h160, const uint8_t *kind, size_t n)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     HIPCHK(e, hipSetDevice(e->device));
     if (e->tgt) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -720,7 +732,7 @@ extern "C" int vk_sweep(vk_engine *e, const vk_transform_spec *t, uint64_t lo, u
                         size_t hit_cap, vk_sweep_stats *out)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     int rc = validate_spec(e, t);
     if (rc) return rc;
     if (!out) return fail(e, VK_E_INVALID_ARG, "stats out pointer is NULL");
@@ -753,7 +765,7 @@ extern "C" int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t lo
                            uint8_t *privkeys, uint8_t *h160_c, uint8_t *h160_u, uint8_t *valid, vk_sweep_stats *out)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     int rc = validate_spec(e, t);
     if (rc) return rc;
     if (hi < lo) return fail(e, VK_E_INVALID_ARG, "seed_hi < seed_lo");
@@ -820,7 +832,7 @@ static int generate_text(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
                          uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out, bool verbose)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     const u32 stride = verbose ? VK_VERBOSE_STRIDE : VK_LINE_STRIDE;
     int rc = validate_spec(e, t);
     if (rc) return rc;
@@ -979,7 +991,7 @@ extern "C" int vk_generate_columns(vk_engine *e, const vk_transform_spec *t, uin
                                    vk_record_columns *cols, vk_sweep_stats *out)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     int rc = validate_spec(e, t);
     if (rc) return rc;
     if (hi < lo) return fail(e, VK_E_INVALID_ARG, "seed_hi < seed_lo");
@@ -1031,7 +1043,7 @@ extern "C" int vk_generate_columns(vk_engine *e, const vk_transform_spec *t, uin
 extern "C" int vk_derive_columns(vk_engine *e, const uint8_t *keys, size_t n, vk_record_columns *cols)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     int rc = check_columns(e, cols, n, false, "vk_derive_columns");
     if (rc) return rc;
     if (n == 0) return VK_OK;
@@ -1065,7 +1077,7 @@ extern "C" int vk_derive_batch_pub(vk_engine *e, const uint8_t *keys, size_t n, 
                                    uint8_t *pub_xy)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     if (n == 0) return VK_OK;
     if (!keys) return fail(e, VK_E_INVALID_ARG, "keys is NULL");
     HIPCHK(e, hipSetDevice(e->device));
@@ -1134,7 +1146,7 @@ extern "C" int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, cons
                                   uint8_t *valid)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     int rc = validate_spec(e, t);
     if (rc) return rc;
     if (n == 0) return VK_OK;
@@ -1179,7 +1191,7 @@ extern "C" int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, cons
 extern "C" int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     if (!words) return fail(e, VK_E_INVALID_ARG, "words is NULL");
     for (int i = 0; i < 2048; i++) {
         const uint8_t *w = words + 8 * i;
@@ -1229,7 +1241,7 @@ static int set_mb_salt(vk_engine *e, const uint8_t *pass, size_t len)
 extern "C" int vk_multibit_passphrase_set(vk_engine *e, const uint8_t *passphrase, size_t len)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     if (len && !passphrase) return fail(e, VK_E_INVALID_ARG, "passphrase is NULL");
     return set_mb_salt(e, passphrase, len);
 }
@@ -1411,7 +1423,7 @@ static void note_overlong(vk_engine *e, const vk_transform_spec *t, size_t overl
 extern "C" size_t vk_last_warning(vk_engine *e, char *buf, size_t cap)
 {
     if (!e) return 0;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     const size_t n = e->warn.size();
     if (buf && cap) {
         const size_t c = std::min(n, cap - 1);
@@ -1425,7 +1437,7 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
                                     uint8_t *keys_out, uint8_t *valid)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     e->warn.clear();
     int rc = validate_spec(e, t, true);
     if (rc) return rc;
@@ -1456,7 +1468,7 @@ extern "C" int vk_scan_strings(vk_engine *e, const vk_transform_spec *t, const u
                                vk_hit *hits, size_t hit_cap, vk_sweep_stats *out)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     e->warn.clear();
     int rc = validate_spec(e, t, true);
     if (rc) return rc;
@@ -1506,7 +1518,7 @@ extern "C" int vk_scan_strings(vk_engine *e, const vk_transform_spec *t, const u
 extern "C" int vk_rescan_strings(vk_engine *e, uint32_t flags, vk_hit *hits, size_t hit_cap, vk_sweep_stats *out)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     if (!out) return fail(e, VK_E_INVALID_ARG, "stats out pointer is NULL");
     if (!(flags & (VK_F_COMPRESSED | VK_F_UNCOMPRESSED)) || (flags & ~(VK_F_COMPRESSED | VK_F_UNCOMPRESSED)))
         return fail(e, VK_E_INVALID_ARG, "flags must be a non-empty subset of VK_F_COMPRESSED | VK_F_UNCOMPRESSED");
@@ -1540,7 +1552,7 @@ extern "C" int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *
                                          const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     e->warn.clear();
     int rc = validate_spec(e, t, true);
     if (rc) return rc;
@@ -1636,7 +1648,7 @@ extern "C" int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy, size_t n_f
                                 size_t n_pass, const uint32_t *path, uint32_t depth, uint32_t count, uint8_t *keys_out, uint8_t *valid)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     if (!e->d_wordlist) return fail(e, VK_E_INVALID_ARG, "bitimage needs the BIP-39 word list: call vk_bip39_wordlist_set first");
     if (n_files == 0 || count == 0) return VK_OK;
     if (!entropy || !pass_offsets || !keys_out || !valid || n_pass == 0) return fail(e, VK_E_INVALID_ARG, "entropy / pass_offsets / keys_out / valid is NULL or n_pass is 0");
@@ -1707,7 +1719,7 @@ extern "C" int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy, size_t n_f
 extern "C" int vk_scan_keys(vk_engine *e, const uint8_t *keys, size_t n, uint32_t flags, vk_hit *hits, size_t hit_cap, vk_sweep_stats *out)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     if (!out) return fail(e, VK_E_INVALID_ARG, "stats out pointer is NULL");
     if (!(flags & (VK_F_COMPRESSED | VK_F_UNCOMPRESSED)) || (flags & ~(VK_F_COMPRESSED | VK_F_UNCOMPRESSED)))
         return fail(e, VK_E_INVALID_ARG, "flags must be a non-empty subset of VK_F_COMPRESSED | VK_F_UNCOMPRESSED");
@@ -1748,7 +1760,7 @@ static void launch_emit(const vk_spec_dev &spec, u64 seed, u32 *out, hipStream_t
 extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const vk_search_target *tg, vk_search_result *out)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     if (!t || !tg || !out) return fail(e, VK_E_INVALID_ARG, "spec / target / out is NULL");
     if (hi < lo) return fail(e, VK_E_INVALID_ARG, "seed_hi < seed_lo");
     const bool slot_kind = t->kind == VK_T_SHA256 || t->kind == VK_T_DOUBLE_SHA256 || t->kind == VK_T_MD5 || t->kind == VK_T_DIRECT;
@@ -1869,7 +1881,7 @@ extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
 extern "C" int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digit, uint8_t xy[64])
 {
     if (!e || !xy) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     if (window >= e->nwin) return fail(e, VK_E_INVALID_ARG, "table index out of range");
     {
         const vk_win_desc &w = e->wins[window];
@@ -1890,7 +1902,7 @@ extern "C" int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digi
 extern "C" int vk_debug_chain_stop(vk_engine *e, int stages)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     e->chain_stop = stages <= 0 ? 99 : stages;
     return VK_OK;
 }
@@ -1898,7 +1910,7 @@ extern "C" int vk_debug_chain_stop(vk_engine *e, int stages)
 extern "C" int vk_debug_scratch(vk_engine *e, int slot, size_t offset, uint8_t *out, size_t n)
 {
     if (!e || !out) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     if (slot < 0 || slot >= VK_SCR_SLOTS || !e->scr[slot] || offset + n > e->scr_cap[slot]) return fail(e, VK_E_INVALID_ARG, "vk_debug_scratch: slot / range");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipMemcpy(out, (const unsigned char *)e->scr[slot] + offset, n, hipMemcpyDeviceToHost));
@@ -1908,7 +1920,7 @@ extern "C" int vk_debug_scratch(vk_engine *e, int slot, size_t offset, uint8_t *
 extern "C" int vk_debug_field(vk_engine *e, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out)
 {
     if (!e || !a || !out || n == 0) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     HIPCHK(e, hipSetDevice(e->device));
     u32 *da = nullptr, *db = nullptr, *dout = nullptr;
     HIPCHK(e, hipMalloc(&da, n * 32));
@@ -1939,7 +1951,7 @@ extern "C" int vk_debug_field(vk_engine *e, int op, const uint8_t *a, const uint
 extern "C" int vk_debug_ring_knobs(vk_engine *e, uint32_t chunk_iters, uint32_t waves_per_simd, uint32_t workers)
 {
     if (!e) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     if (chunk_iters > 100000 || waves_per_simd > 16 || workers > 65536) return fail(e, VK_E_INVALID_ARG, "vk_debug_ring_knobs: value out of range");
     e->dbg_ring_chunk = chunk_iters;
     e->dbg_ring_wps = waves_per_simd;
@@ -1951,7 +1963,7 @@ extern "C" int vk_debug_ring_knobs(vk_engine *e, uint32_t chunk_iters, uint32_t 
 extern "C" int vk_debug_scan(vk_engine *e, const uint32_t *in, size_t n, uint32_t *out)
 {
     if (!e || !in || !out || n == 0 || n > (1u << 26)) return VK_E_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(e->mu);
+    vk_api_lock lk(e->mu);
     HIPCHK(e, hipSetDevice(e->device));
     const size_t off_out = ((n * 4 + 255) / 256) * 256, off_temp = 2 * off_out;
     SCRATCH(e, d, unsigned char *, 7, off_temp + scan_temp_bytes(n));
