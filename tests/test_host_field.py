@@ -62,3 +62,5 @@ def test_host_emulation_sees_a_dropped_carry(tmp_path):
     _, a, b = field_cases()
     got = run(exe, 0, a, b)
     assert any(g != x * y % P for x, y, g in zip(a, b, got))
+    got = run(exe, 16, a, b)   # the fused pair of products has flags of its own (limb 16, the second short chain)
+    assert any(g != 2 * x * y % P for x, y, g in zip(a, b, got))
