@@ -1306,3 +1306,26 @@ def test_a_failed_engine_creation_does_not_poison_the_next_one():
     finally:
         if hog.value:
             assert hip.hipFree(hog) == 0
+
+
+def test_milksad_items_in_pairs_with_odd_batches_and_ragged_ranges(vko):
+    """Pass 1 of the Milksad sweep transforms items b and b + 1 together (transform_milksad2, two interleaved MT19937 chains): odd
+    batch sizes (the last item of a tile has no partner), ranges that end inside a tile and ranges that cross the 2^32 ceiling of
+    the seeds (the partner of a valid item may be beyond it) against the oracle's counters, digest and hits."""
+    import vuke_amd
+    from vuke_amd import _ffi as ffi
+    rnd = random.Random(55)
+    for batch, bpc in ((1, 1), (3, 2), (5, 1), (7, 3), (256, 2)):
+        e = vuke_amd.Engine(0, batch=batch, blocks_per_cu=bpc)
+        for lo, n in ((0, 1), (7, 255), (1000, 256 * batch + 1), (2**32 - 700, 1400), (2**32 - 256 * batch - 3, 256 * batch + 3),
+                      (rnd.getrandbits(31), 256 * batch * 3 + rnd.randrange(1, 256))):
+            hi = lo + n - 1
+            planted = [lo + (n * 2) // 3, lo, min(hi, 2**32 - 1)]
+            tg = [bytes(vko.derive(vko.milksad_key(s)).h160_c) for s in planted if s < 2**32]
+            e.targets_set(tg, [ffi.TARGET_P2PKH] * len(tg))
+            st, hits = e.sweep(ffi.spec(ffi.T_MILKSAD), lo, hi, flags=3)
+            m = vko.Matcher([vko.derive(vko.milksad_key(s)).p2pkh_compressed.decode() for s in planted if s < 2**32])
+            ost, ohits = vko.sweep(vko.spec(vko.T_MILKSAD), lo, hi, flags=3, matcher=m, nthreads=8)
+            assert (st["inputs"], st["keys"], st["matches"], st["digest"]) == (ost["inputs"], ost["keys"], ost["matches"], ost["digest"]), (batch, lo, n)
+            assert sorted(h["seed"] for h in hits) == sorted(h["seed"] for h in ohits), (batch, lo, n)
+        e.close()
