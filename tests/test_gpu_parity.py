@@ -1328,4 +1328,9 @@ def test_milksad_items_in_pairs_with_odd_batches_and_ragged_ranges(vko):
             ost, ohits = vko.sweep(vko.spec(vko.T_MILKSAD), lo, hi, flags=3, matcher=m, nthreads=8)
             assert (st["inputs"], st["keys"], st["matches"], st["digest"]) == (ost["inputs"], ost["keys"], ost["matches"], ost["digest"]), (batch, lo, n)
             assert sorted(h["seed"] for h in hits) == sorted(h["seed"] for h in ohits), (batch, lo, n)
+            # MT19937-64 over the same ragged shapes (64-bit seeds: no ceiling)
+            lo64 = lo + (rnd.getrandbits(40) << 24)
+            st, _ = e.sweep(ffi.spec(ffi.T_MT64), lo64, lo64 + n - 1, flags=1)
+            ost, _ = vko.sweep(vko.spec(vko.T_MT64), lo64, lo64 + n - 1, flags=1, nthreads=8)
+            assert (st["inputs"], st["keys"], st["digest"]) == (ost["inputs"], ost["keys"], ost["digest"]), ("mt64", batch, lo64, n)
         e.close()

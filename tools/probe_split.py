@@ -23,6 +23,8 @@ tag = os.path.basename(os.environ.get("VUKE_HIP_LIB", "shipped"))
 rows = [("c2 milksad", ffi.spec(ffi.T_MILKSAD), 1, 28, 1), ("c3 sha256", ffi.spec(ffi.T_SHA256), 3, 25, 3)]
 if os.environ.get("PROBE_MORE"):   # config 4 (all four LCG variants, compressed keys: 2^26 inputs = 2^28 keys per block) and a Milksad scan that hashes both key forms
     rows = [("c4 lcg", ffi.spec(ffi.T_LCG), 1, 26, 4), ("milksad both forms", ffi.spec(ffi.T_MILKSAD), 3, 27, 1)]
+if os.environ.get("PROBE_MT64"):
+    rows = [("mt64", ffi.spec(ffi.T_MT64), 1, 28, 1)]
 for name, spec, flags, log2, per in rows:
     if name.startswith("c3"):
         h, k = zip(*wl.c3_decoys())
