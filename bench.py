@@ -152,7 +152,7 @@ class Workload:
 
 
 class Milksad(Workload):
-    tag, kernel = "c2", "vk_sweep_kernel<1u>"
+    tag, kernel = "c2", "vk_sweep_kernel<1u, 3>"
     # canonical algorithmic work per Milksad key (32-bit integer ops of a 4-bit-window reference algorithm)
     canonical_ops_per_key = 1736 + 213000 + 2168 + 1455
 
@@ -218,7 +218,7 @@ class Milksad(Workload):
 
 
 class Sha256Scan(Workload):
-    tag, kernel = "c3", "vk_sweep_kernel<0u>"
+    tag, kernel = "c3", "vk_sweep_kernel<0u, 2>"
     canonical_ops_per_key = 2168 + 213000 + 3 * 2168 + 2 * 1455
 
     def describe(self, eng):
@@ -265,7 +265,7 @@ class Sha256Scan(Workload):
 
 
 class LcgAll(Workload):
-    tag, kernel = "c4", "vk_sweep_kernel<3u>"
+    tag, kernel = "c4", "vk_sweep_kernel<3u, 3>"
     canonical_ops_per_key = 40 + 213000 + 2168 + 1455
 
     def describe(self, eng):
@@ -420,7 +420,7 @@ def main():
     ap.add_argument("--layout", type=int, default=None)
     ap.add_argument("--window-bits", type=int, default=None)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--blocks-per-cu", type=int, default=2)
+    ap.add_argument("--blocks-per-cu", type=int, default=0, help="workgroups per CU; 0 = per launch what the kernel instantiation is built for (3, or 2 where uncompressed keys are hashed)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))

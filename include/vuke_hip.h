@@ -144,8 +144,11 @@ typedef struct vk_engine_opts {
                               8..29 for the signed layout (0 = 29: nine windows, 120 GB) */
     uint32_t batch;        /* keys per lane sharing one field inversion (0 = default 128; the workspace, 128 B x batch x
                               lanes, is allocated when the engine is created) */
-    uint32_t blocks_per_cu;/* 256-thread workgroups per CU to launch (0 = what the sweep kernel's occupancy allows);
-                              tiles are handed out dynamically, so the value only sizes the grid and the workspace */
+    uint32_t blocks_per_cu;/* 256-thread workgroups per CU to launch.  0 = per launch, what the sweep kernel instantiation that
+                              runs it is built for: three (three waves per SIMD) for launches that hash compressed keys only --
+                              two for the sha256 family --, two where uncompressed keys are hashed (their LDS table lets two
+                              workgroups share a CU); the workspace is sized for three.  A value given here is used for every
+                              launch; tiles are handed out dynamically, so it only sizes the grid and the workspace */
     uint32_t layout;       /* VK_LAYOUT_*: 0 = uniform unsigned window_bits-wide windows (default) */
     void *stream;          /* hipStream_t to run on (NULL = engine creates its own) */
     uint32_t algo;         /* VK_ALGO_CHAIN (0); other values are rejected */
@@ -160,7 +163,7 @@ typedef struct vk_engine_info_t {
                                ten 26/25-bit windows of 26, 25 the eleven of 24) and the request's own number is not echoed */
     uint32_t windows;       /* table lookups per key (ceil(256 / requested width)); windows - 1 point additions */
     uint32_t batch;         /* keys per lane per field inversion */
-    uint32_t blocks_per_cu;
+    uint32_t blocks_per_cu; /* the value the engine was created with, or 3 (the widest grid of the automatic choice) */
     uint32_t layout;
     uint32_t _pad;
     uint64_t table_bytes;   /* table entries * 64 */

@@ -62,7 +62,7 @@ def test_default_config_two_steps_digest_checked_against_the_oracle():
     assert sp["total_s"] == pytest.approx(sp["hip_runtime_s"] + sp["alloc_s"] + sp["table_wall_s"] + sp["other_s"]) and 0 < sp["table_build_s"] < 0.2
     if o["roofline"]["frac"] is not None:
         # the code object's own count: more than three waves per SIMD would allow (168), at most what two allow (256)
-        assert 168 < o["roofline"]["vgpr"] <= 256 and o["roofline"]["waves_per_simd"] == 2
+        assert 128 < o["roofline"]["vgpr"] <= 168 and o["roofline"]["waves_per_simd"] == 3   # the three-wave instantiation (compressed-only launch, automatic grid)
     # the one-sweep run that follows the timed region: the whole 2^32 space on the geometry the product picks for it
     s = o["strong"]
     assert s["covers_full_2p32"] is True and s["keys"] == 2**32 and s["matches"] == 1026

@@ -62,7 +62,7 @@ def test_bench_geometry_full_2p32_sweep_against_the_oracles_golden():
     g = wl.load_golden("milksad_2p32.json")
     assert g is not None, "tests/golden/milksad_2p32.json is missing: run tests/golden/make_milksad_2p32.py"
     pl = wl.load_golden("milksad_planted.json")["planted"]
-    e = vuke_amd.Engine(0, layout=1, batch=256, blocks_per_cu=2)
+    e = vuke_amd.Engine(0, layout=1, batch=256)
     try:
         info = e.info()
         assert (info["layout"], info["windows"], info["batch"]) == (1, 9, 256)
@@ -228,7 +228,7 @@ def test_randomized_parity_on_the_bench_geometry(vko):
     from vuke_amd import _ffi as ffi
     rnd = random.Random(20261004)
     threads = min(16, len(os.sched_getaffinity(0)))
-    e = vuke_amd.Engine(0, layout=1, batch=256, blocks_per_cu=2)
+    e = vuke_amd.Engine(0, layout=1, batch=256)
     try:
         edges = [0, 2**31 - 1, 2**31, 2**32 - 1, 2**32, 2**63, 2**64 - 1, 10**9, 10**18]
         for c in range(160):

@@ -1315,7 +1315,9 @@ def test_milksad_items_in_pairs_with_odd_batches_and_ragged_ranges(vko):
     import vuke_amd
     from vuke_amd import _ffi as ffi
     rnd = random.Random(55)
-    for batch, bpc in ((1, 1), (3, 2), (5, 1), (7, 3), (256, 2)):
+    # blocks_per_cu 0 = the automatic grid: compressed-only launches run the three-wave instantiation, the others (and every explicit
+    # value below three) the two-wave one -- both are held to the oracle here, on both flag sets
+    for batch, bpc in ((1, 1), (3, 2), (5, 0), (7, 3), (256, 0)):
         e = vuke_amd.Engine(0, batch=batch, blocks_per_cu=bpc)
         for lo, n in ((0, 1), (7, 255), (1000, 256 * batch + 1), (2**32 - 700, 1400), (2**32 - 256 * batch - 3, 256 * batch + 3),
                       (rnd.getrandbits(31), 256 * batch * 3 + rnd.randrange(1, 256))):
@@ -1323,11 +1325,12 @@ def test_milksad_items_in_pairs_with_odd_batches_and_ragged_ranges(vko):
             planted = [lo + (n * 2) // 3, lo, min(hi, 2**32 - 1)]
             tg = [bytes(vko.derive(vko.milksad_key(s)).h160_c) for s in planted if s < 2**32]
             e.targets_set(tg, [ffi.TARGET_P2PKH] * len(tg))
-            st, hits = e.sweep(ffi.spec(ffi.T_MILKSAD), lo, hi, flags=3)
             m = vko.Matcher([vko.derive(vko.milksad_key(s)).p2pkh_compressed.decode() for s in planted if s < 2**32])
-            ost, ohits = vko.sweep(vko.spec(vko.T_MILKSAD), lo, hi, flags=3, matcher=m, nthreads=8)
-            assert (st["inputs"], st["keys"], st["matches"], st["digest"]) == (ost["inputs"], ost["keys"], ost["matches"], ost["digest"]), (batch, lo, n)
-            assert sorted(h["seed"] for h in hits) == sorted(h["seed"] for h in ohits), (batch, lo, n)
+            for flags in (3, 1):
+                st, hits = e.sweep(ffi.spec(ffi.T_MILKSAD), lo, hi, flags=flags)
+                ost, ohits = vko.sweep(vko.spec(vko.T_MILKSAD), lo, hi, flags=flags, matcher=m, nthreads=8)
+                assert (st["inputs"], st["keys"], st["matches"], st["digest"]) == (ost["inputs"], ost["keys"], ost["matches"], ost["digest"]), (batch, bpc, flags, lo, n)
+                assert sorted(h["seed"] for h in hits) == sorted(h["seed"] for h in ohits), (batch, bpc, flags, lo, n)
             # MT19937-64 over the same ragged shapes (64-bit seeds: no ceiling)
             lo64 = lo + (rnd.getrandbits(40) << 24)
             st, _ = e.sweep(ffi.spec(ffi.T_MT64), lo64, lo64 + n - 1, flags=1)

@@ -19,9 +19,9 @@ import bench  # noqa: E402  (csrc_hash only)
 
 src_root, tag, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
 src = os.path.join(src_root, f"c{cfg}")
-KERNELS = {"2": ["vk_sweep_kernel<1u>"], "3": ["vk_sweep_kernel<0u>"], "4": ["vk_sweep_kernel<3u>"],
-           "5m": ["vk_ring_kernel<vk_pbkdf2_body>", "vk_mb_prepare_kernel", "vk_mb_middle_kernel", "vk_mb_final_kernel", "vk_sweep_kernel<100u>"],
-           "5e": ["vk_ring_kernel<vk_electrum_body>", "vk_electrum_prepare_kernel", "vk_electrum_final_kernel", "vk_sweep_kernel<100u>"]}[cfg]
+KERNELS = {"2": ["vk_sweep_kernel<1u, 3>"], "3": ["vk_sweep_kernel<0u, 2>"], "4": ["vk_sweep_kernel<3u, 3>"],
+           "5m": ["vk_ring_kernel<vk_pbkdf2_body>", "vk_mb_prepare_kernel", "vk_mb_middle_kernel", "vk_mb_final_kernel", "vk_sweep_kernel<100u"],
+           "5e": ["vk_ring_kernel<vk_electrum_body>", "vk_electrum_prepare_kernel", "vk_electrum_final_kernel", "vk_sweep_kernel<100u"]}[cfg]
 dst = os.path.join(ROOT, "profiles")
 
 

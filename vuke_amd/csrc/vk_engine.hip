@@ -54,7 +54,8 @@ struct vk_engine {
     double table_build_seconds = 0.0;
     double runtime_init_seconds = 0.0, alloc_seconds = 0.0, table_wall_seconds = 0.0; // where vk_engine_create's wall time went
     u32 batch = 128;
-    u32 blocks_per_cu = 0;
+    u32 blocks_per_cu = 0;   // workgroups per CU the grids and the workspace are sized for
+    bool bpc_auto = true;    // not given by the caller: every launch takes what its instantiation is built for (2 or 3, vk_sweep_design_waves)
     uint4 *table = nullptr;
     uint4 *tgt = nullptr;
     u32 tgt_cap = 0;
@@ -311,6 +312,7 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     if (opts && opts->blocks_per_cu) {
         if (opts->blocks_per_cu > 8) return fail(e, VK_E_INVALID_ARG, "blocks_per_cu must be <= 8");
         e->blocks_per_cu = opts->blocks_per_cu;
+        e->bpc_auto = false;
     }
     if (opts && opts->stream) {
         e->stream = (hipStream_t)opts->stream;
@@ -321,11 +323,7 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     HIPCHK(e, hipEventCreate(&e->ev0));
     HIPCHK(e, hipEventCreate(&e->ev1));
     HIPCHK(e, hipMalloc(&e->d_stats, 12 * sizeof(u64)));
-    if (e->blocks_per_cu == 0) {
-        int occ = 0;
-        HIPCHK(e, vk_sweep_occupancy(&occ));
-        e->blocks_per_cu = (u32)std::max(1, std::min(occ, 4));
-    }
+    if (e->blocks_per_cu == 0) e->blocks_per_cu = 3; // the widest grid an instantiation is built for; launches that want two use two
     HIPCHK(e, hipMalloc(&e->d_wins, sizeof e->wins));
     HIPCHK(e, hipMemcpy(e->d_wins, e->wins, sizeof e->wins, hipMemcpyHostToDevice));
     const double t_runtime = wall_now(); // the HIP runtime is up (first engine of a process: ~0.25 s), the small buffers exist
@@ -601,7 +599,12 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     // Tile = VK_BLOCK lanes x R inputs per lane (R * slots keys share one field inversion).  R is the largest batch
     // that fits e->batch, then shrunk so that every workgroup of the grid gets the same number of full tiles
     // (a 2^28-input block over 768 workgroups would otherwise end with a third of them idle for one tile).
-    const u64 max_grid = (u64)e->cu_count * e->blocks_per_cu;
+    // workgroups per CU: the caller's choice, else what the instantiation that will run is built for (three waves per SIMD for the
+    // compressed-only launches of most kinds, two where uncompressed keys are hashed: vk_sweep_tu.hip)
+    const u32 design = vk_sweep_design_waves(kind, flags);
+    const u32 bpc = e->bpc_auto ? design : e->blocks_per_cu;
+    const u32 waves = bpc >= 3 ? design : 2u; // which instantiation: the three-wave one only under a grid made for it
+    const u64 max_grid = (u64)e->cu_count * bpc;
     u32 R = std::max(1u, e->batch / slots);
     {
         const u64 per_lane = span / (max_grid * VK_BLOCK) + 1; // inputs per lane if the grid shared them evenly
@@ -680,7 +683,7 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     p.out_pub = io.out_pub;
 
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    if (!(vk_launch_sweep_g0(kind, p, grid, e->stream) || vk_launch_sweep_g1(kind, p, grid, e->stream) || vk_launch_sweep_g2(kind, p, grid, e->stream)))
+    if (!(vk_launch_sweep_g0(kind, p, grid, e->stream, waves) || vk_launch_sweep_g1(kind, p, grid, e->stream, waves) || vk_launch_sweep_g2(kind, p, grid, e->stream, waves)))
         return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));

@@ -33,9 +33,6 @@
 #ifndef VK_MILKSAD_PAIRS
 #define VK_MILKSAD_PAIRS 1 /* pass 1 of the Milksad instantiation transforms its items two at a time */
 #endif
-#ifndef VK_SWEEP_WAVES
-#define VK_SWEEP_WAVES 2 /* minimum waves per SIMD the sweep kernel is register-budgeted for */
-#endif
 
 struct vk_hit_dev { // must match vk_hit in include/vuke_hip.h (72 bytes)
     u64 seed;
@@ -273,8 +270,15 @@ VK_DEV void sweep_counters(const vk_sweep_params &p, const u64 *dg, u32 n_keys, 
     }
 }
 
-template <u32 KIND>
-__global__ void __launch_bounds__(VK_BLOCK, VK_SWEEP_WAVES) vk_sweep_kernel(const vk_sweep_params p)
+// WAVES = the waves per SIMD (= resident workgroups per CU) the instantiation is register-budgeted for.  2: every field element in
+// VGPRs (196 - 206 of them); 3: 168 VGPRs, 22 - 33 of the coldest values in scratch.  Round 4 measured three waves 4 % SLOWER than
+// two (37 - 46 spilled registers then, and a part that gave the gain back in clock); after round 5's diet the same experiment is
+// +2.2 % on the Milksad sweep and +2.8 % on the LCG sweep (profiles/r05_three_waves_again.txt), so compressed-only launches of the
+// Milksad / MT19937-64 / raw-key / LCG / xorshift kinds run the WAVES = 3 instantiation on a grid of three workgroups per CU; a launch
+// that hashes uncompressed keys keeps WAVES = 2: its 53 KB schedule table lets only two workgroups share a CU's LDS
+// (vk_sweep_tu.hip: vk_sweep_design_waves).  Four waves: 315 spilled registers, -13 %.
+template <u32 KIND, int WAVES>
+__global__ void __launch_bounds__(VK_BLOCK, WAVES) vk_sweep_kernel(const vk_sweep_params p)
 {
     const u32 tid = threadIdx.x;
     const u32 B = p.R * p.slots;
