@@ -31,7 +31,8 @@
 
 #define VK_BLOCK 256
 #ifndef VK_MILKSAD_PAIRS
-#define VK_MILKSAD_PAIRS 1 /* pass 1 of the Milksad instantiation transforms its items two at a time */
+#define VK_MILKSAD_PAIRS 1 /* pass 1 of the two-wave Milksad instantiation transforms its items two at a time (with three waves on a SIMD the serial
+                              MT19937 chain is covered by the other two: pairs are 1.3 % SLOWER there, profiles/r05_three_waves_again.txt) */
 #endif
 
 struct vk_hit_dev { // must match vk_hit in include/vuke_hip.h (72 bytes)
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(VK_BLOCK, WAVES) vk_sweep_kernel(const vk_swee
             uint4 *it = wk + (u64)b * 8 * nth;
             {
                 bool have;
-                if (KIND == VK_T_MILKSAD && VK_MILKSAD_PAIRS) {
+                if (KIND == VK_T_MILKSAD && VK_MILKSAD_PAIRS && WAVES < 3) {
                     // one slot per input: item b + 1 is the input VK_BLOCK further on.  Even items transform both (two interleaved
                     // MT19937 chains), odd items take what the even one left
                     if ((b & 1u) == 0) {
