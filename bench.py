@@ -131,6 +131,20 @@ def kernel_meta(kernel):
     return next((r for r in km["kernels"] if kernel in r["kernel"]), None)
 
 
+def sweep_kernel_name(kind, flags, blocks_per_cu):
+    """The instantiation of vk_sweep_kernel<KIND, WAVES, UNCOMP, WIDE> that runs a launch: a mirror of the engine's choice
+    (vuke_amd/csrc/vk_sweep_tu.hip: vk_sweep_design_form; vk_engine.hip: run_range), held to it on the GPU box through the
+    vk_debug_last_launch test hook (tests/test_gpu_bench.py).  The metadata and the PMC summary the roofline block quotes are
+    looked up under this name, so a run with another --blocks-per-cu prices the kernel it actually ran."""
+    three_wave_kinds = (1, 2, 3, 4, 100)   # milksad, mt64, lcg, xorshift, raw keys
+    if blocks_per_cu == 0 or blocks_per_cu >= 3:
+        if flags & 2:
+            return f"vk_sweep_kernel<{kind}u, 3, true, true>"
+        if kind in three_wave_kinds:
+            return f"vk_sweep_kernel<{kind}u, 3, false, false>"
+    return f"vk_sweep_kernel<{kind}u, 2, true, false>"
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 class Workload:
     """One BASELINE config: targets, warm-up (checked against the oracle's fixture), timed steps."""
@@ -141,6 +155,8 @@ class Workload:
     def __init__(self, args, rank, world):
         self.args, self.rank, self.world = args, rank, world
         self.digest_checked = self.digest_bad = 0
+        if getattr(self, "sweep_kind", None) is not None:
+            self.kernel = sweep_kernel_name(self.sweep_kind, self.sweep_flags, getattr(args, "blocks_per_cu", 0))
 
     def check_digest(self, got, want):
         self.digest_checked += 1
@@ -152,7 +168,7 @@ class Workload:
 
 
 class Milksad(Workload):
-    tag, kernel = "c2", "vk_sweep_kernel<1u, 3>"
+    tag, sweep_kind, sweep_flags = "c2", 1, 1   # the kernel name follows from kind, flags and --blocks-per-cu (sweep_kernel_name)
     # canonical algorithmic work per Milksad key (32-bit integer ops of a 4-bit-window reference algorithm)
     canonical_ops_per_key = 1736 + 213000 + 2168 + 1455
 
@@ -218,7 +234,7 @@ class Milksad(Workload):
 
 
 class Sha256Scan(Workload):
-    tag, kernel = "c3", "vk_sweep_kernel<0u, 2>"
+    tag, sweep_kind, sweep_flags = "c3", 0, 3
     canonical_ops_per_key = 2168 + 213000 + 3 * 2168 + 2 * 1455
 
     def describe(self, eng):
@@ -265,7 +281,7 @@ class Sha256Scan(Workload):
 
 
 class LcgAll(Workload):
-    tag, kernel = "c4", "vk_sweep_kernel<3u, 3>"
+    tag, sweep_kind, sweep_flags = "c4", 3, 1
     canonical_ops_per_key = 40 + 213000 + 2168 + 1455
 
     def describe(self, eng):
@@ -420,7 +436,7 @@ def main():
     ap.add_argument("--layout", type=int, default=None)
     ap.add_argument("--window-bits", type=int, default=None)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--blocks-per-cu", type=int, default=0, help="workgroups per CU; 0 = per launch what the kernel instantiation is built for (3, or 2 where uncompressed keys are hashed)")
+    ap.add_argument("--blocks-per-cu", type=int, default=0, help="workgroups per CU; 0 = per launch the form the engine picks (three waves per SIMD: three 256-lane workgroups per CU, or one of 768 lanes where uncompressed keys are hashed); 2 = the two-wave form")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))

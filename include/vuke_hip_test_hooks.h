@@ -33,6 +33,16 @@ int vk_debug_ring_knobs(vk_engine *e, uint32_t chunk_iters, uint32_t waves_per_s
  * places the compacted text lines / column pages of generate mode. */
 int vk_debug_scan(vk_engine *e, const uint32_t *in, size_t n, uint32_t *out);
 
+/* Test hook: allocation-failure injection.  The hooks build replaces operator new for the library's own allocations; the k-th next
+ * one made by the calling thread inside the library (0 = the very next) fails once -- std::bad_alloc, or NULL from the nothrow form.
+ * after < 0 disarms.  Returns the number of allocations the thread made through the library since the previous call.  The boundary's
+ * promise under test: such a failure comes back as VK_E_NOMEM with vk_last_error set, never as an exception or a terminate. */
+long long vk_debug_fail_alloc(long long after);
+/* Test hook: the last sweep launch of the engine: out[0] = the kernel form (2 = two waves per SIMD, 256-lane workgroups; 3 = three
+ * waves, compressed keys only; 4 = three waves as one 768-lane workgroup per CU, uncompressed keys hashed), out[1] = workgroups,
+ * out[2] = lanes per workgroup, out[3] = inputs per lane per tile.  bench.py's name of the kernel it prices is held to this. */
+int vk_debug_last_launch(vk_engine *e, uint32_t out[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,8 @@
 include/vuke_hip.h declares, and refuses to run without a GPU (no CPU fallback)."""
 import os
 import re
+import subprocess
+import sys
 
 import pytest
 
@@ -42,7 +44,7 @@ def test_shipped_library_exports_no_test_hooks(built):
     -DVK_TEST_HOOKS) only: the shipped library exports none of them, the test build all of them plus the whole boundary."""
     from vuke_amd import _ffi
     hooks = declared_hooks()
-    assert hooks == sorted(_ffi.HOOK_EXPORTS) and len(hooks) == 6 and all(h.startswith("vk_debug_") for h in hooks)
+    assert hooks == sorted(_ffi.HOOK_EXPORTS) and len(hooks) == 8 and all(h.startswith("vk_debug_") for h in hooks)
     L, H = _ffi.load(), _ffi.load(hooks=True)
     for h in hooks:
         assert not hasattr(L, h), f"{h} exported by the shipped library"
@@ -180,3 +182,56 @@ def test_tests_cited_in_the_documents_exist():
             assert any(n.startswith(cited.rstrip("*")) for n in names), (doc, cited)
         for f in set(re.findall(r"tests/(test_\w+\.py)", text)):
             assert os.path.exists(os.path.join(ROOT, "tests", f)), (doc, f)
+
+
+def test_an_allocation_failure_inside_the_library_is_a_negative_code_not_an_exception(built):
+    """include/vuke_hip.h promises that nothing throws across the boundary.  Every extern "C" function of
+    vk_engine.hip is a function-try-block (VK_API_CATCH): std::bad_alloc -> VK_E_NOMEM with vk_last_error set.  Here, without a GPU:
+    vk_engine_create allocates the engine (nothrow new), reserves its error string and starts the HIP runtime; with the hooks
+    build's allocation-failure injection armed for the k-th allocation of this thread the call must come back with VK_E_NOMEM (the
+    failure hit one of the library's own allocations) or with what it returns unarmed (the k-th allocation does not exist) -- in a
+    child process, so that a std::terminate would be seen as a dead child and not take the test runner with it."""
+    code = r'''
+import ctypes as C, sys
+from vuke_amd import _ffi
+H = _ffi.load(hooks=True)
+e = C.c_void_p()
+base = H.vk_engine_create(0, C.byref(e))          # unarmed: VK_E_NO_DEVICE here, VK_OK on a GPU box
+if base == 0:
+    H.vk_engine_destroy(e)
+seen_nomem = 0
+for k in range(0, 6):
+    H.vk_debug_fail_alloc(k)
+    e = C.c_void_p()
+    rc = H.vk_engine_create(0, C.byref(e))
+    made = H.vk_debug_fail_alloc(-1)
+    msg = (H.vk_last_error(None) or b"").decode()
+    assert rc in (base, _ffi.VK_E_NOMEM), (k, rc, msg)
+    if rc == _ffi.VK_E_NOMEM:
+        seen_nomem += 1
+        assert not e.value and "memory" in msg, (k, msg)
+    elif rc == 0:
+        H.vk_engine_destroy(e)
+    print(k, rc, made, msg)
+assert seen_nomem >= 2, seen_nomem                   # k = 0 (the engine itself, nothrow new) and k = 1 (a throwing allocation)
+print("ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_every_extern_c_function_of_the_engine_is_guarded():
+    """The guard is structural: every extern "C" definition in vk_engine.hip that has a body of more than one line either is a
+    function-try-block closed by VK_API_CATCH / catch (...), or is one of the few that cannot throw (no allocation, no lock)."""
+    src = open(os.path.join(ROOT, "vuke_amd", "csrc", "vk_engine.hip")).read()
+    cannot_throw = {"vk_abi_version", "vk_device_count", "vk_slots_per_input", "vk_slots_per_string", "vk_last_error", "vk_engine_destroy",
+                    "vk_engine_create", "vk_engine_info", "vk_record_column_stride", "vk_debug_fail_alloc"}
+    names = re.findall(r'^extern "C" [\w \*]+?\b(vk_\w+)\(', src, flags=re.M)
+    assert len(names) >= 37
+    for n in names:
+        m = re.search(r'^extern "C" [^\n]*\b' + n + r'\([^{;]*?\)\s*(try)?\s*\{', src, flags=re.M | re.S)
+        assert m, n
+        if n in cannot_throw:
+            continue
+        assert m.group(1) == "try", f"{n} is not a function-try-block"
+    assert src.count("\nVK_API_CATCH(") >= 26

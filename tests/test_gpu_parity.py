@@ -1337,3 +1337,91 @@ def test_milksad_items_in_pairs_with_odd_batches_and_ragged_ranges(vko):
             ost, _ = vko.sweep(vko.spec(vko.T_MT64), lo64, lo64 + n - 1, flags=1, nthreads=8)
             assert (st["inputs"], st["keys"], st["digest"]) == (ost["inputs"], ost["keys"], ost["digest"]), ("mt64", batch, lo64, n)
         e.close()
+
+
+def test_every_kind_in_every_kernel_form_with_targets_against_the_oracle(vko):
+    """Round 6: vk_sweep_kernel<KIND, WAVES, UNCOMP, WIDE> exists per kind as the two-wave form (any key forms), the three-wave
+    compressed-only form (no uncompressed code) and the WIDE form (one 768-lane workgroup per CU, tiles per wave, for launches that
+    hash uncompressed keys).  Every kind x form on ragged ranges, larger than one tile per wave and smaller than one, with planted targets
+    of all three address kinds among 20 000 decoys (the bitmap pre-filter in front of the open-address table must not lose a hit nor
+    report a false one: counters, digest and whole hit records against the oracle), and the form the engine reports through the
+    vk_debug_last_launch hook against the name bench.py prices (bench.sweep_kernel_name)."""
+    import hashlib
+    import vuke_amd
+    import bench
+    from vuke_amd import _ffi as ffi
+    rnd = random.Random(606)
+    kinds = [(ffi.T_SHA256, vko.T_SHA256), (ffi.T_MILKSAD, vko.T_MILKSAD), (ffi.T_MT64, vko.T_MT64), (ffi.T_LCG, vko.T_LCG), (ffi.T_XORSHIFT, vko.T_XORSHIFT),
+             (ffi.T_DOUBLE_SHA256, vko.T_DOUBLE_SHA256), (ffi.T_MD5, vko.T_MD5), (ffi.T_DIRECT, vko.T_DIRECT)]
+    decoys = [hashlib.sha256(b"r6 decoy %d" % j).digest()[:20] for j in range(20000)]
+    for bpc, batch in ((0, 0), (2, 0), (3, 5), (0, 1)):
+        e = vuke_amd.Engine(0, blocks_per_cu=bpc, batch=batch, hooks=True)
+        cus = e.info()["cu_count"]
+        for gk, ok in kinds:
+            gs, os_ = ffi.spec(gk), vko.spec(ok)
+            slots = vko.slots_per_input(os_)
+            for lo, n in ((rnd.getrandbits(30), 3000 + rnd.randrange(500)), (rnd.getrandbits(31), 1), (rnd.getrandbits(29), 64 * 12 * cus // 8 + 77)):
+                hi = lo + n - 1
+                # plant: the oracle's own keys of a few inputs, one per address kind
+                planted = [vko.transform_key(os_, s, (j + s) % slots) for j, s in enumerate((lo, lo + n // 2, hi, lo + n // 3, lo + n // 5, hi - n // 7))]
+                tg, tk, addrs = list(decoys), [j & 1 for j in range(len(decoys))], []
+                for j, key in enumerate(k for k in planted if k is not None):
+                    d = vko.derive(key)
+                    which = j % 3
+                    tg.append(bytes(d.h160_u if which == 1 else d.h160_c))
+                    tk.append(ffi.TARGET_P2WPKH if which == 2 else ffi.TARGET_P2PKH)
+                    addrs.append((d.p2pkh_compressed, d.p2pkh_uncompressed, d.p2wpkh)[which].decode())
+                e.targets_set(tg, tk)
+                m = vko.Matcher(addrs)
+                for flags in (1, 2, 3):
+                    st, hits = e.sweep(gs, lo, hi, flags=flags)
+                    ost, ohits = vko.sweep(os_, lo, hi, flags=flags, matcher=m, nthreads=8)
+                    where = (gk, bpc, batch, lo, n, flags)
+                    assert (st["inputs"], st["keys"], st["matches"], st["digest"]) == (ost["inputs"], ost["keys"], ost["matches"], ost["digest"]), where
+                    srt = lambda hs: sorted((h["seed"], h["sub_index"], h["addr_kind"], h["privkey"], h["h160"]) for h in hs)
+                    assert srt(hits) == srt(ohits), where
+                    ll = e.debug_last_launch()
+                    name = bench.sweep_kernel_name(gk, flags, bpc)
+                    want = 4 if name.endswith("3, true, true>") else 3 if name.endswith("3, false, false>") else 2
+                    assert ll["form"] == want and ll["block"] == (768 if want == 4 else 256), (where, ll, name)
+                    assert ll["grid"] <= cus * (1 if want == 4 else max(bpc, want))
+        e.close()
+
+
+def test_host_allocation_failures_inside_the_engine_come_back_as_vk_e_nomem(heng, vko):
+    """VERDICT r5 item 2 on the device box: the entry points that stage buffers on the host (std::vector, std::string) run with the
+    hooks build's allocation-failure injection armed for their k-th allocation, k = 0 .. all of them: each call returns VK_E_NOMEM or
+    succeeds with the unarmed result, none throws into the caller (ctypes would die with the process), and the engine gives the unarmed
+    result again afterwards."""
+    from vuke_amd import _ffi as ffi
+    H = heng._L
+    rnd = random.Random(2)
+    tg = [rnd.randbytes(20) for _ in range(3000)]
+    lines = [("pass%d" % i).encode() for i in range(500)]
+    calls = {
+        "targets_set": lambda: heng.targets_set(tg, [i & 1 for i in range(len(tg))]),
+        "sweep sha256_chain (staged)": lambda: heng.sweep(ffi.spec(ffi.T_SHA256_CHAIN), 10, 200, flags=3)[0]["digest"],
+        "scan_strings sha256": lambda: heng.scan_strings(ffi.spec(ffi.T_SHA256), lines)[0]["digest"],
+        "generate_lines": lambda: heng.generate_lines(ffi.spec(ffi.T_SHA256), 0, 99, "sha256"),
+        "transform_batch": lambda: heng.transform_batch(ffi.spec(ffi.T_LCG), list(range(50))),
+        "search": lambda: heng.search(ffi.spec(ffi.T_MILKSAD), 0, 99999, key=vko.milksad_key(77777)),
+    }
+    for name, call in calls.items():
+        base = call()
+        H.vk_debug_fail_alloc(1 << 40)
+        assert call() == base
+        total = H.vk_debug_fail_alloc(-1)
+        nomem = 0
+        for k in range(0, min(total, 64)):
+            H.vk_debug_fail_alloc(k)
+            try:
+                got = call()
+                assert got == base, (name, k)
+            except ffi.VkError as exc:
+                assert exc.code == ffi.VK_E_NOMEM and "memory" in str(exc), (name, k, str(exc))
+                nomem += 1
+            finally:
+                H.vk_debug_fail_alloc(-1)
+        assert total == 0 or nomem >= 1, (name, total)
+        assert call() == base, name
+    heng.targets_set([], [])

@@ -27,6 +27,6 @@ echo "built libvuke_hip_$name.so"
 # (probe_ring.py, fuzz_geometries.py) measure the variant and not the shipped kernels
 if [ -f "$b/vk_engine_hooks.o" ]; then
     objs[0]="$b/vk_engine_hooks.o"
-    "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$root/vuke_amd/lib/variants/libvuke_hip_${name}_hooks.so" "${objs[@]}"
+    "$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic-functions -o "$root/vuke_amd/lib/variants/libvuke_hip_${name}_hooks.so" "${objs[@]}"
     echo "built libvuke_hip_${name}_hooks.so"
 fi

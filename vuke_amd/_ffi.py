@@ -82,7 +82,7 @@ EXPORTS = [
     "vk_transform_strings", "vk_bitimage_keys", "vk_scan_keys", "vk_scan_strings", "vk_rescan_strings", "vk_bip39_wordlist_set", "vk_multibit_passphrase_set", "vk_search",
     "vk_slots_per_input", "vk_slots_per_string",
 ]
-HOOK_EXPORTS = ["vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop", "vk_debug_ring_knobs", "vk_debug_scan"]
+HOOK_EXPORTS = ["vk_debug_table_entry", "vk_debug_field", "vk_debug_scratch", "vk_debug_chain_stop", "vk_debug_ring_knobs", "vk_debug_scan", "vk_debug_last_launch", "vk_debug_fail_alloc"]
 
 _lib = None
 _hooks_lib = None
@@ -144,6 +144,9 @@ def load(hooks=False):
         L.vk_debug_chain_stop.argtypes = [vp, C.c_int]
         L.vk_debug_ring_knobs.argtypes = [vp, u32, u32, u32]
         L.vk_debug_scan.argtypes = [vp, vp, sz, vp]
+        L.vk_debug_last_launch.argtypes = [vp, vp]
+        L.vk_debug_fail_alloc.argtypes = [C.c_longlong]
+        L.vk_debug_fail_alloc.restype = C.c_longlong
         _hooks_lib = L
     else:
         _lib = L
@@ -366,6 +369,13 @@ class Engine:
         out = np.empty_like(a)
         self._chk(self._L.vk_debug_scan(self._e, a.ctypes.data, a.size, out.ctypes.data))
         return out
+
+    def debug_last_launch(self):
+        """{form, grid, block, R} of the engine's last sweep launch (form: 2 two waves, 3 three waves compressed-only, 4 the
+        768-lane workgroup per CU of launches that hash uncompressed keys); hooks build only."""
+        out = (C.c_uint32 * 4)()
+        self._chk(self._L.vk_debug_last_launch(self._e, out))
+        return {"form": out[0], "grid": out[1], "block": out[2], "R": out[3]}
 
     def debug_ring_knobs(self, chunk_iters=0, waves_per_simd=0, workers=0):
         """Launch policy of the chain ring for the following chain calls (0 = the library's choice); hooks build only."""

@@ -28,6 +28,6 @@ for p in "${pids[@]}"; do wait "$p"; done
 echo "built $outfile"
 if [ -z "${VK_NO_HOOKS:-}" ]; then
     hooks="${outfile%.so}_hooks.so"
-    "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$hooks" "$obj/vk_engine_hooks.o" "$obj"/vk_sweep_g[0-2].o
+    "$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic-functions -o "$hooks" "$obj/vk_engine_hooks.o" "$obj"/vk_sweep_g[0-2].o
     echo "built $hooks"
 fi

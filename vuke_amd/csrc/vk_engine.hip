@@ -19,6 +19,7 @@
 #include <mutex>
 #include <cctype>
 #include <chrono>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -55,9 +56,12 @@ struct vk_engine {
     double runtime_init_seconds = 0.0, alloc_seconds = 0.0, table_wall_seconds = 0.0; // where vk_engine_create's wall time went
     u32 batch = 128;
     u32 blocks_per_cu = 0;   // workgroups per CU the grids and the workspace are sized for
-    bool bpc_auto = true;    // not given by the caller: every launch takes what its instantiation is built for (2 or 3, vk_sweep_design_waves)
+    bool bpc_auto = true;    // not given by the caller: every launch runs the form the automatic choice names (vk_sweep_design_form)
     uint4 *table = nullptr;
     uint4 *tgt = nullptr;
+    u32 *filt = nullptr;     // pre-filter bitmap of the target table (vk_kernels.cuh: probe_filter_word)
+    u32 filt_mask = 0;       // its bits - 1
+    u32 last_form = 0, last_grid = 0, last_R = 0; // the last sweep launch (vk_debug_last_launch)
     u32 tgt_cap = 0;
     size_t tgt_count = 0;
     vk_hit_dev *d_hits = nullptr;
@@ -81,9 +85,17 @@ struct vk_engine {
 // hipMalloc of another engine, another library in the process): the checks behind the kernel launches read hipGetLastError(), and the
 // runtime keeps an error until somebody reads it -- found by four ranks sharing one card in round 5: three 120 GB tables did not fit,
 // and the fall-back engine of the same process then reported the first attempt's "out of memory" at its first launch.
+// The engine is serialised by its mutex.  Entry points that launch kernels check their launches with hipGetLastError(), which reports
+// the calling THREAD's last non-sticky HIP error whoever caused it: they read a pending one away on entry (a foreign error -- another
+// library sharing the thread -- is discarded rather than blamed on this launch; documented in include/vuke_hip.h).  The engine's own
+// failures are read away where they happen (HIPCHK, scratch(), the workspace allocation of run_range), and entry points that launch
+// nothing (vk_last_warning, the debug setters; vk_engine_info takes no lock at all) leave the thread's error state alone.
 struct vk_api_lock {
     std::lock_guard<std::mutex> lk;
-    explicit vk_api_lock(std::mutex &m) : lk(m) { (void)hipGetLastError(); }
+    explicit vk_api_lock(std::mutex &m, bool launches = true) : lk(m)
+    {
+        if (launches) (void)hipGetLastError();
+    }
 };
 
 // slot `i` of the engine's scratch, at least `bytes` long (contents undefined); nullptr + e->err on failure
@@ -121,7 +133,7 @@ static void *scratch(vk_engine *e, int i, size_t bytes)
             snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
             (e)->err = _b;                                                                          \
             (void)hipGetLastError(); /* the runtime keeps the error until it is read: a later launch check must not find it */ \
-            return VK_E_HIP;                                                                        \
+            return _r == hipErrorOutOfMemory ? VK_E_NOMEM : VK_E_HIP; /* the header's code for "device memory did not suffice" */ \
         }                                                                                           \
     } while (0)
 
@@ -143,6 +155,42 @@ static int fail(vk_engine *e, int code, const char *msg)
     else g_create_error = msg;
     return code;
 }
+
+// ---- nothing throws across the C ABI (include/vuke_hip.h; the reference's convention: errors are values, src/gpu/error.rs:7-20) ----
+// Every extern "C" function below that can allocate on the host (std::vector staging buffers, std::string messages) or take the
+// engine's mutex is a function-try-block ending in VK_API_CATCH: std::bad_alloc / std::length_error become VK_E_NOMEM, anything else
+// VK_E_HIP, with vk_last_error set from storage that was reserved when the engine was created (the handler itself must not allocate:
+// an exception leaving an extern "C" frame into a Rust caller is an abort).
+static int vk_caught(vk_engine *e) noexcept
+{
+    int code = VK_E_HIP;
+    char msg[200];
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        code = VK_E_NOMEM;
+        snprintf(msg, sizeof msg, "out of host memory (std::bad_alloc inside the library)");
+    } catch (const std::length_error &x) {
+        code = VK_E_NOMEM;
+        snprintf(msg, sizeof msg, "host buffer too large (std::length_error: %.120s)", x.what());
+    } catch (const std::exception &x) {
+        snprintf(msg, sizeof msg, "unexpected C++ exception inside the library: %.140s", x.what());
+    } catch (...) {
+        snprintf(msg, sizeof msg, "unexpected C++ exception inside the library");
+    }
+    try {
+        if (e) e->err.assign(msg); // capacity reserved in engine_create: no allocation
+        else g_create_error.assign(msg);
+    } catch (...) {
+    }
+    (void)hipGetLastError();
+    return code;
+}
+#define VK_API_CATCH(e)     \
+    catch (...)             \
+    {                       \
+        return vk_caught(e); \
+    }
 
 extern "C" int vk_abi_version(void) { return VK_ABI_VERSION; }
 
@@ -223,6 +271,7 @@ extern "C" void vk_engine_destroy(vk_engine *e)
         if (p) (void)hipFree(p);
     if (e->table) (void)hipFree(e->table);
     if (e->tgt) (void)hipFree(e->tgt);
+    if (e->filt) (void)hipFree(e->filt);
     if (e->d_hits) (void)hipFree(e->d_hits);
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->work) (void)hipFree(e->work);
@@ -397,13 +446,19 @@ static int engine_init(vk_engine *e, int device, const vk_engine_opts *opts)
     return VK_OK;
 }
 
-extern "C" int vk_engine_create_ex(int device, const vk_engine_opts *opts, vk_engine **out)
+extern "C" int vk_engine_create_ex(int device, const vk_engine_opts *opts, vk_engine **out) try
 {
     if (!out) return fail(nullptr, VK_E_INVALID_ARG, "out is NULL");
     *out = nullptr;
     vk_engine *e = new (std::nothrow) vk_engine();
     if (!e) return fail(nullptr, VK_E_NOMEM, "out of host memory");
-    int rc = engine_init(e, device, opts);
+    int rc;
+    try {
+        e->err.reserve(512); // vk_caught writes its message into this without allocating
+        rc = engine_init(e, device, opts);
+    } catch (...) {
+        rc = vk_caught(e);
+    }
     if (rc != VK_OK) {
         g_create_error = e->err;
         vk_engine_destroy(e);
@@ -412,6 +467,7 @@ extern "C" int vk_engine_create_ex(int device, const vk_engine_opts *opts, vk_en
     *out = e;
     return VK_OK;
 }
+VK_API_CATCH(nullptr)
 
 extern "C" int vk_engine_create(int device, vk_engine **out) { return vk_engine_create_ex(device, nullptr, out); }
 
@@ -435,7 +491,7 @@ extern "C" int vk_engine_info(const vk_engine *e, vk_engine_info_t *out)
 }
 
 // ------------------------------------------------------------------------- targets
-extern "C" int vk_targets_set(vk_engine *e, const uint8_t *h160, const uint8_t *kind, size_t n)
+extern "C" int vk_targets_set(vk_engine *e, const uint8_t *h160, const uint8_t *kind, size_t n) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -446,6 +502,9 @@ extern "C" int vk_targets_set(vk_engine *e, const uint8_t *h160, const uint8_t *
         e->tgt = nullptr;
         e->tgt_cap = 0;
         e->tgt_count = 0;
+        if (e->filt) HIPCHK(e, hipFree(e->filt));
+        e->filt = nullptr;
+        e->filt_mask = 0;
     }
     if (n == 0) return VK_OK;
     if (!h160 || !kind) return fail(e, VK_E_INVALID_ARG, "h160 / kind is NULL");
@@ -454,11 +513,17 @@ extern "C" int vk_targets_set(vk_engine *e, const uint8_t *h160, const uint8_t *
     while (cap < 2 * n) cap <<= 1; // load factor <= 1/2
     std::vector<u32> tab(cap * 8, 0u);
     const u32 mask = (u32)(cap - 1);
+    // the pre-filter: one bit per target among >= 128 bits per target (at most 2^32 bits = 512 MB: the index is one hash160 word)
+    u64 fbits = 1ull << 16;
+    while (fbits < ((u64)n << 7) && fbits < (1ull << 32)) fbits <<= 1;
+    const u32 fmask = (u32)(fbits - 1);
+    std::vector<u32> filt((size_t)(fbits >> 5), 0u);
     for (size_t i = 0; i < n; i++) {
         if (kind[i] > 1) return fail(e, VK_E_INVALID_ARG, "target kind must be 0 (p2pkh) or 1 (p2wpkh)");
         u32 h[5];
         memcpy(h, h160 + 20 * i, 20); // little-endian host == RIPEMD-160 state words
         u32 bit = 1u << kind[i];
+        filt[(h[1] & fmask) >> 5] |= 1u << (h[1] & 31u);
         u32 s = h[0] & mask;
         for (;;) {
             u32 *slot = &tab[(size_t)s * 8];
@@ -476,10 +541,14 @@ extern "C" int vk_targets_set(vk_engine *e, const uint8_t *h160, const uint8_t *
     }
     HIPCHK(e, hipMalloc(&e->tgt, cap * 32));
     HIPCHK(e, hipMemcpy(e->tgt, tab.data(), cap * 32, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMalloc(&e->filt, filt.size() * sizeof(u32)));
+    HIPCHK(e, hipMemcpy(e->filt, filt.data(), filt.size() * sizeof(u32), hipMemcpyHostToDevice));
+    e->filt_mask = fmask;
     e->tgt_cap = (u32)cap;
     e->tgt_count = n;
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 // ------------------------------------------------------------------------- launch helper
 struct launch_io {
@@ -599,26 +668,33 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     // Tile = VK_BLOCK lanes x R inputs per lane (R * slots keys share one field inversion).  R is the largest batch
     // that fits e->batch, then shrunk so that every workgroup of the grid gets the same number of full tiles
     // (a 2^28-input block over 768 workgroups would otherwise end with a third of them idle for one tile).
-    // workgroups per CU: the caller's choice, else what the instantiation that will run is built for (three waves per SIMD for the
-    // compressed-only launches of most kinds, two where uncompressed keys are hashed: vk_sweep_tu.hip)
-    const u32 design = vk_sweep_design_waves(kind, flags);
-    const u32 bpc = e->bpc_auto ? design : e->blocks_per_cu;
-    const u32 waves = bpc >= 3 ? design : 2u; // which instantiation: the three-wave one only under a grid made for it
-    const u64 max_grid = (u64)e->cu_count * bpc;
+    // Which instantiation (vk_sweep_tu.hip): by default what measured fastest for the kind and the key forms of the launch -- three waves
+    // per SIMD as three 256-lane workgroups per CU (compressed only) or one 768-lane workgroup per CU (uncompressed keys hashed), two
+    // waves for the compressed-only launches of the sha256 family.  A caller's blocks_per_cu below three asks for the two-wave form.
+    const u32 design = vk_sweep_design_form(kind, flags);
+    const u32 form = (e->bpc_auto || e->blocks_per_cu >= 3) ? design : VK_FORM_TWO;
+    const u32 bpc = e->bpc_auto ? (form == VK_FORM_TWO ? 2u : 3u) : e->blocks_per_cu;
+    const bool wide = form == VK_FORM_WIDE;
+    const u32 tile_lanes = wide ? 64u : (u32)VK_BLOCK;                 // lanes of a tile = of a workspace slice
+    const u32 units_per_wg = wide ? (u32)VK_WIDE_BLOCK / 64u : 1u;     // tile owners per workgroup: waves (wide) or the workgroup itself
+    const u64 max_wgs = wide ? (u64)e->cu_count * std::max(1u, bpc / 3u) : (u64)e->cu_count * bpc;
+    const u64 max_units = max_wgs * units_per_wg;
     u32 R = std::max(1u, e->batch / slots);
     {
-        const u64 per_lane = span / (max_grid * VK_BLOCK) + 1; // inputs per lane if the grid shared them evenly
-        const u64 rounds = (per_lane + R - 1) / R;             // tiles per workgroup
+        const u64 per_lane = span / (max_units * tile_lanes) + 1; // inputs per lane if the grid shared them evenly
+        const u64 rounds = (per_lane + R - 1) / R;                // tiles per owner
         R = (u32)std::max<u64>(1, (per_lane + rounds - 1) / rounds);
     }
     const u32 B = R * slots;
-    const u64 tile_inputs = (u64)VK_BLOCK * R;
+    const u64 tile_inputs = (u64)tile_lanes * R;
     const u64 ntiles = span / tile_inputs + 1;
-    u32 grid = (u32)std::min<u64>(ntiles, max_grid);
-    // The workspace is one slice of B items per resident workgroup.  B >= slots, and slots grows with the chain depth of
+    u64 units = std::min<u64>(ntiles, max_units);
+    // The workspace is one slice of B items per tile owner.  B >= slots, and slots grows with the chain depth of
     // sha256_chain (up to 8 * 4096): keep the allocation under 16 GiB by launching fewer workgroups (the tile counter hands
     // the same tiles to a smaller grid), and say what is wrong if even one workgroup does not fit.
-    const size_t per_wg = (size_t)VK_BLOCK * B * 8 * sizeof(uint4);
+    const size_t per_unit = (size_t)tile_lanes * B * 8 * sizeof(uint4);
+    const size_t per_wg = per_unit * units_per_wg;
+    u32 grid = (u32)((units + units_per_wg - 1) / units_per_wg);
     const size_t work_cap = (size_t)16 << 30;
     if ((size_t)grid * per_wg > work_cap && (size_t)grid * per_wg > e->work_bytes) {
         const size_t fit = std::max(work_cap, e->work_bytes) / per_wg;
@@ -642,6 +718,7 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
             snprintf(msg, sizeof msg, "hipMalloc of the %.2f GiB batch-inversion workspace (%u workgroups x %u keys per lane) failed: %s", (double)need / (double)((size_t)1 << 30),
                      grid, B, hipGetErrorString(mc));
             e->work = nullptr;
+            (void)hipGetLastError(); // read it away: see HIPCHK
             return fail(e, VK_E_NOMEM, msg);
         }
         e->work_bytes = need;
@@ -670,6 +747,8 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     p.table = e->table;
     p.tgt = e->tgt;
     p.tgt_mask = e->tgt_cap ? e->tgt_cap - 1 : 0;
+    p.filt = e->filt;
+    p.filt_mask = e->filt_mask;
     p.hits = e->d_hits;
     p.hit_cap = (u32)std::min<size_t>(io.hit_cap, 0xFFFFFFFFu);
     p.stats = e->d_stats;
@@ -683,9 +762,14 @@ static int run_range(vk_engine *e, const vk_spec_dev &spec, u32 kind, u32 slots,
     p.out_pub = io.out_pub;
 
     HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-    if (!(vk_launch_sweep_g0(kind, p, grid, e->stream, waves) || vk_launch_sweep_g1(kind, p, grid, e->stream, waves) || vk_launch_sweep_g2(kind, p, grid, e->stream, waves)))
+    e->last_form = form;
+    e->last_grid = grid;
+    e->last_R = R;
+    hipError_t lrc = hipSuccess;
+    if (!(vk_launch_sweep_g0(kind, p, grid, e->stream, form, &lrc) || vk_launch_sweep_g1(kind, p, grid, e->stream, form, &lrc) ||
+          vk_launch_sweep_g2(kind, p, grid, e->stream, form, &lrc)))
         return fail(e, VK_E_UNSUPPORTED, "transform kind not supported on the device");
-    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, lrc);
     HIPCHK(e, hipEventRecord(e->ev1, e->stream));
     u64 hs[12];
     HIPCHK(e, hipMemcpyAsync(hs, e->d_stats, sizeof hs, hipMemcpyDeviceToHost, e->stream));
@@ -732,7 +816,7 @@ static vk_spec_dev to_dev(const vk_transform_spec *t)
 static const u64 VK_LAUNCH_INPUTS = 1ull << 30;
 
 extern "C" int vk_sweep(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, uint32_t flags, vk_hit *hits,
-                        size_t hit_cap, vk_sweep_stats *out)
+                        size_t hit_cap, vk_sweep_stats *out) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -763,9 +847,10 @@ extern "C" int vk_sweep(vk_engine *e, const vk_transform_spec *t, uint64_t lo, u
     out->hits_dropped = out->matches > io.hit_cap ? out->matches - io.hit_cap : 0;
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 extern "C" int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, uint32_t flags,
-                           uint8_t *privkeys, uint8_t *h160_c, uint8_t *h160_u, uint8_t *valid, vk_sweep_stats *out)
+                           uint8_t *privkeys, uint8_t *h160_c, uint8_t *h160_u, uint8_t *valid, vk_sweep_stats *out) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -828,6 +913,7 @@ extern "C" int vk_generate(vk_engine *e, const vk_transform_spec *t, uint64_t lo
     if (out) *out = local;
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 // RangeSource::process in generate mode with ConsoleOutput's compact or verbose format, text made on the device (vk_lines.cuh,
 // vk_verbose_kernel in vk_records.cuh).
@@ -910,16 +996,18 @@ static int generate_text(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
 }
 
 extern "C" int vk_generate_lines(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const char *transform_name,
-                                 const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out)
+                                 const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out) try
 {
     return generate_text(e, t, lo, hi, transform_name, slot_suffix, text, text_cap, text_len, out, false);
 }
+VK_API_CATCH(e)
 
 extern "C" int vk_generate_verbose(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const char *transform_name,
-                                   const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out)
+                                   const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out) try
 {
     return generate_text(e, t, lo, hi, transform_name, slot_suffix, text, text_cap, text_len, out, true);
 }
+VK_API_CATCH(e)
 
 extern "C" size_t vk_record_column_stride(int column) { return column >= 0 && column < VK_RC_COLUMNS ? vk_rc_stride(column) : 0; }
 
@@ -991,7 +1079,7 @@ static int check_columns(vk_engine *e, vk_record_columns *cols, u64 items, bool 
 // RangeSource::process in generate mode into a sink that stores the full record (StorageOutput): the value columns of the record
 // made on the device (vk_records.cuh), each as the bytes of a Parquet PLAIN page.
 extern "C" int vk_generate_columns(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const char *const *slot_suffix,
-                                   vk_record_columns *cols, vk_sweep_stats *out)
+                                   vk_record_columns *cols, vk_sweep_stats *out) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1040,10 +1128,11 @@ extern "C" int vk_generate_columns(vk_engine *e, const vk_transform_spec *t, uin
     if (out) *out = local;
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 // KeyDeriver::derive (src/derive.rs:78-165) for n raw keys, the whole record as columns: what a source that already holds keys
 // (wordlist, stdin, files) hands to a storing sink.  The source column is the caller's (len[VK_RC_SOURCE] = 0).
-extern "C" int vk_derive_columns(vk_engine *e, const uint8_t *keys, size_t n, vk_record_columns *cols)
+extern "C" int vk_derive_columns(vk_engine *e, const uint8_t *keys, size_t n, vk_record_columns *cols) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1075,9 +1164,10 @@ extern "C" int vk_derive_columns(vk_engine *e, const uint8_t *keys, size_t n, vk
     double sec = 0.0;
     return records_pack(e, n, 1, 0, nullptr, cols, &sec);
 }
+VK_API_CATCH(e)
 
 extern "C" int vk_derive_batch_pub(vk_engine *e, const uint8_t *keys, size_t n, uint8_t *normalised, uint8_t *h160_c, uint8_t *h160_u,
-                                   uint8_t *pub_xy)
+                                   uint8_t *pub_xy) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1130,11 +1220,13 @@ extern "C" int vk_derive_batch_pub(vk_engine *e, const uint8_t *keys, size_t n, 
     cleanup();
     return VK_OK;
 }
+VK_API_CATCH(e)
 
-extern "C" int vk_derive_batch(vk_engine *e, const uint8_t *keys, size_t n, uint8_t *normalised, uint8_t *h160_c, uint8_t *h160_u)
+extern "C" int vk_derive_batch(vk_engine *e, const uint8_t *keys, size_t n, uint8_t *normalised, uint8_t *h160_c, uint8_t *h160_u) try
 {
     return vk_derive_batch_pub(e, keys, n, normalised, h160_c, h160_u, nullptr);
 }
+VK_API_CATCH(e)
 
 template <u32 KIND>
 static void launch_transform(const vk_spec_dev &s, const u64 *seeds, u64 n, u32 slots, u32 *keys, unsigned char *valid, hipStream_t st,
@@ -1146,7 +1238,7 @@ static void launch_transform(const vk_spec_dev &s, const u64 *seeds, u64 n, u32 
 }
 
 extern "C" int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, const uint64_t *seeds, size_t n, uint8_t *keys_out,
-                                  uint8_t *valid)
+                                  uint8_t *valid) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1190,8 +1282,9 @@ extern "C" int vk_transform_batch(vk_engine *e, const vk_transform_spec *t, cons
     }
     return VK_OK;
 }
+VK_API_CATCH(e)
 
-extern "C" int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words)
+extern "C" int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1221,6 +1314,7 @@ extern "C" int vk_bip39_wordlist_set(vk_engine *e, const uint8_t *words)
     HIPCHK(e, hipMemcpy(e->d_wordlist + 2048, set.data(), VK_WORDSET_SLOTS * 8, hipMemcpyHostToDevice));
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 static int set_mb_salt(vk_engine *e, const uint8_t *pass, size_t len)
 {
@@ -1241,13 +1335,14 @@ static int set_mb_salt(vk_engine *e, const uint8_t *pass, size_t len)
     return VK_OK;
 }
 
-extern "C" int vk_multibit_passphrase_set(vk_engine *e, const uint8_t *passphrase, size_t len)
+extern "C" int vk_multibit_passphrase_set(vk_engine *e, const uint8_t *passphrase, size_t len) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
     if (len && !passphrase) return fail(e, VK_E_INVALID_ARG, "passphrase is NULL");
     return set_mb_salt(e, passphrase, len);
 }
+VK_API_CATCH(e)
 
 // One stretch of a key-derivation chain through the ring of vk_chain.cuh: `groups` groups of 64 inputs, `iters` iterations
 // in chunks of `chunk_iters`.  Workers <= groups: with no more workers than groups a pop never waits.
@@ -1423,10 +1518,10 @@ static void note_overlong(vk_engine *e, const vk_transform_spec *t, size_t overl
     if (overlong) e->warn = "warning: " + std::to_string(overlong) + " input string(s) produced no keys"; // unreachable since ABI 5: no length limits
 }
 
-extern "C" size_t vk_last_warning(vk_engine *e, char *buf, size_t cap)
+extern "C" size_t vk_last_warning(vk_engine *e, char *buf, size_t cap) try
 {
     if (!e) return 0;
-    vk_api_lock lk(e->mu);
+    vk_api_lock lk(e->mu, false);
     const size_t n = e->warn.size();
     if (buf && cap) {
         const size_t c = std::min(n, cap - 1);
@@ -1435,9 +1530,13 @@ extern "C" size_t vk_last_warning(vk_engine *e, char *buf, size_t cap)
     }
     return n;
 }
+catch (...)
+{
+    return 0;
+}
 
 extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
-                                    uint8_t *keys_out, uint8_t *valid)
+                                    uint8_t *keys_out, uint8_t *valid) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1463,12 +1562,13 @@ extern "C" int vk_transform_strings(vk_engine *e, const vk_transform_spec *t, co
     note_overlong(e, t, overlong);
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 // Source::process for the string-input sources in scan mode (reference src/source/wordlist.rs, src/source/stdin.rs:
 // apply_batch -> derive -> Matcher::check per key): the transform's keys never leave HBM -- the sweep kernel reads them
 // back as VK_T_RAWKEYS with the validity flags as its mask.  hit.seed = index of the input string, hit.sub_index = slot.
 extern "C" int vk_scan_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n, uint32_t flags,
-                               vk_hit *hits, size_t hit_cap, vk_sweep_stats *out)
+                               vk_hit *hits, size_t hit_cap, vk_sweep_stats *out) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1515,10 +1615,11 @@ extern "C" int vk_scan_strings(vk_engine *e, const vk_transform_spec *t, const u
     e->rescan_skipped = out->inputs_skipped;
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 // vk_scan_strings again over the keys its last call left on the device: only the derive + probe sweep runs, not the transform
 // (for a caller whose hit buffer was too small: the KDF chains cost seconds per batch, the sweep milliseconds).
-extern "C" int vk_rescan_strings(vk_engine *e, uint32_t flags, vk_hit *hits, size_t hit_cap, vk_sweep_stats *out)
+extern "C" int vk_rescan_strings(vk_engine *e, uint32_t flags, vk_hit *hits, size_t hit_cap, vk_sweep_stats *out) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1547,12 +1648,13 @@ extern "C" int vk_rescan_strings(vk_engine *e, uint32_t flags, vk_hit *hits, siz
     }
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 // WordlistSource / StdinSource in generate mode with ConsoleOutput's compact format: the label of a line is the input string (plus
 // the slot's suffix), which the compaction kernel takes straight from the input buffer.
 extern "C" int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *t, const uint8_t *data, const uint32_t *offsets, size_t n,
                                          const uint8_t *label_data, const uint32_t *label_offsets, const char *transform_name,
-                                         const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out)
+                                         const char *const *slot_suffix, uint8_t *text, size_t text_cap, size_t *text_len, vk_sweep_stats *out) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1646,9 +1748,10 @@ extern "C" int vk_generate_lines_strings(vk_engine *e, const vk_transform_spec *
     if (out) *out = local;
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 extern "C" int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy, size_t n_files, const uint8_t *pass_data, const uint32_t *pass_offsets,
-                                size_t n_pass, const uint32_t *path, uint32_t depth, uint32_t count, uint8_t *keys_out, uint8_t *valid)
+                                size_t n_pass, const uint32_t *path, uint32_t depth, uint32_t count, uint8_t *keys_out, uint8_t *valid) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1718,8 +1821,9 @@ extern "C" int vk_bitimage_keys(vk_engine *e, const uint8_t *entropy, size_t n_f
     }
     return VK_OK;
 }
+VK_API_CATCH(e)
 
-extern "C" int vk_scan_keys(vk_engine *e, const uint8_t *keys, size_t n, uint32_t flags, vk_hit *hits, size_t hit_cap, vk_sweep_stats *out)
+extern "C" int vk_scan_keys(vk_engine *e, const uint8_t *keys, size_t n, uint32_t flags, vk_hit *hits, size_t hit_cap, vk_sweep_stats *out) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1747,6 +1851,7 @@ extern "C" int vk_scan_keys(vk_engine *e, const uint8_t *keys, size_t n, uint32_
     out->hits_dropped = out->matches > (hits ? hit_cap : 0) ? out->matches - (hits ? hit_cap : 0) : 0;
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 // ------------------------------------------------------------------------- analyzer search
 template <u32 KIND, int ND>
@@ -1760,7 +1865,7 @@ static void launch_emit(const vk_spec_dev &spec, u64 seed, u32 *out, hipStream_t
     hipLaunchKernelGGL((vk_search_emit_kernel<KIND, ND>), dim3(1), dim3(64), 0, s, spec, seed, out);
 }
 
-extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const vk_search_target *tg, vk_search_result *out)
+extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, uint64_t hi, const vk_search_target *tg, vk_search_result *out) try
 {
     if (!e) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1875,13 +1980,14 @@ extern "C" int vk_search(vk_engine *e, const vk_transform_spec *t, uint64_t lo, 
     }
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 // ------------------------------------------------------------------------- test hooks
 // Only in libvuke_hip_hooks.so (build.sh compiles this file a second time with -DVK_TEST_HOOKS); declared in
 // include/vuke_hip_test_hooks.h.  The shipped library exports none of them.
 #ifdef VK_TEST_HOOKS
 #include "../../include/vuke_hip_test_hooks.h"
-extern "C" int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digit, uint8_t xy[64])
+extern "C" int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digit, uint8_t xy[64]) try
 {
     if (!e || !xy) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1901,16 +2007,18 @@ extern "C" int vk_debug_table_entry(vk_engine *e, uint32_t window, uint32_t digi
     }
     return VK_OK;
 }
+VK_API_CATCH(e)
 
-extern "C" int vk_debug_chain_stop(vk_engine *e, int stages)
+extern "C" int vk_debug_chain_stop(vk_engine *e, int stages) try
 {
     if (!e) return VK_E_INVALID_ARG;
-    vk_api_lock lk(e->mu);
+    vk_api_lock lk(e->mu, false);
     e->chain_stop = stages <= 0 ? 99 : stages;
     return VK_OK;
 }
+VK_API_CATCH(e)
 
-extern "C" int vk_debug_scratch(vk_engine *e, int slot, size_t offset, uint8_t *out, size_t n)
+extern "C" int vk_debug_scratch(vk_engine *e, int slot, size_t offset, uint8_t *out, size_t n) try
 {
     if (!e || !out) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1919,8 +2027,9 @@ extern "C" int vk_debug_scratch(vk_engine *e, int slot, size_t offset, uint8_t *
     HIPCHK(e, hipMemcpy(out, (const unsigned char *)e->scr[slot] + offset, n, hipMemcpyDeviceToHost));
     return VK_OK;
 }
+VK_API_CATCH(e)
 
-extern "C" int vk_debug_field(vk_engine *e, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out)
+extern "C" int vk_debug_field(vk_engine *e, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out) try
 {
     if (!e || !a || !out || n == 0) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1948,22 +2057,24 @@ extern "C" int vk_debug_field(vk_engine *e, int op, const uint8_t *a, const uint
     }
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 // chunk length (iterations), resident waves per SIMD and worker waves of the chain ring for the following chain calls; 0 = the
 // library's own choice.  (Rounds 2-3 read VUKE_RING_* from the environment on every call, in the shipped library: ADVICE r3.)
-extern "C" int vk_debug_ring_knobs(vk_engine *e, uint32_t chunk_iters, uint32_t waves_per_simd, uint32_t workers)
+extern "C" int vk_debug_ring_knobs(vk_engine *e, uint32_t chunk_iters, uint32_t waves_per_simd, uint32_t workers) try
 {
     if (!e) return VK_E_INVALID_ARG;
-    vk_api_lock lk(e->mu);
+    vk_api_lock lk(e->mu, false);
     if (chunk_iters > 100000 || waves_per_simd > 16 || workers > 65536) return fail(e, VK_E_INVALID_ARG, "vk_debug_ring_knobs: value out of range");
     e->dbg_ring_chunk = chunk_iters;
     e->dbg_ring_wps = waves_per_simd;
     e->dbg_ring_workers = workers;
     return VK_OK;
 }
+VK_API_CATCH(e)
 
 // exclusive prefix sum of n u32 through vk_scan_kernel (the offsets of generate mode's compacted text / columns)
-extern "C" int vk_debug_scan(vk_engine *e, const uint32_t *in, size_t n, uint32_t *out)
+extern "C" int vk_debug_scan(vk_engine *e, const uint32_t *in, size_t n, uint32_t *out) try
 {
     if (!e || !in || !out || n == 0 || n > (1u << 26)) return VK_E_INVALID_ARG;
     vk_api_lock lk(e->mu);
@@ -1976,4 +2087,58 @@ extern "C" int vk_debug_scan(vk_engine *e, const uint32_t *in, size_t n, uint32_
     HIPCHK(e, hipMemcpy(out, d + off_out, n * 4, hipMemcpyDeviceToHost));
     return VK_OK;
 }
+VK_API_CATCH(e)
+// Allocation-failure injection (tests/test_abi.py, tests/test_gpu_parity.py): the hooks build replaces the global operator new for the
+// library's OWN references (build.sh links libvuke_hip_hooks.so with -Bsymbolic-functions; malloc / free underneath, so memory may
+// cross to libstdc++'s operator delete and back).  vk_debug_fail_alloc(k) arms the calling thread: its k-th next allocation from
+// inside the library (0 = the very next one) throws std::bad_alloc, once; k < 0 disarms.  Returns the allocations the thread has made
+// through the library since the previous call.  What the tests hold: every armed call returns VK_E_NOMEM (or succeeds when the
+// k-th allocation does not exist), none terminates the process, and the engine works afterwards.
+#if !defined(__HIP_DEVICE_COMPILE__)
+static thread_local long long g_fail_after = -1, g_allocs = 0;
+static void *vk_hook_alloc(size_t n, bool may_throw)
+{
+    g_allocs++;
+    if (g_fail_after >= 0 && g_fail_after-- == 0) {
+        if (may_throw) throw std::bad_alloc();
+        return nullptr;
+    }
+    void *p = malloc(n ? n : 1);
+    if (!p && may_throw) throw std::bad_alloc();
+    return p;
+}
+void *operator new(size_t n) { return vk_hook_alloc(n, true); }
+void *operator new[](size_t n) { return vk_hook_alloc(n, true); }
+void *operator new(size_t n, const std::nothrow_t &) noexcept { return vk_hook_alloc(n, false); }
+void *operator new[](size_t n, const std::nothrow_t &) noexcept { return vk_hook_alloc(n, false); }
+void operator delete(void *p) noexcept { free(p); }
+void operator delete[](void *p) noexcept { free(p); }
+void operator delete(void *p, size_t) noexcept { free(p); }
+void operator delete[](void *p, size_t) noexcept { free(p); }
+void operator delete(void *p, const std::nothrow_t &) noexcept { free(p); }
+void operator delete[](void *p, const std::nothrow_t &) noexcept { free(p); }
+#endif
+extern "C" long long vk_debug_fail_alloc(long long after)
+{
+#if !defined(__HIP_DEVICE_COMPILE__)
+    const long long seen = g_allocs;
+    g_allocs = 0;
+    g_fail_after = after;
+    return seen;
+#else
+    return 0;
+#endif
+}
+
+extern "C" int vk_debug_last_launch(vk_engine *e, uint32_t out[4]) try
+{
+    if (!e || !out) return VK_E_INVALID_ARG;
+    vk_api_lock lk(e->mu, false);
+    out[0] = e->last_form;
+    out[1] = e->last_grid;
+    out[2] = e->last_form == VK_FORM_WIDE ? (u32)VK_WIDE_BLOCK : (u32)VK_BLOCK;
+    out[3] = e->last_R;
+    return VK_OK;
+}
+VK_API_CATCH(e)
 #endif // VK_TEST_HOOKS

@@ -30,6 +30,7 @@
 #define VK_F_EMIT 0x10000u /* internal: generate-mode records */
 
 #define VK_BLOCK 256
+#define VK_WIDE_BLOCK 768 /* the wide form of the sweep kernel: twelve waves, three per SIMD, one workgroup per CU */
 #ifndef VK_MILKSAD_PAIRS
 #define VK_MILKSAD_PAIRS 1 /* pass 1 of the two-wave Milksad instantiation transforms its items two at a time (with three waves on a SIMD the serial
                               MT19937 chain is covered by the other two: pairs are 1.3 % SLOWER there, profiles/r05_three_waves_again.txt) */
@@ -52,12 +53,14 @@ struct vk_sweep_params {
     u32 slots;      // slots per input
     u32 R;          // inputs per lane per tile
     u32 flags;
-    u32 nwin, pad1;
+    u32 nwin;
+    u32 filt_mask;  // bits of the pre-filter - 1 (power of two), valid when tgt != nullptr
     u32 tgt_mask;   // capacity - 1 (power of two), valid when tgt != nullptr
     u32 hit_cap;
     u32 pad0;
     const uint4 *table;
     const uint4 *tgt;  // slots of 2 x uint4: {h0,h1,h2,h3}, {h4, kindbits, 0, 0}
+    const u32 *filt;   // pre-filter of the target table: bit (h1 & filt_mask) is set for every target (probe_filter_word)
     vk_hit_dev *hits;
     u64 *stats;        // [0] keys [1] matches [2] hit cursor [3..6] digest [7] tile counter [8] shader cycles [9] 100 MHz ticks of workgroup 0
     uint4 *work;       // batch-inversion workspace
@@ -84,16 +87,27 @@ VK_DEV u32 probe_targets(const uint4 *__restrict__ tgt, u32 mask, const u32 h[5]
     return 0;
 }
 
+// Pre-filter in front of the open-address table (round 6).  A miss in the table costs a CHAIN of dependent loads per lane -- with a
+// million targets at load factor 1/2 an unsuccessful linear probe reads 2.4 slots on average, and a wave waits for its longest lane
+// -- every one of them exposed, twice per key when both key forms are hashed: a quarter of config 3's wave-cycles were spent parked
+// in those waits (profiles/r06_forms_pmc.txt).  The filter is a bitmap of >= 128 bits per target indexed by the hash160's second
+// word: ONE independent 4-byte load per hash160, issued when the hash is done and looked at after the other key form has been hashed;
+// 99.2 % of the keys stop there, the rest (true hits and the filter's false positives) take the exact probe.  What is reported is
+// decided by the exact table alone: the filter only skips hash160s that cannot be in it.
+VK_DEV u32 probe_filter_word(const u32 *__restrict__ filt, u32 fmask, const u32 h[5]) { return filt[(h[1] & fmask) >> 5]; }
+VK_DEV bool probe_filter_hit(u32 word, const u32 h[5]) { return ((word >> (h[1] & 31u)) & 1u) != 0; }
+
 // The digest accumulators live in LDS, one column per lane ([word][lane]: conflict-free 8-byte accesses): they are touched
 // once per key, and as registers they were 8 VGPRs held across the whole tile loop -- the difference between 0 and a few
 // spilled registers in the instantiations whose transform carries more state (mt64, raw keys, double_sha256, sha256_chain).
-VK_DEV void digest_fold(u64 *dg /* LDS, this lane's column, stride VK_BLOCK */, const u32 h[5])
+template <int TL>
+VK_DEV void digest_fold(u64 *dg /* LDS, this lane's column, stride TL (the lanes of a tile) */, const u32 h[5])
 {
     u64 a = (u64)h[0] | ((u64)h[1] << 32), b = (u64)h[2] | ((u64)h[3] << 32);
     dg[0] ^= a;
-    dg[VK_BLOCK] ^= b;
-    dg[2 * VK_BLOCK] ^= (u64)h[4];
-    dg[3 * VK_BLOCK] += a + b + h[4];
+    dg[TL] ^= b;
+    dg[2 * TL] ^= (u64)h[4];
+    dg[3 * TL] += a + b + h[4];
 }
 
 VK_DEV void work_store(uint4 *base, u64 stride, const fe &f)
@@ -144,12 +158,12 @@ VK_DEV bool item_key(u32 kw[8], const vk_sweep_params &p, u64 off, u32 sub)
 // pass 2 of one tile: walk the B items of this lane backwards from `inv` = 1 / (e_0 .. e_{B-1}); (r, sub) = the (input row, slot)
 // counters as pass 1 left them.  e and the running product of the item before it are what the two multiplies at the top of the
 // body wait for: they are requested one item ahead (16 registers), X and Y at the top of the body (needed two multiplies later).
-template <u32 KIND>
+template <u32 KIND, bool UNCOMP, int TL>
 VK_DEV void sweep_pass2(const vk_sweep_params &p, const uint4 *wk, const u32 B, const u64 tile_off, fe inv, u32 r, u32 sub, u64 *dg, u32 &n_keys,
                         u32 &n_match, vk_lds_u4p tail)
 {
-    const u32 tid = threadIdx.x;
-    const u64 nth = VK_BLOCK;
+    const u32 tid = TL == 64 ? (threadIdx.x & 63u) : threadIdx.x; // the lane's place in its tile
+    const u64 nth = TL;
     fe nz, ncp;
     work_load(nz, wk + (u64)(B - 1) * 8 * nth + 4 * nth, nth);
     if (B > 1) work_load(ncp, wk + (u64)(B - 2) * 8 * nth + 6 * nth, nth);
@@ -187,18 +201,23 @@ VK_DEV void sweep_pass2(const vk_sweep_params &p, const uint4 *wk, const u32 B, 
         fe_canon(x);
         fe_canon(y);
         n_keys++;
-        const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
+        const u64 off = tile_off + (u64)r * TL + tid;
         u32 hc[5], hu[5];
         u32 bits_c = 0, bits_u = 0;
-        if (p.flags & VK_F_COMPRESSED) {
+        u32 fw_c = 0, fw_u = 0; // the pre-filter's words: requested as soon as a hash160 exists, looked at after both
+        if (!UNCOMP || (p.flags & VK_F_COMPRESSED)) { // an instantiation without the uncompressed form only runs compressed-only launches
             hash160_pub33(hc, x, y.v[0] & 1u);
-            digest_fold(dg, hc);
-            if (p.tgt) bits_c = probe_targets(p.tgt, p.tgt_mask, hc);
+            digest_fold<TL>(dg, hc);
+            if (p.tgt) fw_c = probe_filter_word(p.filt, p.filt_mask, hc);
         }
-        if (p.flags & VK_F_UNCOMPRESSED) {
+        if (UNCOMP && (p.flags & VK_F_UNCOMPRESSED)) {
             hash160_pub65_lds(hu, x, y, tail);
-            digest_fold(dg, hu);
-            if (p.tgt) bits_u = probe_targets(p.tgt, p.tgt_mask, hu);
+            digest_fold<TL>(dg, hu);
+            if (p.tgt) fw_u = probe_filter_word(p.filt, p.filt_mask, hu);
+        }
+        if (p.tgt) { // fw_* stay 0 for a key form that was not hashed
+            if (fw_c && probe_filter_hit(fw_c, hc)) bits_c = probe_targets(p.tgt, p.tgt_mask, hc);
+            if (UNCOMP && fw_u && probe_filter_hit(fw_u, hu)) bits_u = probe_targets(p.tgt, p.tgt_mask, hu);
         }
         // Matcher::check order (reference src/matcher.rs:72-98): p2pkh(c), p2pkh(u), p2wpkh
         int kind = -1;
@@ -224,7 +243,7 @@ VK_DEV void sweep_pass2(const vk_sweep_params &p, const uint4 *wk, const u32 B, 
 #pragma unroll
                     for (int i = 0; i < 8; i++) h->privkey[i] = bswap32(k[7 - i]);
 #pragma unroll
-                    for (int i = 0; i < 5; i++) h->h160[i] = (kind == 1) ? hu[i] : hc[i];
+                    for (int i = 0; i < 5; i++) h->h160[i] = (UNCOMP && kind == 1) ? hu[i] : hc[i];
                     h->pad = 0;
                 }
             }
@@ -235,11 +254,11 @@ VK_DEV void sweep_pass2(const vk_sweep_params &p, const uint4 *wk, const u32 B, 
 #pragma unroll
                     for (int i = 0; i < 8; i++) p.out_priv[item * 8 + i] = bswap32(k[7 - i]);
                 }
-                if (p.out_h160c && (p.flags & VK_F_COMPRESSED)) {
+                if (p.out_h160c && (!UNCOMP || (p.flags & VK_F_COMPRESSED))) {
 #pragma unroll
                     for (int i = 0; i < 5; i++) p.out_h160c[item * 5 + i] = hc[i];
                 }
-                if (p.out_h160u && (p.flags & VK_F_UNCOMPRESSED)) {
+                if (UNCOMP && p.out_h160u && (p.flags & VK_F_UNCOMPRESSED)) {
 #pragma unroll
                     for (int i = 0; i < 5; i++) p.out_h160u[item * 5 + i] = hu[i];
                 }
@@ -256,11 +275,12 @@ VK_DEV void sweep_pass2(const vk_sweep_params &p, const uint4 *wk, const u32 B, 
 }
 
 // counters of one workgroup into p.stats: one wave-reduced atomic per wave and counter
+template <int TL>
 VK_DEV void sweep_counters(const vk_sweep_params &p, const u64 *dg, u32 n_keys, u32 n_match)
 {
     const u32 tid = threadIdx.x;
     const u64 w_keys = wave_add((u64)n_keys), w_match = wave_add((u64)n_match);
-    const u64 d0 = wave_xor(dg[0]), d1 = wave_xor(dg[VK_BLOCK]), d2 = wave_xor(dg[2 * VK_BLOCK]), d3 = wave_add(dg[3 * VK_BLOCK]);
+    const u64 d0 = wave_xor(dg[0]), d1 = wave_xor(dg[TL]), d2 = wave_xor(dg[2 * TL]), d3 = wave_add(dg[3 * TL]);
     if ((tid & 63) == 0) {
         atomicAdd((unsigned long long *)&p.stats[0], (unsigned long long)w_keys);
         atomicAdd((unsigned long long *)&p.stats[1], (unsigned long long)w_match);
@@ -271,49 +291,65 @@ VK_DEV void sweep_counters(const vk_sweep_params &p, const u64 *dg, u32 n_keys, 
     }
 }
 
-// WAVES = the waves per SIMD (= resident workgroups per CU) the instantiation is register-budgeted for.  2: every field element in
-// VGPRs (196 - 206 of them); 3: 168 VGPRs, 22 - 33 of the coldest values in scratch.  Round 4 measured three waves 4 % SLOWER than
-// two (37 - 46 spilled registers then, and a part that gave the gain back in clock); after round 5's diet the same experiment is
-// +2.2 % on the Milksad sweep and +2.8 % on the LCG sweep (profiles/r05_three_waves_again.txt), so compressed-only launches of the
-// Milksad / MT19937-64 / raw-key / LCG / xorshift kinds run the WAVES = 3 instantiation on a grid of three workgroups per CU; a launch
-// that hashes uncompressed keys keeps WAVES = 2: its 53 KB schedule table lets only two workgroups share a CU's LDS
-// (vk_sweep_tu.hip: vk_sweep_design_waves).  Four waves: 315 spilled registers, -13 %.
-template <u32 KIND, int WAVES>
-__global__ void __launch_bounds__(VK_BLOCK, WAVES) vk_sweep_kernel(const vk_sweep_params p)
+// WAVES = the waves per SIMD the instantiation is register-budgeted for.  2: every field element in VGPRs (196 - 206 of them);
+// 3: 168 VGPRs, the coldest values in scratch.  Round 4 measured three waves 4 % SLOWER than two (37 - 46 spilled registers then, and
+// a part that gave the gain back in clock); after round 5's diet the same experiment is +2.2 % on the Milksad sweep and +2.8 % on the
+// LCG sweep (profiles/r05_three_waves_again.txt).  Four waves: 315 spilled registers, -13 %.
+// UNCOMP = the instantiation holds the code that hashes uncompressed keys (chosen per launch by p.flags); without it the kernel
+// runs compressed-only launches and carries none of that code (round 6: a template parameter, not a launch flag over shared code).
+// WIDE = one workgroup of 768 lanes per CU instead of three of 256 (round 6): three waves per SIMD for the launches that hash
+// uncompressed keys, whose 53 KB schedule table does not fit a CU's LDS three times (3 x 78 KB) but fits once beside twelve waves'
+// landing slots and digest columns (53 + 12 x 6.2 = 127 KB).  Twelve waves would meet in every barrier of the tile loop, so the
+// wide form has none: a tile is 64 lanes x R inputs and every WAVE takes its own from the counter (TL = the lanes of a tile).
+template <u32 KIND, int WAVES, bool UNCOMP, bool WIDE>
+__global__ void __launch_bounds__(WIDE ? VK_WIDE_BLOCK : VK_BLOCK, WAVES) vk_sweep_kernel(const vk_sweep_params p)
 {
-    const u32 tid = threadIdx.x;
+    constexpr int NT = WIDE ? VK_WIDE_BLOCK : VK_BLOCK; // lanes of the workgroup
+    constexpr int TL = WIDE ? 64 : VK_BLOCK;             // lanes of a tile = of a workspace slice = of a digest column block
+    const u32 tid = WIDE ? (threadIdx.x & 63u) : threadIdx.x;                      // the lane's place in its tile
+    const u32 unit = WIDE ? blockIdx.x * (NT / TL) + (threadIdx.x >> 6) : blockIdx.x; // which slice of the workspace
     const u32 B = p.R * p.slots;
     // workgroup 0 is resident for the whole launch (tiles come from a counter): its shader-cycle and constant-rate counters
     // give the clock the part actually held under this load
     const u64 clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     u32 n_keys = 0, n_match = 0; // per lane and launch: far below 2^32
-    __shared__ u64 s_dg[4 * VK_BLOCK];
-    u64 *dg = s_dg + tid;
+    __shared__ u64 s_dg[4 * NT];
+    u64 *dg = s_dg + (WIDE ? (threadIdx.x >> 6) * (4 * TL) : 0u) + tid;
 #pragma unroll
-    for (int i = 0; i < 4; i++) dg[i * VK_BLOCK] = 0;
-    // workspace of this workgroup: item b, quad q, lane t at wk[(b*8 + q) * VK_BLOCK] -- one contiguous
-    // B * 32 KB region per workgroup (a few TLB entries), every access a fully coalesced 16 B per lane
-    const u64 nth = VK_BLOCK;
-    uint4 *wk = p.work + (u64)blockIdx.x * ((u64)B * 8 * VK_BLOCK) + tid;
+    for (int i = 0; i < 4; i++) dg[i * TL] = 0;
+    // workspace of this tile owner: item b, quad q, lane t at wk[(b*8 + q) * TL] -- one contiguous
+    // B * TL * 128 B region (a few TLB entries), every access a fully coalesced 16 B per lane
+    const u64 nth = TL;
+    uint4 *wk = p.work + (u64)unit * ((u64)B * 8 * TL) + tid;
     __shared__ u64 s_tile;
-    __shared__ uint4 s_gather[(VK_BLOCK / 64) * VK_LDS_DEPTH * VK_LTILE_FULL]; // whole-entry slots per wave (lds_gather_issue)
+    __shared__ uint4 s_gather[(NT / 64) * VK_LDS_DEPTH * VK_LTILE_FULL]; // whole-entry slots per wave (lds_gather_issue)
     // the wave's slot, as a scalar: the LDS-direct loads take their LDS address from M0
-    uint4 *gtile = s_gather + __builtin_amdgcn_readfirstlane(tid >> 6) * (VK_LDS_DEPTH * VK_LTILE_FULL);
+    uint4 *gtile = s_gather + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (VK_LDS_DEPTH * VK_LTILE_FULL);
     // W[t] + K[t] of the second SHA-256 block of an uncompressed key, one row per value of Y's last byte (vk_hash.cuh): dynamic LDS,
     // VK_TAIL_LDS_BYTES of it when the launch hashes uncompressed keys (vk_sweep_tu.hip), none otherwise
     extern __shared__ vk_u32x4 s_tail[];
     const vk_lds_u4p tail = (vk_lds_u4p)s_tail;
-    if (p.flags & VK_F_UNCOMPRESSED) sha256_tail65_build_row(tail, tid); // VK_BLOCK = 256 rows; made visible by the tile loop's first barrier
+    if (UNCOMP && (p.flags & VK_F_UNCOMPRESSED)) {
+        if (!WIDE || threadIdx.x < 256) sha256_tail65_build_row(tail, threadIdx.x); // 256 rows
+        if (WIDE) __syncthreads(); // the classic form's rows are made visible by the tile loop's first barrier
+    }
 
 #pragma unroll 1
     for (;;) {
-        // tiles are handed out by an atomic counter: workgroups that run ahead (clock, XCD, table locality) take more
-        if (tid == 0) s_tile = atomicAdd((unsigned long long *)(p.stats + 7), 1ull);
-        __syncthreads();
-        const u64 tile = s_tile;
-        __syncthreads();
+        // tiles are handed out by an atomic counter: whoever runs ahead (clock, XCD, table locality) takes more
+        u64 tile;
+        if (WIDE) {
+            u64 t = 0;
+            if (tid == 0) t = atomicAdd((unsigned long long *)(p.stats + 7), 1ull);
+            tile = ((u64)__builtin_amdgcn_readfirstlane((u32)(t >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)t);
+        } else {
+            if (tid == 0) s_tile = atomicAdd((unsigned long long *)(p.stats + 7), 1ull);
+            __syncthreads();
+            tile = s_tile;
+            __syncthreads();
+        }
         if (tile >= p.ntiles) break;
-        const u64 tile_off = tile * ((u64)VK_BLOCK * p.R);
+        const u64 tile_off = tile * ((u64)TL * p.R);
         // ---------------------------------------------------------------- pass 1
         fe c;
         u32 r = 0, sub = 0;
@@ -321,17 +357,17 @@ __global__ void __launch_bounds__(VK_BLOCK, WAVES) vk_sweep_kernel(const vk_swee
         bool have_next = false;
 #pragma unroll 1
         for (u32 b = 0; b < B; b++) {
-            const u64 off = tile_off + (u64)r * VK_BLOCK + tid;
+            const u64 off = tile_off + (u64)r * TL + tid;
             u32 kw[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // stays zero where the reference emits nothing (item_key returns false)
             // parked per item: X*ZZ^2, Y, e = ZZZ and the running product of e: y = Y / e, x = X*ZZ^2 / e^2 (ZZ^3 = ZZZ^2)
             uint4 *it = wk + (u64)b * 8 * nth;
             {
                 bool have;
                 if (KIND == VK_T_MILKSAD && VK_MILKSAD_PAIRS && WAVES < 3) {
-                    // one slot per input: item b + 1 is the input VK_BLOCK further on.  Even items transform both (two interleaved
+                    // one slot per input: item b + 1 is the input TL further on.  Even items transform both (two interleaved
                     // MT19937 chains), odd items take what the even one left
                     if ((b & 1u) == 0) {
-                        const u64 off1 = off + VK_BLOCK, sa = p.lo + off, sb = p.lo + off1;
+                        const u64 off1 = off + TL, sa = p.lo + off, sb = p.lo + off1;
                         transform_milksad2(kw, kw_next, (u32)sa, (u32)sb);
                         have = off <= p.span && sa <= 0xFFFFFFFFull;          // transform_milksad's skip rule
                         have_next = off1 <= p.span && sb <= 0xFFFFFFFFull;
@@ -382,12 +418,12 @@ __global__ void __launch_bounds__(VK_BLOCK, WAVES) vk_sweep_kernel(const vk_swee
         // (as a kernel of its own, budgeted for 3 or 4 waves per SIMD, with every tile's items kept in HBM until it had read them,
         // pass 2 made the Milksad sweep 4.8 % SLOWER and the sha256 scan 0 - 1.5 % slower, same box, three rounds each:
         // profiles/r04_split_pass2_experiment.txt; the variant's last source is commit fe19f6c)
-        sweep_pass2<KIND>(p, wk, B, tile_off, inv, r, sub, dg, n_keys, n_match, tail);
+        sweep_pass2<KIND, UNCOMP, TL>(p, wk, B, tile_off, inv, r, sub, dg, n_keys, n_match, tail);
     }
     // ------------------------------------------------------------------- counters
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         p.stats[8] = __builtin_amdgcn_s_memtime() - clk0;
         p.stats[9] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
-    sweep_counters(p, dg, n_keys, n_match);
+    sweep_counters<TL>(p, dg, n_keys, n_match);
 }
