@@ -1402,9 +1402,9 @@ def test_host_allocation_failures_inside_the_engine_come_back_as_vk_e_nomem(heng
         "targets_set": lambda: heng.targets_set(tg, [i & 1 for i in range(len(tg))]),
         "sweep sha256_chain (staged)": lambda: heng.sweep(ffi.spec(ffi.T_SHA256_CHAIN), 10, 200, flags=3)[0]["digest"],
         "scan_strings sha256": lambda: heng.scan_strings(ffi.spec(ffi.T_SHA256), lines)[0]["digest"],
-        "generate_lines": lambda: heng.generate_lines(ffi.spec(ffi.T_SHA256), 0, 99, "sha256"),
+        "generate_lines": lambda: heng.generate_lines(ffi.spec(ffi.T_SHA256), 0, 99, "sha256")[0],
         "transform_batch": lambda: heng.transform_batch(ffi.spec(ffi.T_LCG), list(range(50))),
-        "search": lambda: heng.search(ffi.spec(ffi.T_MILKSAD), 0, 99999, key=vko.milksad_key(77777)),
+        "search": lambda: {k: v for k, v in heng.search(ffi.spec(ffi.T_MILKSAD), 0, 99999, key=vko.milksad_key(77777)).items() if "seconds" not in k},
     }
     for name, call in calls.items():
         base = call()
