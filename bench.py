@@ -108,7 +108,7 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
-def load_pmc(tag):
+def load_pmc(tag, kernel=None):
     """profiles/pmc_<tag>.json (tools/pmc_summary.py) if it was taken from the kernel sources in this tree, else a reason."""
     path = os.path.join(ROOT, "profiles", f"pmc_{tag}.json")
     if not os.path.exists(path):
@@ -116,6 +116,12 @@ def load_pmc(tag):
     pj = json.load(open(path))
     if pj.get("csrc_hash") != csrc_hash():
         return None, f"profiles/pmc_{tag}.json was taken from other kernel sources ({pj.get('csrc_hash')} != {csrc_hash()}): re-run tools/profile.sh"
+    if kernel and kernel not in pj.get("kernels", []):
+        return None, f"profiles/pmc_{tag}.json describes {pj.get('kernels', ['?'])[0]}, this run launches {kernel} (another --blocks-per-cu): no roofline for it"
+    floor, meas = pj.get("cycles_per_valu_inst_floor"), pj.get("cycles_per_valu_inst_per_simd")
+    if floor and meas and floor > meas:
+        return None, (f"profiles/pmc_{tag}.json prices the instruction mix at {floor:.3f} cycles per instruction, ABOVE the {meas:.3f} it measured: "
+                      "the floor model is wrong for this kernel (tools/pmc_summary.py, profiles/valu_rates.json)")
     return pj, None
 
 
@@ -633,7 +639,7 @@ def main():
         per_launch_keys = keys_done / max(launches, 1)
         per_launch_s = kernel_s / max(launches, 1)
         rate = keys_done / kernel_s  # this rank's keys per second of kernel time
-        pmc, why = load_pmc(w.tag)
+        pmc, why = load_pmc(w.tag, w.kernel)
         roof = {"bound": "valu-int", "peak": PEAK_INT32 / 1e12,
                 "unit": "T lane-ops/s = executed VALU wave-instructions (rocprofv3 SQ_INSTS_VALU) x 64 lanes / s; peak = the 16-lanes-per-clock "
                         "class (v_mad_u64_u32, carry adds, v_add3, v_alignbit): 256 CU x 4 SIMD x 16 lanes x 2.4 GHz",
@@ -643,18 +649,22 @@ def main():
             roof["shader_clock_ghz"] = clock_ghz  # live: s_memtime / s_memrealtime of workgroup 0 of every sweep launch of this run
         if pmc:
             per_key = pmc["valu_insts_per_key"]
-            if clock_ghz:
-                # the same fraction against the peak at the clock the part actually held (DVFS lowers it under this load)
-                roof["frac_at_measured_clock"] = per_key * rate / (PEAK_INT32 * clock_ghz / 2.4)
-                roof["frac_at_measured_clock_note"] = ("may read slightly above 1: the peak prices every instruction in the 16-lanes-per-clock class, "
-                                                       "and about a sixth of this mix (plain adds, shifts, logic) issues faster than that; `frac` is the contract's figure")
+            floor = pmc.get("cycles_per_valu_inst_floor")
+            if clock_ghz and floor:
+                # at the clock the part actually held (DVFS lowers it under this load): the priced issue floor of this kernel's own
+                # instruction mix at its own occupancy (profiles/valu_rates.json) over the cycles per instruction of THIS run --
+                # <= 1 by construction of the floor; what is missing to 1 is waiting (wave_cycle_split below)
+                live_cycles = clock_ghz * 1e9 * 1024 * 64 / (per_key * rate)
+                roof["cycles_per_valu_inst_per_simd_live"] = live_cycles
+                roof["frac_at_measured_clock"] = floor / live_cycles
             roof.update({"achieved": per_key * rate / 1e12, "frac": per_key * rate / PEAK_INT32,
                          "valu_insts_per_key": per_key, "pmc_source": pmc["source"], "pmc_csrc_hash": pmc["csrc_hash"], "pmc_git": pmc.get("git"),
                          "cycles_per_valu_inst_per_simd": pmc.get("cycles_per_valu_inst_per_simd"),
                          "valu_busy_pct_in_profile": pmc.get("valu_busy_pct"),
                          "effective_clock_ghz_in_profile": pmc.get("effective_clock_ghz"),
                          "traffic": pmc.get("hbm_bytes_per_launch_calibrated", pmc.get("hbm_bytes_per_launch")),
-                         "cycles_per_valu_inst_floor": pmc.get("cycles_per_valu_inst_floor"), "valu_int64_share": (pmc.get("valu_mix") or {}).get("int64_share"),
+                         "cycles_per_valu_inst_floor": pmc.get("cycles_per_valu_inst_floor"), "wave_cycle_split_in_profile": pmc.get("wave_cycle_split"),
+                         "valu_int64_share": (pmc.get("valu_mix") or {}).get("int64_share"),
                          "scratch": pmc.get("dispatch", {}).get("Scratch_Size")})
         else:
             roof.update({"achieved": None, "frac": None, "traffic": None, "pmc_refused": why})

@@ -8,7 +8,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "build", "libvko.so")
+# VKO_LIB: another build of the same checker (oracle/Makefile `asan`: build/asan/libvko.so under AddressSanitizer + UBSan, with
+# python started under LD_PRELOAD=libasan -- tools/run_sanitizers.sh, tests/test_sanitizers.py)
+_LIB = os.environ.get("VKO_LIB") or os.path.join(_HERE, "build", "libvko.so")
 
 T_SHA256, T_MILKSAD, T_MT64, T_LCG, T_XORSHIFT, T_SHA256_CHAIN, T_ELECTRUM, T_MULTIBIT, T_DOUBLE_SHA256, T_MD5, T_DIRECT, T_ARMORY = range(12)
 VARIANT_ALL = 0xFFFFFFFF
@@ -16,6 +18,8 @@ F_COMPRESSED, F_UNCOMPRESSED, F_FAITHFUL, F_BATCHED = 1, 2, 0x100, 0x200
 
 
 def build(force=False):
+    if os.environ.get("VKO_LIB"):
+        return _LIB
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)

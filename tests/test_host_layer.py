@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def host():
     import __graft_entry__ as ge
     ge.build()
-    L = C.CDLL(os.path.join(ROOT, "vuke_amd", "lib", "libvuke_host.so"))
+    L = C.CDLL(os.environ.get("VUKE_HOST_LIB") or os.path.join(ROOT, "vuke_amd", "lib", "libvuke_host.so"))   # VUKE_HOST_LIB: the sanitizer build (tools/run_sanitizers.sh)
     L.vkh_matcher_load.restype = C.c_long
     return L
 
@@ -216,7 +216,7 @@ def test_fast_analyzers_run_without_a_device():
     """`vuke analyze KEY --fast` = direct + heuristic (src/analyze/{direct,heuristic}.rs and their tests): key bytes only."""
     import json
     import subprocess
-    exe = os.path.join(ROOT, "vuke_amd", "lib", "vuke-hip")
+    exe = os.environ.get("VUKE_HIP_EXE") or os.path.join(ROOT, "vuke_amd", "lib", "vuke-hip")
     run = lambda *a: subprocess.run([exe, "analyze", *a], capture_output=True, text=True, timeout=60)
     r = run("0x2a", "--fast")                                   # direct.rs test_small_number
     assert r.returncode == 0, r.stderr

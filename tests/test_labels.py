@@ -92,7 +92,7 @@ def test_rust_crate_label_suffix_equals_the_oracles_labels():
 def host():
     import subprocess
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "vuke_amd", "host")], check=True)
-    L = C.CDLL(os.path.join(ROOT, "vuke_amd", "lib", "libvuke_host.so"))
+    L = C.CDLL(os.environ.get("VUKE_HOST_LIB") or os.path.join(ROOT, "vuke_amd", "lib", "libvuke_host.so"))   # VUKE_HOST_LIB: the sanitizer build (tools/run_sanitizers.sh)
     return L
 
 

@@ -32,10 +32,25 @@ def demangle(names):
     return names
 
 
-# issue cost in cycles per wave-instruction per SIMD with two waves resident ("wall" column of profiles/r03_ubench_valu_rates.txt):
-# what a VALU instruction of each class holds its SIMD for when nothing else stalls -- the floor the measured
-# cycles_per_valu_inst_per_simd (rocprofv3: GRBM_GUI_ACTIVE / SQ_INSTS_VALU) is held against
-PRICE = {"mad64": 4.50, "full": 4.47, "bitop3": 3.34, "mov": 3.96, "fast": 2.47}
+# issue cost in cycles per wave-instruction per SIMD, per instruction class and per number of resident waves per SIMD:
+# profiles/valu_rates.json (tools/ubench_rates.py over tools/ubench_block.hip + tools/ubench_carry.hip: the smallest wall-clock
+# figure any member of the class reached at that occupancy) -- what a VALU instruction of each class holds its SIMD for when nothing
+# else stalls.  A kernel's mix is priced at ITS occupancy (512 VGPRs / its allocation): the measured
+# cycles_per_valu_inst_per_simd (rocprofv3: GRBM_GUI_ACTIVE / SQ_INSTS_VALU) is held against that floor, and bench.py refuses a
+# summary whose floor lies above the measurement (round 5 priced three-wave kernels with two-wave rates).
+def load_rates():
+    path = os.path.join(ROOT, "profiles", "valu_rates.json")
+    return {int(w): r for w, r in json.load(open(path))["waves_per_simd"].items()}
+
+
+def price_for(vgpr, agpr=0, rates=None):
+    """(waves per SIMD the allocation allows, {class: cycles}) from the measured occupancies (nearest one not above)."""
+    rates = rates or load_rates()
+    waves = max(1, min(8, 512 // max(vgpr + agpr, 1)))
+    have = max(w for w in rates if w <= waves)
+    return waves, rates[have]
+
+
 FAST = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32",
         "v_add_nc_u32", "v_min_u32", "v_max_u32", "v_xnor_b32")
 
@@ -88,7 +103,9 @@ def unit(src, extra, tag):
             n = sum(m.values())
             row["valu_static_mix"] = {k: round(v / n, 4) for k, v in sorted(m.items())}
             row["valu_static_count"] = n
-            row["cycles_per_valu_inst_floor"] = round(sum(PRICE[k] * v for k, v in m.items()) / n, 3)
+            waves, price = price_for(row["vgpr"], row["agpr"])
+            row["waves_per_simd"] = waves
+            row["cycles_per_valu_inst_floor"] = round(sum(price[k] * v for k, v in m.items()) / n, 3)
         rows.append(row)
     return rows
 

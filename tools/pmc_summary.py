@@ -19,7 +19,10 @@ import bench  # noqa: E402  (csrc_hash only)
 
 src_root, tag, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
 src = os.path.join(src_root, f"c{cfg}")
-KERNELS = {"2": ["vk_sweep_kernel<1u, 3>"], "3": ["vk_sweep_kernel<0u, 2>"], "4": ["vk_sweep_kernel<3u, 3>"],
+# the sweep instantiation each config runs with the engine's automatic choice: bench.sweep_kernel_name (held to the engine by
+# tests/test_gpu_parity.py through the vk_debug_last_launch hook); PMC_BPC = the --blocks-per-cu the profiled bench ran with
+BPC = int(os.environ.get("PMC_BPC", "0"))
+KERNELS = {"2": [bench.sweep_kernel_name(1, 1, BPC)], "3": [bench.sweep_kernel_name(0, 3, BPC)], "4": [bench.sweep_kernel_name(3, 1, BPC)],
            "5m": ["vk_ring_kernel<vk_pbkdf2_body>", "vk_mb_prepare_kernel", "vk_mb_middle_kernel", "vk_mb_final_kernel", "vk_sweep_kernel<100u"],
            "5e": ["vk_ring_kernel<vk_electrum_body>", "vk_electrum_prepare_kernel", "vk_electrum_final_kernel", "vk_sweep_kernel<100u"]}[cfg]
 dst = os.path.join(ROOT, "profiles")
@@ -116,15 +119,24 @@ if mix.get("SQ_INSTS_VALU"):
         km = json.load(open(km_path))
         row = next((r for r in km["kernels"] if KERNELS[0] in r["kernel"] and "valu_static_mix" in r), None)
         if row and km.get("csrc_hash") == bench.csrc_hash():
-            price = {"mad64": 4.50, "full": 4.47, "bitop3": 3.34, "mov": 3.96, "fast": 2.47}
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import kernel_meta as kmeta
+            waves, price = kmeta.price_for(row["vgpr"], row["agpr"])
             sm = dict(row["valu_static_mix"])
             sm.pop("mad64", None)
             rest = sum(sm.values())
             rest_price = sum(price[k] * v for k, v in sm.items()) / rest if rest else price["full"]
             share = out["valu_mix"]["int64_share"]
+            out["waves_per_simd"] = waves
             out["cycles_per_valu_inst_floor"] = share * price["mad64"] + (1.0 - share) * rest_price
-            out["cycles_per_valu_inst_floor_note"] = ("dynamic 64-bit share (SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU) at 4.50 cycles + the rest at the static mix of the code "
-                                                      "object (profiles/r04_kernel_meta.json) priced with profiles/r03_ubench_valu_rates.txt (two waves per SIMD)")
+            out["cycles_per_valu_inst_floor_note"] = (f"dynamic 64-bit share (SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU) at {price['mad64']:.2f} cycles + the rest at the static mix of "
+                                                      f"the code object (profiles/kernel_meta.json), every class priced at the kernel's own occupancy of {waves} waves per SIMD "
+                                                      "(profiles/valu_rates.json: tools/ubench_block.hip + tools/ubench_carry.hip, smallest figure of each class)")
+            if "cycles_per_valu_inst_per_simd" in out:
+                out["issue_efficiency"] = out["cycles_per_valu_inst_floor"] / out["cycles_per_valu_inst_per_simd"]
+                w = counters
+                if "SQ_WAVE_CYCLES" in w:
+                    out["wave_cycle_split"] = {k: w[k] / w["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in w}
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters and keys_total:
     fetch, write = counters["FETCH_SIZE"] * 1024, counters["WRITE_SIZE"] * 1024
     out["hbm_fetch_bytes_raw"] = fetch

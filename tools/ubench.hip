@@ -87,10 +87,14 @@ static void run(int waves_per_simd, int cus, u64 *out, u32 live_lanes = 64)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<OP>, grid, block, 0, 0, out, 1u, 10, live_lanes);
+    // exactly waves_per_simd workgroups on EVERY CU: each asks for a 1/waves_per_simd share of the CU's 160 KB of LDS, so no CU can take
+    // one more (round 6: without it a 3-per-CU grid landed 4 / 2 on some CUs and the wall-clock figure read 4/3 of the truth)
+    const size_t lds = (size_t)(160 * 1024) / waves_per_simd - 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k<OP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k<OP>, grid, block, lds, 0, out, 1u, 10, live_lanes);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<OP>, grid, block, 0, 0, out, 7u, iters, live_lanes);
+    hipLaunchKernelGGL(k<OP>, grid, block, lds, 0, out, 7u, iters, live_lanes);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -110,7 +114,7 @@ static void run(int waves_per_simd, int cus, u64 *out, u32 live_lanes = 64)
 template <int OP>
 static void sweep_occ(int cus, u64 *out)
 {
-    for (int w : {1, 2, 4, 8}) run<OP>(w, cus, out);
+    for (int w : {1, 2, 3, 4, 8}) run<OP>(w, cus, out); // 3: the sweep kernels' occupancy since round 5
     printf("\n");
 }
 

@@ -82,10 +82,14 @@ static void run(int waves_per_simd, int cus, u64 *out)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<PAT>, grid, block, 0, 0, out, 1u, 10);
+    // exactly waves_per_simd workgroups on EVERY CU: each asks for a 1/waves_per_simd share of the CU's 160 KB of LDS, so no CU can take
+    // one more (round 6: without it a 3-per-CU grid landed 4 / 2 on some CUs and the wall-clock figure read 4/3 of the truth)
+    const size_t lds = (size_t)(160 * 1024) / waves_per_simd - 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&k<PAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k<PAT>, grid, block, lds, 0, out, 1u, 10);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<PAT>, grid, block, 0, 0, out, 7u, iters);
+    hipLaunchKernelGGL(k<PAT>, grid, block, lds, 0, out, 7u, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;

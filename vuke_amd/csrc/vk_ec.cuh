@@ -137,8 +137,21 @@ VK_DEV u32 scalar_digit(const u32 k[8], u32 bitpos, u32 W)
     return __builtin_amdgcn_alignbit(hi, lo, sh) & ((1u << W) - 1u);
 }
 
+// The scalar parked in LDS ([limb][lane] u32 columns of the wave, VK_PARK): the window geometry is wave-uniform, so the limb pair is two
+// ds_read_b32 at a uniform offset; eight registers less across the whole window loop of the three-wave kernels.
+struct vk_kpark {
+    const u32 *col; // this lane's column, stride 64
+};
+VK_DEV u32 scalar_digit(const vk_kpark &k, u32 bitpos, u32 W)
+{
+    const u32 limb = __builtin_amdgcn_readfirstlane(bitpos >> 5), sh = __builtin_amdgcn_readfirstlane(bitpos & 31);
+    const u32 lo = k.col[limb * 64], hi = limb < 7 ? k.col[(limb + 1) * 64] : 0u;
+    return __builtin_amdgcn_alignbit(hi, lo, sh) & ((1u << W) - 1u);
+}
+
 // digit of window wd (magnitude), updating the running carry; neg = take the point's negative
-VK_DEV u32 window_digit(const u32 k[8], const vk_win_desc &wd, u32 &carry, bool &neg)
+template <typename K>
+VK_DEV u32 window_digit(const K &k, const vk_win_desc &wd, u32 &carry, bool &neg)
 {
     u32 raw = scalar_digit(k, wd.off, wd.bits) + carry;
     const u32 half = 1u << (wd.bits - 1);
@@ -361,7 +374,8 @@ VK_DEV void xyzz_aadd_flip(xyzz &r, const fe &qx, const fe &qy)
 #ifndef VK_LDS_DEPTH
 #define VK_LDS_DEPTH 1 /* power of two; 2 and 4 measured 0.4 % slower than 1: the latency is covered, the gain is the cheaper miss path */
 #endif
-VK_DEV void ecmult_table_lds_xyzz(xyzz &acc, const u32 k[8], const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin, uint4 *slots)
+template <typename K>
+VK_DEV void ecmult_table_lds_xyzz(xyzz &acc, const K &k, const uint4 *__restrict__ table, const vk_win_desc *__restrict__ wins, u32 nwin, uint4 *slots)
 {
     bool inf = true, zone = false;
     // Every addition leaves the NEGATIVE of the sum in the accumulator (xyzz_madd_flip): `minus` says that the accumulator stands for

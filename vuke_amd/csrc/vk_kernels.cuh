@@ -31,6 +31,9 @@
 
 #define VK_BLOCK 256
 #define VK_WIDE_BLOCK 768 /* the wide form of the sweep kernel: twelve waves, three per SIMD, one workgroup per CU */
+#ifndef VK_PARK
+#define VK_PARK 1 /* A/B switch of the LDS parking of c and k in the three-wave forms (vk_sweep_kernel) */
+#endif
 #ifndef VK_MILKSAD_PAIRS
 #define VK_MILKSAD_PAIRS 1 /* pass 1 of the two-wave Milksad instantiation transforms its items two at a time (with three waves on a SIMD the serial
                               MT19937 chain is covered by the other two: pairs are 1.3 % SLOWER there, profiles/r05_three_waves_again.txt) */
@@ -291,6 +294,21 @@ VK_DEV void sweep_counters(const vk_sweep_params &p, const u64 *dg, u32 n_keys, 
     }
 }
 
+// the parking area of the forms that have one; the others declare no LDS for it (not even a word: the dynamic schedule table behind
+// the static LDS must stay 16-byte aligned)
+template <int WORDS>
+struct vk_park_lds {
+    static __device__ __forceinline__ u32 *base()
+    {
+        __shared__ u32 s_park[WORDS];
+        return s_park;
+    }
+};
+template <>
+struct vk_park_lds<0> {
+    static __device__ __forceinline__ u32 *base() { return nullptr; }
+};
+
 // WAVES = the waves per SIMD the instantiation is register-budgeted for.  2: every field element in VGPRs (196 - 206 of them);
 // 3: 168 VGPRs, the coldest values in scratch.  Round 4 measured three waves 4 % SLOWER than two (37 - 46 spilled registers then, and
 // a part that gave the gain back in clock); after round 5's diet the same experiment is +2.2 % on the Milksad sweep and +2.8 % on the
@@ -321,6 +339,14 @@ __global__ void __launch_bounds__(WIDE ? VK_WIDE_BLOCK : VK_BLOCK, WAVES) vk_swe
     // B * TL * 128 B region (a few TLB entries), every access a fully coalesced 16 B per lane
     const u64 nth = TL;
     uint4 *wk = p.work + (u64)unit * ((u64)B * 8 * TL) + tid;
+    // VK_PARK (the three-wave form of compressed-only launches): values that live across the whole elliptic-curve multiplication of an
+    // item but are touched once per item -- the running product c and the scalar k, 8 words each -- wait in LDS ([word][lane] u32 columns
+    // per wave, 16 KB per workgroup) instead of in registers the 168-VGPR budget does not have: 22 -> 12 spilled registers, Milksad sweep
+    // +1.65 %, LCG sweep +-0, same box.  NOT in the wide form: parking c there (its LDS has no room for k as well) measured -6 % on the
+    // sha256 scan (profiles/r06_lds_parking_experiment.txt).
+    constexpr bool PARK_C = VK_PARK && WAVES >= 3 && !WIDE, PARK_K = PARK_C;
+    constexpr int PARK_WORDS = (PARK_C ? 8 : 0) + (PARK_K ? 8 : 0);
+    u32 *park = vk_park_lds<(NT / 64) * PARK_WORDS * 64>::base() + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (PARK_WORDS * 64) + (threadIdx.x & 63u);
     __shared__ u64 s_tile;
     __shared__ uint4 s_gather[(NT / 64) * VK_LDS_DEPTH * VK_LTILE_FULL]; // whole-entry slots per wave (lds_gather_issue)
     // the wave's slot, as a scalar: the LDS-direct loads take their LDS address from M0
@@ -388,7 +414,14 @@ __global__ void __launch_bounds__(WIDE ? VK_WIDE_BLOCK : VK_BLOCK, WAVES) vk_swe
                 }
                 scalar_normalize(k);
                 xyzz Q;
-                ecmult_table_lds_xyzz(Q, k, p.table, p.wins, p.nwin, gtile);
+                if (PARK_K) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) park[(8 + i) * 64] = k[i];
+                    const vk_kpark kp = {park + 8 * 64};
+                    ecmult_table_lds_xyzz(Q, kp, p.table, p.wins, p.nwin, gtile);
+                } else {
+                    ecmult_table_lds_xyzz(Q, k, p.table, p.wins, p.nwin, gtile);
+                }
                 fe e;
                 if (have) {
                     fe_sqr(e, Q.zz);
@@ -399,8 +432,20 @@ __global__ void __launch_bounds__(WIDE ? VK_WIDE_BLOCK : VK_BLOCK, WAVES) vk_swe
                     fe_set_zero(Q.y);
                     fe_set_one(e);
                 }
-                if (b == 0) c = e;
-                else fe_mul(c, c, e);
+                if (PARK_C) {
+                    if (b == 0) {
+                        c = e;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) c.v[i] = park[i * 64];
+                        fe_mul(c, c, e);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) park[i * 64] = c.v[i];
+                } else {
+                    if (b == 0) c = e;
+                    else fe_mul(c, c, e);
+                }
                 work_store(it, nth, Q.x);
                 work_store(it + 2 * nth, nth, Q.y);
                 work_store(it + 4 * nth, nth, e);
@@ -413,6 +458,10 @@ __global__ void __launch_bounds__(WIDE ? VK_WIDE_BLOCK : VK_BLOCK, WAVES) vk_swe
         }
         // ---------------------------------------------------------------- invert
         fe inv;
+        if (PARK_C) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) c.v[i] = park[i * 64];
+        }
         fe_inv(inv, c);
         // ---------------------------------------------------------------- pass 2
         // (as a kernel of its own, budgeted for 3 or 4 waves per SIMD, with every tile's items kept in HBM until it had read them,

@@ -108,7 +108,7 @@ long vkh_matcher_load(const char *path, uint8_t *h160, uint8_t *kind, size_t cap
         std::vector<uint8_t> h, k;
         m.device_targets(h, k);
         *n_device = k.size();
-        if (k.size() <= cap) {
+        if (!k.empty() && k.size() <= cap) { // (an empty vector's data() may be null: not an argument for memcpy)
             memcpy(h160, h.data(), h.size());
             memcpy(kind, k.data(), k.size());
         }
