@@ -503,7 +503,7 @@ def main():
     try:
         eng = vuke_amd.Engine(local_rank, window_bits=args.window_bits, batch=args.batch, blocks_per_cu=args.blocks_per_cu, layout=args.layout)
     except vuke_amd.VkError as exc:
-        if args.layout == 0 or exc.code != ffi.VK_E_HIP:
+        if args.layout == 0 or exc.code not in (ffi.VK_E_NOMEM, ffi.VK_E_HIP):   # NOMEM since round 6 (hipErrorOutOfMemory); HIP from older builds
             raise
         # the 120 GB table did not fit (shared or smaller device): fall back to the library's default geometry
         print(f"bench.py: layout {args.layout} unavailable ({exc}); using the default 24-bit uniform table", file=sys.stderr)

@@ -32,6 +32,15 @@ pub const VK_TARGET_P2WPKH: u8 = 1;
 pub const VK_ADDR_P2PKH_C: u32 = 0;
 pub const VK_ADDR_P2PKH_U: u32 = 1;
 pub const VK_ADDR_P2WPKH: u32 = 2;
+// vk_engine_opts.layout / .algo, vk_search_target.mode (found missing by tests/test_abi_layout.py in round 6: the crate spelled them as
+// bare numbers in its doc comments)
+pub const VK_LAYOUT_UNIFORM: u32 = 0;
+pub const VK_LAYOUT_SIGNED: u32 = 1;
+pub const VK_LAYOUT_SIGNED9: u32 = 1;
+pub const VK_ALGO_CHAIN: u32 = 0;
+pub const VK_SEARCH_EXACT: u32 = 0;
+pub const VK_SEARCH_MASKED: u32 = 1;
+pub const VK_SEARCH_CASCADE: u32 = 2;
 pub const VK_RC_SOURCE: usize = 0;
 pub const VK_RC_KEY_RAW: usize = 1;
 pub const VK_RC_KEY_HEX: usize = 2;

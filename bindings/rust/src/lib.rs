@@ -6,13 +6,28 @@ pub mod hip_range;
 
 use std::ffi::CStr;
 
+/// What a negative return code of the C ABI means (`include/vuke_hip.h`, "Error convention"): errors are values, nothing unwinds
+/// across the boundary -- the library catches `std::bad_alloc` and every other C++ exception at its `extern "C"` frames (ABI note of
+/// round 6), so none of these calls can abort the Rust caller.  Mirrors the reference's `GpuError` (`src/gpu/error.rs:7-20`).
+pub fn error_kind(rc: i32) -> &'static str {
+    match rc {
+        ffi::VK_OK => "ok",
+        ffi::VK_E_NO_DEVICE => "no usable gfx950 device (the caller falls back to its CPU path, like src/main.rs:1582-1587)",
+        ffi::VK_E_HIP => "HIP runtime error, or an unexpected exception inside the library",
+        ffi::VK_E_INVALID_ARG => "invalid argument",
+        ffi::VK_E_UNSUPPORTED => "not supported by this build",
+        ffi::VK_E_NOMEM => "out of memory: a device allocation (table, workspace, hit buffer) or a host staging buffer did not fit",
+        _ => "unknown error code",
+    }
+}
+
 /// `Err(message)` for a negative `VK_E_*` return code, with the engine's `vk_last_error` text.
 pub fn check(engine: *const ffi::VkEngine, rc: i32) -> Result<(), String> {
     if rc == ffi::VK_OK {
         return Ok(());
     }
     let msg = unsafe { CStr::from_ptr(ffi::vk_last_error(engine)) }.to_string_lossy().into_owned();
-    Err(format!("vuke_hip error {rc}: {msg}"))
+    Err(format!("vuke_hip error {rc} ({}): {msg}", error_kind(rc)))
 }
 
 /// Owned engine handle: one per GPU, internally serialised (safe to share between threads).

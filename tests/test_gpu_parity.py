@@ -11,6 +11,8 @@ import pytest
 
 from tests import pyref
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 N = pyref.N
@@ -1425,3 +1427,56 @@ def test_host_allocation_failures_inside_the_engine_come_back_as_vk_e_nomem(heng
         assert total == 0 or nomem >= 1, (name, total)
         assert call() == base, name
     heng.targets_set([], [])
+
+
+def test_the_rust_crates_call_sequence_executed_in_c_against_the_oracle(vko, tmp_path):
+    """SURVEY 8 (f4) while it stays blocked (no rustc / cargo): tests/abi/hip_range_driver.c performs `impl Source for HipRangeSource`
+    (bindings/rust/src/hip_range.rs, scan mode) through include/vuke_hip.h and the shipped libvuke_hip.so -- targets_set, per spec a sweep
+    of both key forms with the hits_dropped retry (forced here by a hit buffer of 3 records), sort by (seed, slot), the label of every
+    hit as `seed + label_suffix(spec, slot)`, targets cleared.  Its output against the oracle: the reference's labels
+    (vko.transform_label = Transform::apply_batch's strings, tests/golden/labels.json), address kinds, keys and ProcessStats counters.
+    tests/test_abi_layout.py holds the driver's text to the Rust source's."""
+    import subprocess
+    from vuke_amd import _ffi as ffi
+    exe = tmp_path / "hip_range_driver"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-D_POSIX_C_SOURCE=200809L", "-I", os.path.join(ROOT, "include"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "abi", "hip_range_driver.c"), "-L", os.path.join(ROOT, "vuke_amd", "lib"), "-lvuke_hip",
+                    "-Wl,-rpath," + os.path.join(ROOT, "vuke_amd", "lib")], check=True, capture_output=True, text=True)
+    start, end = 1000, 1000 + 2999
+    specs = [(ffi.T_LCG, ffi.VARIANT_ALL, 1, 10), (ffi.T_LCG, 2, 0, 10), (ffi.T_XORSHIFT, ffi.VARIANT_ALL, 0, 10), (ffi.T_SHA256_CHAIN, ffi.VARIANT_ALL, 0, 3),
+             (ffi.T_SHA256_CHAIN, 2, 0, 4), (ffi.T_MILKSAD, ffi.VARIANT_ALL, 0, 10), (ffi.T_SHA256, ffi.VARIANT_ALL, 0, 10)]
+    rnd = random.Random(64)
+    lines, addrs = [], []
+    for kind, var, en, depth in specs:
+        osp = vko.spec(kind, var, en, depth)
+        slots = vko.slots_per_input(osp)
+        for j in range(9):                                  # nine planted keys per spec > the 3-record buffer: the retry loop runs
+            seed, sub = rnd.randrange(start, end + 1), rnd.randrange(slots)
+            key = vko.transform_key(osp, seed, sub)
+            if key is None:
+                continue
+            d = vko.derive(key)
+            which = j % 3
+            lines.append("%s %d" % (bytes(d.h160_u if which == 1 else d.h160_c).hex(), 1 if which == 2 else 0))
+            addrs.append((d.p2pkh_compressed, d.p2pkh_uncompressed, d.p2wpkh)[which].decode())
+    tf = tmp_path / "targets.txt"
+    tf.write_text("\n".join(lines) + "\n")
+    args = [str(exe), str(tf), str(start), str(end), "3"] + [str(x) for sp in specs for x in sp]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    got, cur = [], []
+    for ln in r.stdout.splitlines():
+        if ln.startswith("stats "):
+            got.append((cur, [int(x) for x in ln.split()[1:]]))
+            cur = []
+        else:
+            cur.append(tuple(ln.rsplit(" ", 2)))
+    assert len(got) == len(specs)
+    m = vko.Matcher(addrs)
+    for (kind, var, en, depth), (hits, stats) in zip(specs, got):
+        osp = vko.spec(kind, var, en, depth)
+        ost, ohits = vko.sweep(osp, start, end, flags=3, matcher=m, nthreads=8)
+        want = [(vko.transform_label(osp, h["seed"], h["sub_index"]), str(h["addr_kind"]), h["privkey"].hex()) for h in sorted(ohits, key=lambda h: (h["seed"], h["sub_index"]))]
+        assert hits == want, (kind, var, en, depth, hits[:3], want[:3])
+        assert stats[:3] == [ost["inputs"], ost["keys"], ost["matches"]], (kind, stats, ost)
+        assert len(want) >= 5 and stats[3] >= 2, (kind, len(want), stats)     # the retry loop did run

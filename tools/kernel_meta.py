@@ -44,11 +44,17 @@ def load_rates():
 
 
 def price_for(vgpr, agpr=0, rates=None):
-    """(waves per SIMD the allocation allows, {class: cycles}) from the measured occupancies (nearest one not above)."""
+    """(waves per SIMD the allocation allows, {class: cycles} at that occupancy -- the nearest measured one not above)."""
     rates = rates or load_rates()
     waves = max(1, min(8, 512 // max(vgpr + agpr, 1)))
     have = max(w for w in rates if w <= waves)
     return waves, rates[have]
+
+
+def best_price():
+    """{class: cycles}: the smallest issue cost of each class at any occupancy -- what the pipe sustains; the FLOOR of a mix is priced
+    with these (tools/ubench_rates.py says why the price at the kernel's own occupancy is not one)."""
+    return json.load(open(os.path.join(ROOT, "profiles", "valu_rates.json")))["best_any_occupancy"]
 
 
 FAST = ("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_xor_b32", "v_and_b32", "v_or_b32", "v_not_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32",
@@ -105,7 +111,9 @@ def unit(src, extra, tag):
             row["valu_static_count"] = n
             waves, price = price_for(row["vgpr"], row["agpr"])
             row["waves_per_simd"] = waves
-            row["cycles_per_valu_inst_floor"] = round(sum(price[k] * v for k, v in m.items()) / n, 3)
+            best = best_price()
+            row["cycles_per_valu_inst_floor"] = round(sum(best[k] * v for k, v in m.items()) / n, 3)
+            row["cycles_per_valu_inst_priced_at_occupancy"] = round(sum(price[k] * v for k, v in m.items()) / n, 3)
         rows.append(row)
     return rows
 

@@ -122,16 +122,22 @@ if mix.get("SQ_INSTS_VALU"):
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import kernel_meta as kmeta
             waves, price = kmeta.price_for(row["vgpr"], row["agpr"])
+            best = kmeta.best_price()
             sm = dict(row["valu_static_mix"])
             sm.pop("mad64", None)
             rest = sum(sm.values())
-            rest_price = sum(price[k] * v for k, v in sm.items()) / rest if rest else price["full"]
             share = out["valu_mix"]["int64_share"]
+
+            def priced(pr):
+                rest_price = sum(pr[k] * v for k, v in sm.items()) / rest if rest else pr["full"]
+                return share * pr["mad64"] + (1.0 - share) * rest_price
             out["waves_per_simd"] = waves
-            out["cycles_per_valu_inst_floor"] = share * price["mad64"] + (1.0 - share) * rest_price
-            out["cycles_per_valu_inst_floor_note"] = (f"dynamic 64-bit share (SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU) at {price['mad64']:.2f} cycles + the rest at the static mix of "
-                                                      f"the code object (profiles/kernel_meta.json), every class priced at the kernel's own occupancy of {waves} waves per SIMD "
-                                                      "(profiles/valu_rates.json: tools/ubench_block.hip + tools/ubench_carry.hip, smallest figure of each class)")
+            out["cycles_per_valu_inst_floor"] = priced(best)
+            out["cycles_per_valu_inst_priced_at_occupancy"] = priced(price)
+            out["cycles_per_valu_inst_floor_note"] = ("dynamic 64-bit share (SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU) + the rest at the static mix of the code object "
+                                                      "(profiles/kernel_meta.json), every class at the best issue rate it reaches at ANY occupancy (profiles/valu_rates.json: "
+                                                      "tools/ubench_block.hip + tools/ubench_carry.hip) = what the pipes sustain for this mix; `priced_at_occupancy` = the same mix "
+                                                      f"at the single-class rates of the kernel's own {waves} waves per SIMD (not a floor: a real mix overlaps its classes across waves)")
             if "cycles_per_valu_inst_per_simd" in out:
                 out["issue_efficiency"] = out["cycles_per_valu_inst_floor"] / out["cycles_per_valu_inst_per_simd"]
                 w = counters

@@ -11,7 +11,7 @@ lg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 lo = int(sys.argv[2]) if len(sys.argv) > 2 else 3_000_000_000
 hi = lo + (1 << lg) - 1
 vko.build()
-e = vuke_amd.Engine(0, layout=1, batch=256, blocks_per_cu=2)
+e = vuke_amd.Engine(0, layout=1, batch=256)   # blocks_per_cu 0: the form the engine picks (both key forms: the 768-lane workgroups)
 out = []
 for kind, okind, name in ((ffi.T_MILKSAD, vko.T_MILKSAD, "milksad"), (ffi.T_LCG, vko.T_LCG, "lcg")):
     t = time.perf_counter(); st, _ = e.sweep(ffi.spec(kind), lo, hi, flags=3); tg = time.perf_counter() - t

@@ -5,8 +5,11 @@
 
 For every class the static / dynamic instruction mix of a kernel is priced with (tools/kernel_meta.py, tools/pmc_summary.py) and for
 every measured number of resident waves per SIMD: the SMALLEST wall-clock cost (shader cycles per wave-instruction per SIMD) any
-member of the class reached -- a floor, so that `measured cycles per instruction >= priced floor` holds by construction of the
-model and a summary that violates it is a defect (bench.py refuses it).  The multiplier class also takes the multiply-add / carry
+member of the class reached, and `best_any_occupancy`: the smallest over all occupancies = what the pipe sustains for that class
+when the SIMD has enough waves to choose from.  The FLOOR a kernel's mix is held against is priced with the latter (`measured
+cycles per instruction >= floor`; bench.py refuses a summary that violates it); the price at the kernel's own occupancy is
+reported beside it but is NOT a floor: a real mix at three waves issues ~2 % faster than the sum of its classes' single-class
+streams at three waves (waves in different classes at the same moment overlap better than three waves of one class).  The multiplier class also takes the multiply-add / carry
 patterns of tools/ubench_carry.hip (several instructions per asm block: no s_nop between them, as in the shipped field layer)."""
 import json
 import re
@@ -44,11 +47,13 @@ def main():
             if vals:
                 row[cls] = min(vals)
         rates[str(w)] = row
-    json.dump({"tool": "tools/ubench_rates.py", "sources": [a, b], "unit": "shader cycles per wave-instruction per SIMD (wall), smallest member of the class",
+    best = {cls: min(row[cls] for row in rates.values() if cls in row) for cls in CLASSES}
+    json.dump({"tool": "tools/ubench_rates.py", "best_any_occupancy": best, "sources": [a, b], "unit": "shader cycles per wave-instruction per SIMD (wall), smallest member of the class",
                "classes": CLASSES, "waves_per_simd": rates, "per_instruction": {str(w): {k: min(v) for k, v in ins.items()} for w, ins in sorted(per.items())},
                "multiplier_patterns": {str(w): v for w, v in sorted(carry.items())}}, open(out, "w"), indent=1)
     for w, row in rates.items():
         print(w, row)
+    print("best", best)
 
 
 if __name__ == "__main__":
