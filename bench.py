@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 # Integer-VALU peak: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s.  This is the
 # 16-lanes-per-clock class that carries this path's arithmetic (v_mad_u64_u32, v_addc_co_u32, v_add3, v_alignbit:
-# 30-38 T measured, profiles/r01_ubench_valu_rates.txt); plain VOP2 adds / logic issue ~1.5x faster (52-58 T) and make
+# 30-38 T measured, profiles/archive/r01_ubench_valu_rates.txt); plain VOP2 adds / logic issue ~1.5x faster (52-58 T) and make
 # up ~15 % of the mix, so a fraction slightly above the naive bound is possible in principle.
 PEAK_INT32 = 256 * 4 * 16 * 2.4e9
 HBM_PEAK = 8.0e12
@@ -454,7 +454,7 @@ def main():
     if args.layout is None and args.window_bits is None:
         if args.strong:
             # ONE 2^32 sweep end to end: allocating and building the 120 GB table costs 0.4-5 s (hipMalloc of 120 GB varies
-            # that much between boxes), more than it saves; by measured wall time (profiles/r02_strong_geometry.txt) the
+            # that much between boxes), more than it saves; by measured wall time (profiles/archive/r02_strong_geometry.txt) the
             # ten-window table wins on one GPU and the eleven-window table from two GPUs up
             args.layout, args.window_bits = 1, (26 if world_hint == 1 else 24)   # signed windows: 18 GB / 4 GB (round 4; unsigned 43 / 11.8 GB before)
         else:
@@ -582,8 +582,8 @@ def main():
         a2.strong = True
         sync()
         ts0 = time.perf_counter()
-        # by measured wall time (profiles/r02_strong_geometry.txt) the big table cannot pay for itself inside one sweep: ten signed
-        # windows on one GPU (18 GB: the rate of the unsigned 26-bit table at 0.4 of its size, profiles/r04_signed_geometries.txt),
+        # by measured wall time (profiles/archive/r02_strong_geometry.txt) the big table cannot pay for itself inside one sweep: ten signed
+        # windows on one GPU (18 GB: the rate of the unsigned 26-bit table at 0.4 of its size, profiles/archive/r04_signed_geometries.txt),
         # eleven (4 GB) from two GPUs
         g_bits = 26 if world == 1 else 24
         try:

@@ -128,7 +128,7 @@ def test_product_does_not_touch_oracle():
 
 def test_coalescer_lint_record_covers_the_kernel_sources_in_the_tree():
     """tools/lint_coalescer.py (the mechanical check for the LLVM register-coalescer defect behind round 1's short-fold
-    failure, profiles/r02_short_fold_root_cause.txt) was run on exactly these kernel sources and found nothing."""
+    failure, profiles/archive/r02_short_fold_root_cause.txt) was run on exactly these kernel sources and found nothing."""
     import json
     import bench
     rec = json.load(open(os.path.join(ROOT, "profiles", "lint_coalescer.json")))
@@ -158,14 +158,17 @@ def test_profile_files_cited_in_the_documents_exist():
     them (the tag carries the round and a letter), and a stale citation would point the reader at nothing."""
     import glob
     import re
-    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("tools", "README.md")):
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("tools", "README.md"), os.path.join("docs", "DESIGN_rounds_1-5.md")):
         text = open(os.path.join(ROOT, doc)).read()
-        for cited in set(re.findall(r"profiles/[A-Za-z0-9_.*{},\-]+", text)):
+        for cited in set(re.findall(r"profiles/[A-Za-z0-9_.*{},/\-]+", text)):   # sub-directories too: profiles/archive/ holds rounds 1 - 4
             cited = cited.rstrip(".,)")
             pats = [cited]
-            m = re.match(r"(.*)\{([^}]*)\}(.*)", cited)
-            if m:
-                pats = [m.group(1) + x + m.group(3) for x in m.group(2).split(",")]
+            while any("{" in p for p in pats):   # every brace group, not only the first
+                nxt = []
+                for p in pats:
+                    m = re.match(r"(.*?)\{([^}]*)\}(.*)", p)
+                    nxt += [m.group(1) + x + m.group(3) for x in m.group(2).split(",")] if m else [p.replace("{", "")]
+                pats = nxt
             for p in pats:
                 assert glob.glob(os.path.join(ROOT, p)) or glob.glob(os.path.join(ROOT, p + "*")), (doc, p)
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Analyzer brute force (vk_search_kernel) on one GPU: seeds/s of an exhaustive exact search over the
 2^32 Milksad space (target absent: every seed is tried), of a masked LCG search and of a depth-10 sha256_chain search.
-Prints one JSON line per search; profiled by tools/profile.sh-style rocprofv3 passes (profiles/r02b_search_*)."""
+Prints one JSON line per search; profiled by tools/profile.sh-style rocprofv3 passes (profiles/archive/r02b_search_*)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vuke_amd

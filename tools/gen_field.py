@@ -10,9 +10,9 @@ even column carries through vcc, the odd one through a scratch SGPR pair.  A col
 column two before it takes the pair (counter, 0) as the SOURCE addend of its first multiply-add -- the accumulator itself
 is a fresh early-clobber output -- so the compiler only has to put a zero next to the counter (one plain v_mov_b32) instead
 of copying a 64-bit pair into the tied accumulator (v_mov_b64, a 16-lane-class instruction, plus the s_nop the tied form
-drew after every statement): +1.3 % on the Milksad sweep, same-box (profiles/r02_kernel_experiments.txt).
+drew after every statement): +1.3 % on the Milksad sweep, same-box (profiles/archive/r02_kernel_experiments.txt).
 
-Operand discipline of every statement emitted here (audited in round 2, profiles/r02_short_fold_root_cause.txt): a
+Operand discipline of every statement emitted here (audited in round 2, profiles/archive/r02_short_fold_root_cause.txt): a
 statement of more than one instruction either early-clobbers its outputs ("=&v" / "=&s") or, where an operand is
 read-write ("+v"), every plain input is read only by the instruction that overwrites the register it could share (the
 reduction's t[8+i] is the high half of its own accumulator pair); carries never leave a statement in vcc, only in a

@@ -2,7 +2,7 @@
 """Register / scratch / LDS metadata of every gfx950 kernel in the shipped sources: compiles each translation unit with
 `hipcc -S --offload-device-only` (the flags of vuke_amd/csrc/build.sh) and prints the amdhsa metadata of its kernels.
 
-    python tools/kernel_meta.py [--json profiles/r03_kernel_meta.json]
+    python tools/kernel_meta.py [--json profiles/archive/r03_kernel_meta.json]
 
 (The same numbers `llvm-readelf --notes` shows for the code objects inside libvuke_hip.so; reading them from the assembly
 avoids unbundling the fat binary.)"""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build-time lint for an LLVM register-coalescer miscompile that hit the generated field code (round 1, "short fold").
 
-Root cause found in round 2 (profiles/r02_short_fold_root_cause.txt): when outputs of two inline-asm statements are copied
+Root cause found in round 2 (profiles/archive/r02_short_fold_root_cause.txt): when outputs of two inline-asm statements are copied
 into the halves of one wide register tuple (e.g. r.v[0..2] from the fold statement, r.v[3] from the carry chain before
 it), the coalescer may join the 32-bit values into sub-registers of different tuples and then mark the asm output that fed
 the dropped lane `dead` -- the lane of the surviving tuple keeps a stale value.  No hazard, no missing clobber: the MIR is

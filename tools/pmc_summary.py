@@ -112,7 +112,7 @@ if mix.get("SQ_INSTS_VALU"):
     # dynamic mix of the dominant kernel: share of 64-bit integer VALU instructions (the multiplier v_mad_u64_u32, and
     # v_lshl_add_u64 in the SHA-512 kernels); the floor prices that share at the multiplier's issue cost and the rest with the
     # static mix of the code object (tools/kernel_meta.py: cycles per wave-instruction per SIMD with two waves resident,
-    # profiles/r03_ubench_valu_rates.txt)
+    # profiles/archive/r03_ubench_valu_rates.txt)
     out["valu_mix"] = {"int64_share": mix.get("SQ_INSTS_VALU_INT64", 0.0) / mix["SQ_INSTS_VALU"], "int32_share": mix.get("SQ_INSTS_VALU_INT32", 0.0) / mix["SQ_INSTS_VALU"]}
     km_path = os.path.join(dst, "kernel_meta.json")
     if os.path.exists(km_path):

@@ -1,5 +1,5 @@
 """A/B of sweep-kernel variants on the bench geometry (VUKE_HIP_LIB selects the library; written for round 4's split-pass-2
-experiment, profiles/r04_split_pass2_experiment.txt): kernel time and wall time per 2^28-key
+experiment, profiles/archive/r04_split_pass2_experiment.txt): kernel time and wall time per 2^28-key
 block of config 2 (Milksad, compressed) and per 2^25-input block of config 3 (sha256, both hash160s, 1 M-slot probe table),
 after one untimed block (a variant may size its workspace on first use).  Digests are printed so that two variants can be
 compared: they must be equal.

@@ -1,5 +1,5 @@
 // ubench_carry.hip -- round 5: is the 8.75-cycle single-wave issue interval of v_mad_u64_u32 / v_addc_co_u32
-// (profiles/r03_ubench_valu_rates.txt) a property of the instruction class or of the carry register being reused?
+// (profiles/archive/r03_ubench_valu_rates.txt) a property of the instruction class or of the carry register being reused?
 // Patterns (inline asm, independent accumulators, all CUs, 1 / 2 / 3 waves per SIMD):
 //   mad_vcc     8 multiply-adds, every one writes its carry to vcc                      (round 3's measurement: WAW on vcc)
 //   mad_8sgpr   8 multiply-adds, each writes its carry to its own SGPR pair             (no reuse within 8 instructions)

@@ -49,7 +49,7 @@ __device__ __constant__ const u64 VK_K512[80] = {
 // A 64-bit value from its halves AS A REGISTER PAIR.  Written as (hi << 32) | lo the compiler sees two zero-extended
 // summands, reassociates every SHA-512 addition into one 64-bit add per half and materialises the zero halves with
 // v_mov: 8 003 VALU instructions per PBKDF2 iteration; as a bit-cast of a two-element vector the pair stays a pair and
-// each addition is ONE v_lshl_add_u64 (4.2 issue cycles, like a 32-bit v_alignbit: profiles/r03_ubench_valu_rates.txt):
+// each addition is ONE v_lshl_add_u64 (4.2 issue cycles, like a 32-bit v_alignbit: profiles/archive/r03_ubench_valu_rates.txt):
 // 6 602 instructions per iteration -- 3 086 v_alignbit, 1 757 v_bitop3, 1 478 v_lshl_add_u64, 236 shifts.
 typedef u32 vk_u32x2 __attribute__((ext_vector_type(2)));
 VK_DEV u64 pack64(u32 lo, u32 hi)

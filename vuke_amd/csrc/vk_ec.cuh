@@ -193,7 +193,7 @@ VK_DEV void fe_cond_negate(fe &y, bool neg)
 // a quad read one whole entry per instruction (16 lines per instruction, ~50 G entries/s), and the load unit hands the
 // quarters to their owner through the wave's LDS slot.  Every lane of the wave must take part (no divergence around
 // these calls).  (The per-lane and the register-staged forms of the sweep's table read, and its Jacobian accumulator,
-// were A/B variants until round 3: profiles/r01_table_read_experiments.txt; last in the sources at commit 4b24351.)
+// were A/B variants until round 3: profiles/archive/r01_table_read_experiments.txt; last in the sources at commit 4b24351.)
 // No staging registers: the load unit writes lane i's 16 bytes to slot + 16 i.  Round r of a whole-entry read fetches,
 // in lane L, quarter L & 3 of the entry owned by quad lane r; the owner then finds its 64 bytes contiguous in round
 // (lane & 3) at lanes (lane & ~3) .. +3.  The x-only read does the same with lane pairs and halves of x.  A round is 65

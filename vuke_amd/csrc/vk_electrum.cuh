@@ -26,8 +26,9 @@
 
 // big-endian word i of seed || 0x80 || 0.. || 64-bit bit length of (prefix + len) bytes, read from the input bytes themselves
 // (any length, any alignment); `last` = index of the low word of the length field.  A word that lies entirely inside the seed
-// comes from the two aligned dwords around it (v_alignbyte_b32 + byte swap): the second dword may reach up to three bytes
-// beyond the seed, which is why the device copy of the input carries VK_STRING_SLACK bytes behind the last string.
+// comes from the two aligned dwords around it (v_alignbyte_b32 + byte swap): the second dword reaches up to four bytes
+// beyond the seed (all four when the word's address is aligned: p[1] is then entirely behind it), which is why the device copy of
+// the input carries VK_STRING_SLACK = 8 bytes behind the last string.
 #define VK_STRING_SLACK 8
 VK_DEV u32 electrum_tail_word_bytes(const unsigned char *__restrict__ seed, u32 i, u32 len, u32 last, u32 prefix)
 {

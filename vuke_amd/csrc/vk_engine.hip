@@ -1368,7 +1368,7 @@ static int run_ring(vk_engine *e, u32 groups, u32 iters, u32 chunk_iters, typena
         e->ring_waves_per_simd = std::max(1, std::min(nb, ne)); // a 256-thread block is one wave on each SIMD of its CU
     }
     // Workers: as many waves per SIMD as keep EVERY worker busy (workers <= groups) and every SIMD equally loaded -- a whole
-    // number of waves per SIMD.  Measured (tools/probe_ring.py, profiles/r03_ring_probe.txt): at the config's 100 000 inputs
+    // number of waves per SIMD.  Measured (tools/probe_ring.py, profiles/archive/r03_ring_probe.txt): at the config's 100 000 inputs
     // = 1 563 groups, 1 024 workers (one per SIMD) finish in 84 ms / 609 ms (MultiBit / Electrum); 1 563 workers take 108 /
     // 737 ms (the dispatcher doubles some CUs up and leaves others with one wave, and the doubled ones set the time) and 2 048
     // workers 93 / 639 ms (a quarter of them spin for a group at any time).

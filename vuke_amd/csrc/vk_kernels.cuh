@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(WIDE ? VK_WIDE_BLOCK : VK_BLOCK, WAVES) vk_swe
         // ---------------------------------------------------------------- pass 2
         // (as a kernel of its own, budgeted for 3 or 4 waves per SIMD, with every tile's items kept in HBM until it had read them,
         // pass 2 made the Milksad sweep 4.8 % SLOWER and the sha256 scan 0 - 1.5 % slower, same box, three rounds each:
-        // profiles/r04_split_pass2_experiment.txt; the variant's last source is commit fe19f6c)
+        // profiles/archive/r04_split_pass2_experiment.txt; the variant's last source is commit fe19f6c)
         sweep_pass2<KIND, UNCOMP, TL>(p, wk, B, tile_off, inv, r, sub, dg, n_keys, n_match, tail);
     }
     // ------------------------------------------------------------------- counters

@@ -373,7 +373,7 @@ int main(int argc, char **argv)
         vk_engine_opts opts{};
         opts.window_bits = window_bits;
         // The table geometry follows the size of the job (keys = inputs x slots of every transform), by measured END-TO-END time
-        // (profiles/r02_strong_geometry.txt, profiles/r03_probe_c2_cli.txt): the 120 GB signed-window table sweeps a 2^32-key scan in
+        // (profiles/archive/r02_strong_geometry.txt, profiles/archive/r03_probe_c2_cli.txt): the 120 GB signed-window table sweeps a 2^32-key scan in
         // 2.6 s instead of 3.4 s, but allocating and releasing 120 GB costs 0.4 s on a quiet box and 2 - 6 s when the memory has just
         // been freed by another process (the driver scrubs VRAM), so it only pays from several sweeps' worth of keys on; in between
         // ten signed windows (18 GB, built in 15 ms; until round 4 the unsigned W = 26 table, 43 GB, at the same sweep rate) are the
