@@ -144,11 +144,15 @@ typedef struct vk_engine_opts {
                               8..29 for the signed layout (0 = 29: nine windows, 120 GB) */
     uint32_t batch;        /* keys per lane sharing one field inversion (0 = default 128; the workspace, 128 B x batch x
                               lanes, is allocated when the engine is created) */
-    uint32_t blocks_per_cu;/* 256-thread workgroups per CU to launch.  0 = per launch, what the sweep kernel instantiation that
-                              runs it is built for: three (three waves per SIMD) for launches that hash compressed keys only --
-                              two for the sha256 family --, two where uncompressed keys are hashed (their LDS table lets two
-                              workgroups share a CU); the workspace is sized for three.  A value given here is used for every
-                              launch; tiles are handed out dynamically, so it only sizes the grid and the workspace */
+    uint32_t blocks_per_cu;/* 256-thread workgroups per CU to launch.  0 = per launch, the form that measured fastest for the
+                              transform kind and the key forms hashed (vk_sweep_tu.hip: vk_sweep_design_form): three workgroups
+                              per CU (three waves per SIMD) for launches that hash compressed keys only -- two for the sha256
+                              family --, and ONE workgroup of 768 threads per CU (three waves per SIMD around one LDS schedule
+                              table, tiles per wave) where uncompressed keys are hashed; the workspace is sized for three tile
+                              owners per SIMD row (6.4 GB at batch 256).  A value >= 3 given here
+                              keeps those forms and sizes grid and workspace; a value below 3 runs every launch in the
+                              two-waves-per-SIMD form on that many 256-thread workgroups per CU.  Tiles are handed out
+                              dynamically, so the value never changes results */
     uint32_t layout;       /* VK_LAYOUT_*: 0 = uniform unsigned window_bits-wide windows (default) */
     void *stream;          /* hipStream_t to run on (NULL = engine creates its own) */
     uint32_t algo;         /* VK_ALGO_CHAIN (0); other values are rejected */
