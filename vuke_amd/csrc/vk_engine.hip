@@ -1370,8 +1370,9 @@ static int run_ring(vk_engine *e, u32 groups, u32 iters, u32 chunk_iters, typena
     // Workers: as many waves per SIMD as keep EVERY worker busy (workers <= groups) and every SIMD equally loaded -- a whole
     // number of waves per SIMD.  Measured (tools/probe_ring.py, profiles/archive/r03_ring_probe.txt): at the config's 100 000 inputs
     // = 1 563 groups, 1 024 workers (one per SIMD) finish in 84 ms / 609 ms (MultiBit / Electrum); 1 563 workers take 108 /
-    // 737 ms (the dispatcher doubles some CUs up and leaves others with one wave, and the doubled ones set the time) and 2 048
-    // workers 93 / 639 ms (a quarter of them spin for a group at any time).
+    // 737 ms and 2 048 workers 93 / 639 ms (a quarter of them spin for a group at any time).  Why even ONE doubled CU costs 5 %
+    // (profiles/r06_ring_worker_probe.txt): the ring is FIFO, every group gets one chunk per trip through the queue, a group that
+    // meets a two-wave worker falls most of a chunk time behind for good, and the call ends with the most delayed group.
     int wps = e->ring_waves_per_simd;
     if (e->dbg_ring_wps) wps = std::min(wps, (int)e->dbg_ring_wps);
     const u32 simds = (u32)e->cu_count * 4u;
